@@ -1,0 +1,152 @@
+"""ctypes front-end of the CPU oracle (oracle/picasso_oracle.c).
+
+TEST INFRASTRUCTURE.  Import only from tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package (picasso_amd) must never
+import this module.
+
+Every function mirrors a reference function; see the C file for file:line.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libpicasso_oracle.so")
+_lib = None
+
+DTYPE_CODES = {
+    np.dtype("uint16"): 0, np.dtype("uint8"): 1, np.dtype("int16"): 2,
+    np.dtype("uint32"): 3, np.dtype("int32"): 4, np.dtype("float32"): 5,
+}
+METHODS = {"sigma": 0, "sigmaxy": 1}
+
+
+def build(force: bool = False) -> str:
+    """Compile the oracle with gcc (seconds).  Returns the .so path."""
+    src = os.path.join(_HERE, "picasso_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+    return _SO
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = ctypes.CDLL(_SO)
+        i64, f64, i32 = ctypes.c_int64, ctypes.c_double, ctypes.c_int
+        p = ctypes.c_void_p
+        L.orc_identify.argtypes = [p, i32, i64, i64, i64, i32, f64, p, i64, i64,
+                                   p, p, p, p, i64, p, i32]
+        L.orc_identify.restype = i32
+        L.orc_get_spots.argtypes = [p, i32, i64, i64, i64, p, p, p, i64, i32, f64, f64, f64, p]
+        L.orc_get_spots.restype = i32
+        L.orc_gaussmle.argtypes = [p, i64, i32, f64, i32, i32, p, p, p, p, i32]
+        L.orc_gaussmle.restype = i32
+        L.orc_initial_parameters.argtypes = [p, i64, i32, p]
+        L.orc_initial_parameters.restype = i32
+        L.orc_unit_vectors.argtypes = [i32, p, p]
+        L.orc_max_threads.restype = i32
+        _lib = L
+    return _lib
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def max_threads() -> int:
+    return int(lib().orc_max_threads())
+
+
+def normalise_roi(roi, Y, X):
+    """numpy slice semantics of ``frame[y0:y1, x0:x1]`` (localize.py:331)."""
+    if roi is None:
+        return None
+    (y0, x0), (y1, x1) = roi
+    ys, ye, _ = slice(y0, y1).indices(Y)
+    xs, xe, _ = slice(x0, x1).indices(X)
+    return np.array([ys, xs, max(ye, ys), max(xe, xs)], np.int64)
+
+
+def frame_range(frame_bounds, F):
+    """Inclusive frame range of localize.py:395-401."""
+    lo, hi = 0, F
+    if frame_bounds is not None:
+        if frame_bounds[0] is not None:
+            lo = max(frame_bounds[0], lo)
+        if frame_bounds[1] is not None:
+            hi = min(frame_bounds[1], hi)
+    return lo, hi
+
+
+def identify(movie, min_ng, box, roi=None, frame_bounds=None, threads=1):
+    """-> frame, y, x (int64) and net_gradient (float32), frame/y/x ordered."""
+    movie = np.ascontiguousarray(movie)
+    F, Y, X = movie.shape
+    code = DTYPE_CODES[movie.dtype]
+    r = normalise_roi(roi, Y, X)
+    lo, hi = frame_range(frame_bounds, F)
+    cap = max(1024, F * 64)
+    while True:
+        fr = np.empty(cap, np.int64); yy = np.empty(cap, np.int64)
+        xx = np.empty(cap, np.int64); ng = np.empty(cap, np.float32)
+        n = ctypes.c_int64(0)
+        rc = lib().orc_identify(_ptr(movie), code, F, Y, X, int(box), float(min_ng),
+                                _ptr(r) if r is not None else None, lo, hi,
+                                _ptr(fr), _ptr(yy), _ptr(xx), _ptr(ng), cap,
+                                ctypes.byref(n), int(threads))
+        if rc < 0:
+            raise ValueError(f"orc_identify failed ({rc})")
+        if rc == 0:
+            k = n.value
+            return fr[:k].copy(), yy[:k].copy(), xx[:k].copy(), ng[:k].copy()
+        cap = n.value
+
+
+def get_spots(movie, frame, y, x, box, camera_info):
+    movie = np.ascontiguousarray(movie)
+    F, Y, X = movie.shape
+    frame = np.ascontiguousarray(frame, np.int64)
+    y = np.ascontiguousarray(y, np.int64)
+    x = np.ascontiguousarray(x, np.int64)
+    N = len(frame)
+    spots = np.empty((N, box, box), np.float32)
+    lib().orc_get_spots(_ptr(movie), DTYPE_CODES[movie.dtype], F, Y, X, _ptr(frame), _ptr(y),
+                        _ptr(x), N, int(box), float(camera_info["Baseline"]),
+                        float(camera_info["Sensitivity"]), float(camera_info["Gain"]), _ptr(spots))
+    return spots
+
+
+def gaussmle(spots, eps, max_it, method="sigmaxy", threads=1):
+    spots = np.ascontiguousarray(spots, np.float32)
+    N, box, _ = spots.shape
+    if method not in METHODS:
+        raise ValueError("Method not available.")
+    thetas = np.zeros((N, 6), np.float32)
+    crlbs = np.full((N, 6), np.inf, np.float32)
+    ll = np.zeros(N, np.float32)
+    it = np.zeros(N, np.int32)
+    rc = lib().orc_gaussmle(_ptr(spots), N, box, float(eps), int(max_it), METHODS[method],
+                            _ptr(thetas), _ptr(crlbs), _ptr(ll), _ptr(it), int(threads))
+    if rc != 0:
+        raise ValueError(f"orc_gaussmle failed ({rc})")
+    return thetas, crlbs, ll, it
+
+
+def initial_parameters(spots):
+    spots = np.ascontiguousarray(spots, np.float32)
+    N, box, _ = spots.shape
+    th = np.zeros((N, 6), np.float32)
+    lib().orc_initial_parameters(_ptr(spots), N, box, _ptr(th))
+    return th
+
+
+def unit_vectors(box):
+    ux = np.zeros((box, box), np.float32); uy = np.zeros((box, box), np.float32)
+    lib().orc_unit_vectors(int(box), _ptr(ux), _ptr(uy))
+    return ux, uy

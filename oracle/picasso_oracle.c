@@ -1,0 +1,603 @@
+/*
+ * picasso_oracle.c — CPU restatement of the reference's localization hot path.
+ *
+ * TEST INFRASTRUCTURE.  This file is the parity oracle and the timed CPU
+ * baseline ("port").  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load it; the product path (picasso_amd/) never does.
+ *
+ * It restates, in plain C, the algorithm of these reference functions
+ * (paths relative to the reference tree, jungmannlab/picasso v0.10.3):
+ *
+ *   picasso/localize.py:97-134    _local_maxima
+ *   picasso/localize.py:153-181   _gradient_at
+ *   picasso/localize.py:202-244   _net_gradient
+ *   picasso/localize.py:247-292   identify_in_image
+ *   picasso/localize.py:295-337   identify_in_frame (ROI crop, float32 cast)
+ *   picasso/localize.py:340-421   identify_by_frame_number (frame bounds)
+ *   picasso/localize.py:917-931   _cut_spots_numba
+ *   picasso/localize.py:1101-1112 _to_photons
+ *   picasso/gaussmle.py:28-168    initial parameters
+ *   picasso/gaussmle.py:268-383   integrated-Gaussian model and derivatives
+ *   picasso/gaussmle.py:533-742   _mlefit_sigma, _update_theta_sigma, CRLB
+ *   picasso/gaussmle.py:745-954   _mlefit_sigmaxy, _update_theta_sigmaxy, CRLB
+ *
+ * Arithmetic follows numba's type promotion, which is what the reference
+ * executes in production: int64 (op) float32 -> float64, float64 literal (op)
+ * float32 -> float64, float32 ** int -> float32, results rounded to float32
+ * only where the reference stores into a float32 array.  Each such place is
+ * marked "f32 store".  Parity status: pinned against (1) golden vectors
+ * minted by executing the reference's own source under NumPy semantics
+ * (tests/golden/make_goldens.py; agreement <= 1e-4 px, iterations +-1 on
+ * borderline convergence) and (2) the real-numba
+ * identification table the reference bundles (tests/golden/
+ * numba_identifications_testdata.npz; bit-exact).
+ *
+ * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+#define ORC_MAX_BOX 33
+#define ORC_MAX_PIX (ORC_MAX_BOX * ORC_MAX_BOX)
+
+enum { ORC_U16 = 0, ORC_U8 = 1, ORC_I16 = 2, ORC_U32 = 3, ORC_I32 = 4, ORC_F32 = 5 };
+enum { ORC_SIGMA = 0, ORC_SIGMAXY = 1 };
+
+static inline float px_as_f32(const void *base, int dtype, int64_t idx)
+{
+    switch (dtype) {
+    case ORC_U16: return (float)((const uint16_t *)base)[idx];
+    case ORC_U8:  return (float)((const uint8_t *)base)[idx];
+    case ORC_I16: return (float)((const int16_t *)base)[idx];
+    case ORC_U32: return (float)((const uint32_t *)base)[idx];
+    case ORC_I32: return (float)((const int32_t *)base)[idx];
+    default:      return ((const float *)base)[idx];
+    }
+}
+
+/* numpy maximum/minimum: NaN-propagating */
+static inline double np_max(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+static inline double np_min(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+static inline float np_maxf(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+static inline float np_minf(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+static inline float np_signf(float a) { return (a != a) ? a : (a > 0.0f ? 1.0f : (a < 0.0f ? -1.0f : 0.0f)); }
+
+/* ------------------------------------------------------------------------
+ * identify  (picasso/localize.py:97-134, 202-244, 247-292)
+ * ---------------------------------------------------------------------- */
+
+/* unit vectors ux[k][l] = (h-l)/r, uy[k][l] = (h-k)/r in float32
+ * (picasso/localize.py:279-286; float32 array ** 2, sqrt and /= all stay
+ * float32 under numba's mixed-input ufunc loop matching). */
+void orc_unit_vectors(int box, float *ux, float *uy)
+{
+    int h = box / 2;
+    for (int k = 0; k < box; k++)
+        for (int l = 0; l < box; l++) {
+            float vx = (float)(h - l), vy = (float)(h - k);
+            float n2 = vx * vx + vy * vy;
+            float n = sqrtf(n2);
+            ux[k * box + l] = vx / n; /* centre: 0/0 = NaN, never read */
+            uy[k * box + l] = vy / n;
+        }
+}
+
+/* One frame, already cropped to the ROI and cast to float32.
+ * Appends (y, x, ng) in np.where order (y-major).  Returns the number found
+ * (may exceed cap; only the first cap are stored). */
+static int64_t identify_image(const float *img, int Y, int X, int box, double min_ng,
+                              const float *ux, const float *uy,
+                              int64_t *oy, int64_t *ox, float *ong, int64_t cap)
+{
+    int h = box / 2;
+    int64_t n = 0;
+    for (int i = h; i < Y - (h + 1); i++) {          /* localize.py:122 */
+        for (int j = h; j < X - (h + 1); j++) {      /* localize.py:123 */
+            /* np.argmax over the window: first maximum in row-major order,
+             * NaN counts as the maximum (numpy semantics). */
+            float best = img[(int64_t)(i - h) * X + (j - h)];
+            int bk = 0, bl = 0;
+            for (int k = 0; k < box; k++)
+                for (int l = 0; l < box; l++) {
+                    float v = img[(int64_t)(i - h + k) * X + (j - h + l)];
+                    if (v > best || (v != v && best == best)) { best = v; bk = k; bl = l; }
+                }
+            if (bk != h || bl != h) continue;
+            /* net gradient, float32 accumulator, k then m (localize.py:233-243).
+             * Negative indices wrap like numba's (row/col -1 -> last). */
+            float ng = 0.0f;
+            for (int k_index = 0; k_index < box; k_index++) {
+                int k = i - h + k_index;
+                for (int l_index = 0; l_index < box; l_index++) {
+                    int m = j - h + l_index;
+                    if (k == i && m == j) continue;
+                    int km1 = k - 1 < 0 ? k - 1 + Y : k - 1;
+                    int mm1 = m - 1 < 0 ? m - 1 + X : m - 1;
+                    float gy = img[(int64_t)(k + 1) * X + m] - img[(int64_t)km1 * X + m];
+                    float gx = img[(int64_t)k * X + (m + 1)] - img[(int64_t)k * X + mm1];
+                    float t1 = gy * uy[k_index * box + l_index];
+                    float t2 = gx * ux[k_index * box + l_index];
+                    float s = t1 + t2;
+                    ng = ng + s;
+                }
+            }
+            if ((double)ng > min_ng) {               /* localize.py:288, strict */
+                if (n < cap) { oy[n] = i; ox[n] = j; ong[n] = ng; }
+                n++;
+            }
+        }
+    }
+    return n;
+}
+
+/* Whole movie.  roi = {y0, x0, y1, x1} (already normalised to the frame) or
+ * NULL.  Frames outside [f_lo, f_hi] (inclusive, localize.py:401) are
+ * skipped.  Output is ordered by frame, then y, then x.  Returns 0, or 1 if
+ * the capacity was too small (out_n then holds the needed count). */
+int orc_identify(const void *movie, int dtype, int64_t F, int64_t Y, int64_t X,
+                 int box, double min_ng, const int64_t *roi, int64_t f_lo, int64_t f_hi,
+                 int64_t *out_frame, int64_t *out_y, int64_t *out_x, float *out_ng,
+                 int64_t cap, int64_t *out_n, int nthreads)
+{
+    if (box < 1 || box > ORC_MAX_BOX || (box & 1) == 0) return -1;
+    int64_t y0 = 0, x0 = 0, y1 = Y, x1 = X;
+    if (roi) { y0 = roi[0]; x0 = roi[1]; y1 = roi[2]; x1 = roi[3]; }
+    int cy = (int)(y1 - y0), cx = (int)(x1 - x0);
+    if (cy < 0) cy = 0;
+    if (cx < 0) cx = 0;
+    float ux[ORC_MAX_PIX], uy[ORC_MAX_PIX];
+    orc_unit_vectors(box, ux, uy);
+    if (f_lo < 0) f_lo = 0;
+    if (f_hi > F - 1) f_hi = F - 1;
+    int64_t nf = f_hi - f_lo + 1;
+    if (nf <= 0 || cy == 0 || cx == 0) { *out_n = 0; return 0; }
+
+    int h = box / 2;
+    /* exact upper bound on maxima per frame: centres are > h apart */
+    int64_t per_frame_cap = ((int64_t)cy / (h + 1) + 1) * ((int64_t)cx / (h + 1) + 1);
+    int64_t *cnt = (int64_t *)calloc((size_t)nf, sizeof(int64_t));
+    int64_t **fy = (int64_t **)calloc((size_t)nf, sizeof(int64_t *));
+    int64_t **fx = (int64_t **)calloc((size_t)nf, sizeof(int64_t *));
+    float **fg = (float **)calloc((size_t)nf, sizeof(float *));
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 4) num_threads(nthreads)
+#endif
+    for (int64_t fi = 0; fi < nf; fi++) {
+        int64_t f = f_lo + fi;
+        float *img = (float *)malloc(sizeof(float) * (size_t)cy * (size_t)cx);
+        for (int r = 0; r < cy; r++)
+            for (int c = 0; c < cx; c++)
+                img[(int64_t)r * cx + c] = px_as_f32(movie, dtype, (f * Y + (y0 + r)) * X + (x0 + c));
+        int64_t *ty = (int64_t *)malloc(sizeof(int64_t) * (size_t)per_frame_cap);
+        int64_t *tx = (int64_t *)malloc(sizeof(int64_t) * (size_t)per_frame_cap);
+        float *tg = (float *)malloc(sizeof(float) * (size_t)per_frame_cap);
+        cnt[fi] = identify_image(img, cy, cx, box, min_ng, ux, uy, ty, tx, tg, per_frame_cap);
+        fy[fi] = ty; fx[fi] = tx; fg[fi] = tg;
+        free(img);
+    }
+    int64_t n = 0;
+    for (int64_t fi = 0; fi < nf; fi++) {
+        for (int64_t q = 0; q < cnt[fi]; q++) {
+            if (n < cap) {
+                out_frame[n] = f_lo + fi;
+                out_y[n] = fy[fi][q] + y0;           /* localize.py:334-336 */
+                out_x[n] = fx[fi][q] + x0;
+                out_ng[n] = fg[fi][q];
+            }
+            n++;
+        }
+        free(fy[fi]); free(fx[fi]); free(fg[fi]);
+    }
+    free(cnt); free(fy); free(fx); free(fg);
+    *out_n = n;
+    return n > cap ? 1 : 0;
+}
+
+/* ------------------------------------------------------------------------
+ * get_spots = _cut_spots_numba + _to_photons
+ * (picasso/localize.py:917-931, 1101-1112)
+ * ---------------------------------------------------------------------- */
+int orc_get_spots(const void *movie, int dtype, int64_t F, int64_t Y, int64_t X,
+                  const int64_t *frame, const int64_t *y, const int64_t *x, int64_t N,
+                  int box, double baseline, double sensitivity, double gain, float *spots)
+{
+    (void)F;
+    int r = box / 2;
+    float b = (float)baseline, s = (float)sensitivity, g = (float)gain;
+    for (int64_t i = 0; i < N; i++)
+        for (int a = 0; a < box; a++)
+            for (int c = 0; c < box; c++) {
+                float v = px_as_f32(movie, dtype, (frame[i] * Y + (y[i] - r + a)) * X + (x[i] - r + c));
+                float t = v - b;      /* float32 array arithmetic, in this order */
+                t = t * s;
+                t = t / g;
+                spots[(i * box + a) * box + c] = t;
+            }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------
+ * gaussmle  (picasso/gaussmle.py)
+ * ---------------------------------------------------------------------- */
+#define SQRT_2PI 2.5066282746310002 /* np.sqrt(2.0*np.pi) */
+#define SQRT_2   1.4142135623730951
+#define SQRT_PI  1.7724538509055159
+
+/* gaussmle.py:28-48 */
+static void sum_and_com(const float *spot, int size, double *sum, double *y, double *x)
+{
+    double sy = 0.0, sx = 0.0, s = 0.0;
+    for (int i = 0; i < size; i++)
+        for (int j = 0; j < size; j++) {
+            double v = (double)spot[i * size + j];
+            sy += v * (double)i;
+            sx += v * (double)j;
+            s += v;
+        }
+    if (s <= 0.0) { *sum = 0.01; *y = (size - 1) / 2.0; *x = (size - 1) / 2.0; return; }
+    *sum = s; *y = sy / s; *x = sx / s;
+}
+
+/* gaussmle.py:61-91; returns the minimum of the filtered spot (float32) */
+static float mean_filter_min(const float *spot, int size)
+{
+    float best = 0.0f;
+    int first = 1;
+    for (int k = 0; k < size; k++)
+        for (int l = 0; l < size; l++) {
+            int min_m = k - 1 > 0 ? k - 1 : 0, max_m = k + 2 < size ? k + 2 : size;
+            int min_n = l - 1 > 0 ? l - 1 : 0, max_n = l + 2 < size ? l + 2 : size;
+            int N = (max_m - min_m) * (max_n - min_n);
+            double nsum = 0.0;
+            for (int m = min_m; m < max_m; m++)
+                for (int n = min_n; n < max_n; n++) nsum += (double)spot[m * size + n];
+            float f = (float)(nsum / (double)N);          /* f32 store */
+            /* np.min: NaN propagates */
+            if (first) { best = f; first = 0; }
+            else if (best == best && (f < best || f != f)) best = f;
+        }
+    return best;
+}
+
+/* gaussmle.py:94-139; theta6 = x, y, photons, bg, sx, sy as float32 */
+static void initial_parameters(const float *spot, int size, float *theta6)
+{
+    double sum, y, x;
+    sum_and_com(spot, size, &sum, &y, &x);
+    float bg = mean_filter_min(spot, size);
+    double photons = sum - (double)(size * size) * (double)bg;
+    double photons_sane = np_max(1.0, photons);
+    int size_half = size / 2;
+    double sdy = 0.0, sdx = 0.0, sum_y = 0.0, sum_x = 0.0;
+    for (int i = 0; i < size; i++) {
+        double d2 = (double)((i - size_half) * (i - size_half));
+        float vy = spot[i * size + size_half] - bg;       /* spot - bg is a float32 array */
+        float vx = spot[size_half * size + i] - bg;
+        sdy += (double)vy * d2;
+        sdx += (double)vx * d2;
+        sum_y += (double)vy;
+        sum_x += (double)vx;
+    }
+    /* numba's default error model would raise ZeroDivisionError when
+     * sum_y == 0; we follow IEEE (NaN/inf -> 0.01) like the NumPy execution
+     * of the same source.  See DESIGN.md "degenerate spots". */
+    double sy = sqrt(sdy / sum_y), sx = sqrt(sdx / sum_x);
+    if (!isfinite(sy)) sy = 0.01;
+    if (!isfinite(sx)) sx = 0.01;
+    if (sx == 0) sx = 0.01;
+    if (sy == 0) sy = 0.01;
+    theta6[0] = (float)x; theta6[1] = (float)y; theta6[2] = (float)photons_sane;
+    theta6[3] = bg; theta6[4] = (float)sx; theta6[5] = (float)sy;
+}
+
+/* gaussmle.py:268-280 */
+static inline double gaussian_integral(int x, float mu, float sigma)
+{
+    double sq_norm = 0.70710678118654757 / (double)sigma;
+    double d = (double)x - (double)mu;
+    return 0.5 * (erf((d + 0.5) * sq_norm) - erf((d - 0.5) * sq_norm));
+}
+
+/* gaussmle.py:283-303 */
+static inline void d_gaussian_integral(int x, float mu, float sigma, float photons, double PSFy,
+                                       double *dudt, double *d2udt2)
+{
+    double d = (double)x - (double)mu;
+    double ta = (d + 0.5) / (double)sigma, tb = (d - 0.5) / (double)sigma;
+    double a = exp(-0.5 * (ta * ta));
+    double b = exp(-0.5 * (tb * tb));
+    float s3 = sigma * (sigma * sigma);                   /* float32 ** 3 stays float32 */
+    *dudt = (double)photons * PSFy * (b - a) / (SQRT_2PI * (double)sigma);
+    *d2udt2 = (double)photons * ((d - 0.5) * b - (d + 0.5) * a) * PSFy / (SQRT_2PI * (double)s3);
+}
+
+static inline double ipow_d(double a, int m) /* numba int power: square-and-multiply */
+{
+    double r = 1.0;
+    while (m) { if (m & 1) r *= a; m >>= 1; a *= a; }
+    return r;
+}
+static inline float ipow_f(float a, int m)
+{
+    float r = 1.0f;
+    while (m) { if (m & 1) r *= a; m >>= 1; a *= a; }
+    return r;
+}
+
+/* gaussmle.py:306-316 */
+static inline double G(int n, int m, int x, float mu, float sigma_x)
+{
+    double a_minus = (double)x - (double)mu - 0.5;
+    double a_plus = (double)x - (double)mu + 0.5;
+    float s2 = sigma_x * sigma_x;
+    double exp_minus = exp(-(a_minus * a_minus) / (2.0 * (double)s2));
+    double exp_plus = exp(-(a_plus * a_plus) / (2.0 * (double)s2));
+    return (ipow_d(a_minus, m) * exp_minus - ipow_d(a_plus, m) * exp_plus)
+           / ((double)ipow_f(sigma_x, n) * SQRT_2PI);
+}
+
+/* gaussmle.py:319-336 */
+static inline void d_gaussian_integral_sigma(int x, float mu, float sigma_x, float photons, double PSFy,
+                                             double *dudt, double *d2udt2)
+{
+    *dudt = (double)photons * PSFy * G(2, 1, x, mu, sigma_x);
+    *d2udt2 = (double)photons * PSFy * (G(5, 3, x, mu, sigma_x) - 2.0 * G(3, 1, x, mu, sigma_x));
+}
+
+/* gaussmle.py:339-383 (including the precedence quirk at :380-382) */
+static inline void d_gaussian_integral_iso_sigma(int x, int y, float mu, float nu, float sigma, float photons,
+                                                 double PSFx, double PSFy, double *dudt, double *d2udt2)
+{
+    double s = (double)sigma;
+    double a_plus = ((double)x - (double)mu + 0.5) / (SQRT_2 * s);
+    double a_minus = ((double)x - (double)mu - 0.5) / (SQRT_2 * s);
+    double b_plus = ((double)y - (double)nu + 0.5) / (SQRT_2 * s);
+    double b_minus = ((double)y - (double)nu - 0.5) / (SQRT_2 * s);
+    double Fx = a_minus * exp(-(a_minus * a_minus)) - a_plus * exp(-(a_plus * a_plus));
+    double Fy = b_minus * exp(-(b_minus * b_minus)) - b_plus * exp(-(b_plus * b_plus));
+    double dPSFxdt = Fx / (SQRT_PI * s);
+    double dPSFydt = Fy / (SQRT_PI * s);
+    double dFxdt = (a_plus * exp(-(a_plus * a_plus)) * (1 - 2 * (a_plus * a_plus))
+                    - a_minus * exp(-(a_minus * a_minus)) * (1 - 2 * (a_minus * a_minus))) / s;
+    double dFydy = (b_plus * exp(-(b_plus * b_plus)) * (1 - 2 * (b_plus * b_plus))
+                    - b_minus * exp(-(b_minus * b_minus)) * (1 - 2 * (b_minus * b_minus))) / s;
+    float s2 = sigma * sigma;          /* float32 ** 2 */
+    float sinv = 1.0f / sigma;         /* float32 ** (-1) */
+    double d2PSFxdt2 = (1 / SQRT_PI) * ((-Fx / (double)s2) + (double)sinv * dFxdt);
+    double d2PSFydt2 = (1 / SQRT_PI) * ((-Fy / (double)s2) + (double)sinv * dFydy);
+    *dudt = (double)photons * (PSFy * dPSFxdt + PSFx * dPSFydt);
+    *d2udt2 = (double)photons * PSFy * d2PSFxdt2 + 2 * dPSFxdt * dPSFydt + PSFx * d2PSFydt2;
+}
+
+/* symmetric pinv diagonal via cyclic Jacobi (np.linalg.pinv, rcond 1e-15:
+ * singular values <= 1e-15 * max are dropped).  M is n x n, row-major. */
+static void pinv_diag_sym(const double *Min, int n, double *diag)
+{
+    double A[36], V[36];
+    int nonfinite = 0;
+    for (int i = 0; i < n * n; i++) { A[i] = Min[i]; if (!isfinite(A[i])) nonfinite = 1; }
+    if (nonfinite) { for (int i = 0; i < n; i++) diag[i] = NAN; return; }
+    for (int i = 0; i < n; i++) for (int j = 0; j < n; j++) V[i * n + j] = (i == j);
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int p = 0; p < n; p++) for (int q = p + 1; q < n; q++) off += A[p * n + q] * A[p * n + q];
+        if (off == 0.0) break;
+        for (int p = 0; p < n; p++)
+            for (int q = p + 1; q < n; q++) {
+                double apq = A[p * n + q];
+                if (apq == 0.0) continue;
+                double app = A[p * n + p], aqq = A[q * n + q];
+                double tau = (aqq - app) / (2.0 * apq);
+                double t = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                double c = 1.0 / sqrt(1.0 + t * t), s = t * c;
+                for (int k = 0; k < n; k++) {
+                    double akp = A[k * n + p], akq = A[k * n + q];
+                    A[k * n + p] = c * akp - s * akq;
+                    A[k * n + q] = s * akp + c * akq;
+                }
+                for (int k = 0; k < n; k++) {
+                    double apk = A[p * n + k], aqk = A[q * n + k];
+                    A[p * n + k] = c * apk - s * aqk;
+                    A[q * n + k] = s * apk + c * aqk;
+                }
+                for (int k = 0; k < n; k++) {
+                    double vkp = V[k * n + p], vkq = V[k * n + q];
+                    V[k * n + p] = c * vkp - s * vkq;
+                    V[k * n + q] = s * vkp + c * vkq;
+                }
+            }
+    }
+    double smax = 0.0;
+    for (int i = 0; i < n; i++) if (fabs(A[i * n + i]) > smax) smax = fabs(A[i * n + i]);
+    double cutoff = 1e-15 * smax;
+    for (int i = 0; i < n; i++) {
+        double acc = 0.0;
+        for (int k = 0; k < n; k++) {
+            double lam = A[k * n + k];
+            if (fabs(lam) > cutoff) acc += V[i * n + k] * V[i * n + k] / lam;
+        }
+        diag[i] = acc;
+    }
+}
+
+/* One spot, both methods.  thetas/crlbs rows of 6, as gaussmle.py:455-459
+ * allocates them (the caller pre-fills crlbs with +inf, thetas with 0). */
+static void mlefit_one(const float *spot, int size, int method, double eps, int max_it,
+                       float *theta_out, float *crlb_out, float *ll_out, int32_t *it_out)
+{
+    const int np_ = method == ORC_SIGMAXY ? 6 : 5;
+    float theta[6], init[6];
+    initial_parameters(spot, size, init);
+    theta[0] = init[0]; theta[1] = init[1]; theta[2] = init[2]; theta[3] = init[3];
+    if (method == ORC_SIGMAXY) { theta[4] = init[4]; theta[5] = init[5]; }
+    else { theta[4] = (float)(((double)init[4] + (double)init[5]) / 2); theta[5] = 0.0f; }
+
+    float max_step[6];
+    max_step[0] = theta[4]; max_step[1] = theta[4];
+    max_step[2] = (float)(0.1 * (double)theta[2]);
+    max_step[3] = (float)(0.1 * (double)theta[3]);
+    max_step[4] = (float)(0.2 * (double)theta[4]);
+    max_step[5] = (float)(0.2 * (double)theta[5]);
+
+    float dudt[6], d2udt2[6], num[6], den[6];
+    float old_x = theta[0], old_y = theta[1], old_sx = theta[4], old_sy = theta[5];
+    int kk = 0;
+    while (kk < max_it) {
+        kk++;
+        for (int l = 0; l < 6; l++) { num[l] = 0.0f; den[l] = 0.0f; }
+        for (int ii = 0; ii < size; ii++)
+            for (int jj = 0; jj < size; jj++) {
+                float sgy = method == ORC_SIGMAXY ? theta[5] : theta[4];
+                double PSFx = gaussian_integral(ii, theta[0], theta[4]);
+                double PSFy = gaussian_integral(jj, theta[1], sgy);
+                double a, b;
+                d_gaussian_integral(ii, theta[0], theta[4], theta[2], PSFy, &a, &b);
+                dudt[0] = (float)a; d2udt2[0] = (float)b;             /* f32 store */
+                d_gaussian_integral(jj, theta[1], sgy, theta[2], PSFx, &a, &b);
+                dudt[1] = (float)a; d2udt2[1] = (float)b;
+                dudt[2] = (float)(PSFx * PSFy); d2udt2[2] = 0.0f;
+                dudt[3] = 1.0f; d2udt2[3] = 0.0f;
+                if (method == ORC_SIGMAXY) {
+                    d_gaussian_integral_sigma(ii, theta[0], theta[4], theta[2], PSFy, &a, &b);
+                    dudt[4] = (float)a; d2udt2[4] = (float)b;
+                    d_gaussian_integral_sigma(jj, theta[1], theta[5], theta[2], PSFx, &a, &b);
+                    dudt[5] = (float)a; d2udt2[5] = (float)b;
+                } else {
+                    d_gaussian_integral_iso_sigma(ii, jj, theta[0], theta[1], theta[4], theta[2],
+                                                  PSFx, PSFy, &a, &b);
+                    dudt[4] = (float)a; d2udt2[4] = (float)b;
+                }
+                double model = (double)theta[2] * PSFx * PSFy + (double)theta[3];
+                double cf = 0.0, df = 0.0;
+                float data = spot[jj * size + ii];
+                if (model > 10e-3) {
+                    cf = (double)data / model - 1;
+                    df = (double)data / (model * model);
+                }
+                cf = np_min(cf, 10e4);
+                df = np_min(df, 10e4);
+                for (int l = 0; l < np_; l++) {
+                    float du2 = dudt[l] * dudt[l];                     /* float32 ** 2 */
+                    num[l] = (float)((double)num[l] + cf * (double)dudt[l]);
+                    den[l] = (float)((double)den[l] + (cf * (double)d2udt2[l] - df * (double)du2));
+                }
+            }
+        if (method == ORC_SIGMAXY) {                                   /* gaussmle.py:860-884 */
+            for (int l = 0; l < 6; l++) {
+                if (den[l] == 0.0f) theta[l] = theta[l] - np_signf(num[l]) * max_step[l];
+                else theta[l] = theta[l] - np_minf(np_maxf(num[l] / den[l], -max_step[l]), max_step[l]);
+            }
+            theta[2] = (float)np_max((double)theta[2], 1.0);
+            theta[3] = (float)np_max((double)theta[3], 0.01);
+            theta[4] = (float)np_max((double)theta[4], 0.01);
+            theta[5] = (float)np_max((double)theta[5], 0.01);
+            int conv = ((double)fabsf(old_x - theta[0]) < eps) && ((double)fabsf(old_y - theta[1]) < eps)
+                       && ((double)fabsf(old_sx - theta[4]) < eps) && ((double)fabsf(old_sy - theta[5]) < eps);
+            if (conv) break;
+            old_x = theta[0]; old_y = theta[1]; old_sx = theta[4]; old_sy = theta[5];
+        } else {                                                       /* gaussmle.py:647-670 */
+            for (int l = 0; l < 5; l++) {
+                float update;
+                if (den[l] == 0.0f) update = np_signf(num[l] * max_step[l]);   /* +-1, not +-max_step */
+                else update = np_minf(np_maxf(num[l] / den[l], -max_step[l]), max_step[l]);
+                theta[l] = theta[l] - update;
+            }
+            theta[2] = (float)np_max((double)theta[2], 1.0);
+            theta[3] = (float)np_max((double)theta[3], 0.01);
+            theta[4] = (float)np_max((double)theta[4], 0.01);
+            theta[4] = (float)np_min((double)theta[4], (double)size);
+            int conv = ((double)fabsf(old_x - theta[0]) < eps) && ((double)fabsf(old_y - theta[1]) < eps);
+            if (conv) break;
+            old_x = theta[0]; old_y = theta[1];
+        }
+    }
+    for (int l = 0; l < 5; l++) theta_out[l] = theta[l];
+    theta_out[5] = method == ORC_SIGMAXY ? theta[5] : theta[4];
+    *it_out = kk;
+
+    /* CRLB and log-likelihood (gaussmle.py:673-742, 887-954) */
+    double M[36];
+    for (int i = 0; i < 36; i++) M[i] = 0.0;
+    double ll = 0.0;
+    for (int l = 0; l < 6; l++) dudt[l] = 0.0f;
+    for (int ii = 0; ii < size; ii++)
+        for (int jj = 0; jj < size; jj++) {
+            float sgy = method == ORC_SIGMAXY ? theta[5] : theta[4];
+            double PSFx = gaussian_integral(ii, theta[0], theta[4]);
+            double PSFy = gaussian_integral(jj, theta[1], sgy);
+            double a, b;
+            d_gaussian_integral(ii, theta[0], theta[4], theta[2], PSFy, &a, &b); dudt[0] = (float)a;
+            d_gaussian_integral(jj, theta[1], sgy, theta[2], PSFx, &a, &b); dudt[1] = (float)a;
+            if (method == ORC_SIGMAXY) {
+                d_gaussian_integral_sigma(ii, theta[0], theta[4], theta[2], PSFy, &a, &b); dudt[4] = (float)a;
+                d_gaussian_integral_sigma(jj, theta[1], theta[5], theta[2], PSFx, &a, &b); dudt[5] = (float)a;
+            } else {
+                d_gaussian_integral_iso_sigma(ii, jj, theta[0], theta[1], theta[4], theta[2], PSFx, PSFy, &a, &b);
+                dudt[4] = (float)a;
+            }
+            dudt[2] = (float)(PSFx * PSFy);
+            dudt[3] = 1.0f;
+            double model = (double)theta[2] * PSFx * PSFy + (double)theta[3];
+            for (int k = 0; k < np_; k++)
+                for (int l = k; l < np_; l++) {
+                    float prod = dudt[l] * dudt[k];                    /* float32 * float32 */
+                    M[k * np_ + l] += (double)prod / model;
+                    M[l * np_ + k] = M[k * np_ + l];
+                }
+            if (model > 0) {
+                float data = spot[jj * size + ii];
+                if (data > 0) {
+                    float dlogd = data * logf(data);                   /* np.log(float32) is float32 */
+                    ll += (double)data * log(model) - model - (double)dlogd + (double)data;
+                } else {
+                    ll += -model;
+                }
+            }
+        }
+    *ll_out = (float)ll;
+    double diag[6];
+    pinv_diag_sym(M, np_, diag);
+    for (int k = 0; k < np_; k++) crlb_out[k] = (float)diag[k];
+    if (method == ORC_SIGMA) crlb_out[5] = crlb_out[4];
+}
+
+/* gaussmle.py:409-475.  method: 0 "sigma", 1 "sigmaxy". */
+int orc_gaussmle(const float *spots, int64_t N, int box, double eps, int max_it, int method,
+                 float *thetas, float *crlbs, float *loglik, int32_t *iterations, int nthreads)
+{
+    if (box < 1 || box > ORC_MAX_BOX) return -1;
+    if (method != ORC_SIGMA && method != ORC_SIGMAXY) return -2;   /* "Method not available." */
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads)
+#endif
+    for (int64_t i = 0; i < N; i++) {
+        for (int l = 0; l < 6; l++) { thetas[i * 6 + l] = 0.0f; crlbs[i * 6 + l] = INFINITY; }
+        mlefit_one(spots + i * box * box, box, method, eps, max_it,
+                   thetas + i * 6, crlbs + i * 6, loglik + i, iterations + i);
+    }
+    return 0;
+}
+
+/* initial parameters only (for unit pinning of M1) */
+int orc_initial_parameters(const float *spots, int64_t N, int box, float *theta6)
+{
+    for (int64_t i = 0; i < N; i++) initial_parameters(spots + i * box * box, box, theta6 + i * 6);
+    return 0;
+}
+
+int orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

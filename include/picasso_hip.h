@@ -1,0 +1,158 @@
+/*
+ * picasso_hip.h — C ABI of libpicasso_hip.so, the MI355X (gfx950) backend for
+ * Picasso's localization hot path.
+ *
+ * Conventions follow the one native binding the reference already has
+ * (picasso/ext/pygpufit/gpufit.py:40-76,338-366, Gpufit's C interface):
+ *   - the caller owns every buffer; arrays are C-contiguous;
+ *   - every call returns an int status, 0 = ok; pmi_last_error() gives the text;
+ *   - no torch / numpy types cross this boundary, only pointers and sizes.
+ *
+ * Two families of entry points:
+ *   pmi_<op>        host buffers in, host buffers out (what a ctypes/cffi/cgo
+ *                   binding of the reference would call; does H2D/D2H inside);
+ *   pmi_<op>_dev    device pointers + a HIP stream (void* = hipStream_t, NULL =
+ *                   default stream); asynchronous; used to keep a movie
+ *                   resident in HBM and to chain identify -> fit without a
+ *                   host round trip.
+ *
+ * Reference interfaces replaced (paths relative to jungmannlab/picasso v0.10.3):
+ *   pmi_identify*      picasso/localize.py:639-749 identify (-> :247-292
+ *                      identify_in_image, :97-134 _local_maxima, :202-244
+ *                      _net_gradient, :295-337 ROI crop, :395-401 frame bounds)
+ *   pmi_get_spots*     picasso/localize.py:1115-1145 get_spots (-> :917-931
+ *                      _cut_spots_numba, :1101-1112 _to_photons)
+ *   pmi_gaussmle*      picasso/gaussmle.py:409-475 gaussmle / :478-530
+ *                      gaussmle_async (-> :533-742 sigma, :745-954 sigmaxy)
+ *   pmi_locs_from_fits_dev  picasso/gaussmle.py:957-1037 locs_from_fits
+ *   pmi_localize_mle_dev    picasso/localize.py:1682-1815 localize with
+ *                      fitting_method="gaussmle" (identify -> get_spots -> fit
+ *                      -> table) as one asynchronous device pipeline
+ */
+#ifndef PICASSO_HIP_H
+#define PICASSO_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PMI_OK            0
+#define PMI_ERR_CAPACITY  1  /* output capacity too small; *out_n = rows needed */
+#define PMI_ERR_ARG      -1
+#define PMI_ERR_HIP      -2
+#define PMI_ERR_NODEVICE -3
+
+/* movie pixel types (the reference casts every frame to float32,
+ * picasso/localize.py:332; integers up to 24 bits are exact) */
+enum pmi_dtype { PMI_U16 = 0, PMI_U8 = 1, PMI_I16 = 2, PMI_U32 = 3, PMI_I32 = 4, PMI_F32 = 5 };
+/* picasso/gaussmle.py:413 method: "sigma" | "sigmaxy" */
+enum pmi_mle_method { PMI_MLE_SIGMA = 0, PMI_MLE_SIGMAXY = 1 };
+
+#define PMI_MAX_BOX 21   /* odd box sizes 3..21 */
+
+/* ---- library / device ------------------------------------------------ */
+int         pmi_version(void);
+const char *pmi_last_error(void);            /* gpufit_get_last_error analogue  */
+int         pmi_device_count(void);          /* gpufit_cuda_available analogue: 0 = no GPU */
+int         pmi_set_device(int device);
+int         pmi_device_info(char *name, size_t name_len, int *compute_units,
+                            size_t *total_mem_bytes);
+
+/* ---- device memory, for hosts without a HIP binding ------------------- */
+int pmi_malloc(void **dptr, size_t bytes);
+int pmi_free(void *dptr);
+int pmi_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
+int pmi_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
+int pmi_stream_synchronize(void *stream);
+int pmi_release_scratch(void);               /* frees the library's cached scratch buffers */
+
+/* ---- identify --------------------------------------------------------- *
+ * movie: (F, Y, X) pixels of `dtype`.  roi4 = {y0, x0, y1, x1} already
+ * normalised to the frame (numpy slice semantics), or NULL.  Frames outside
+ * [f_lo, f_hi] (inclusive) are skipped.  A pixel is reported when it is the
+ * first maximum of its box x box window and its net gradient is > min_ng.
+ * Output rows are ordered by (frame, y, x); coordinates are frame coordinates.
+ * If more than `cap` rows exist, returns PMI_ERR_CAPACITY and *out_n = needed. */
+int pmi_identify(const void *movie, int dtype, int64_t F, int64_t Y, int64_t X,
+                 int box, double min_ng, const int64_t *roi4, int64_t f_lo, int64_t f_hi,
+                 int32_t *out_frame, int32_t *out_y, int32_t *out_x, float *out_ng,
+                 int64_t cap, int64_t *out_n);
+
+/* Device form.  d_out_n is a device int64 receiving the row count (rows beyond
+ * cap are counted but not written).  Nothing is synchronised. */
+int pmi_identify_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
+                     int box, double min_ng, const int64_t *roi4, int64_t f_lo, int64_t f_hi,
+                     int32_t *d_frame, int32_t *d_y, int32_t *d_x, float *d_ng,
+                     int64_t cap, int64_t *d_out_n, void *stream);
+
+/* ---- get_spots -------------------------------------------------------- *
+ * spots[i] = float32(movie[frame, y-r:y+r+1, x-r:x+r+1]); then
+ * (s - baseline) * sensitivity / gain in float32, in that order.            */
+int pmi_get_spots(const void *movie, int dtype, int64_t F, int64_t Y, int64_t X,
+                  const int32_t *frame, const int32_t *y, const int32_t *x, int64_t N,
+                  int box, double baseline, double sensitivity, double gain,
+                  float *out_spots);
+/* d_n: optional device count (rows = min(*d_n, N)); NULL = N rows. */
+int pmi_get_spots_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
+                      const int32_t *d_frame, const int32_t *d_y, const int32_t *d_x,
+                      int64_t N, const int64_t *d_n, int box, double baseline,
+                      double sensitivity, double gain, float *d_spots, void *stream);
+
+/* ---- gaussmle --------------------------------------------------------- *
+ * spots: (N, box, box) float32 photons.  Outputs as gaussmle.py:455-459
+ * allocates them: thetas (N,6) = x, y, photons, bg, sx, sy in box-origin
+ * coordinates; crlbs (N,6); loglik (N); iterations (N) int32.              */
+int pmi_gaussmle(const float *spots, int64_t N, int box, double eps, int max_it, int method,
+                 float *thetas, float *crlbs, float *loglik, int32_t *iterations);
+int pmi_gaussmle_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box,
+                     double eps, int max_it, int method, float *d_thetas, float *d_crlbs,
+                     float *d_loglik, int32_t *d_iterations, void *stream);
+/* Fused ROI extraction + photon conversion + fit straight from the movie
+ * (no (N,box,box) round trip through HBM). */
+int pmi_gaussmle_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
+                           const int32_t *d_frame, const int32_t *d_y, const int32_t *d_x,
+                           int64_t N, const int64_t *d_n, int box, double baseline,
+                           double sensitivity, double gain, double eps, int max_it, int method,
+                           float *d_thetas, float *d_crlbs, float *d_loglik,
+                           int32_t *d_iterations, void *stream);
+
+/* ---- locs_from_fits (gaussmle.py:957-1037) ---------------------------- *
+ * Builds the 17-column localization table as structure-of-arrays, row i from
+ * identification i (rows stay in identification order = frame order).
+ * d_cols: 17 device pointers in this order, each N elements of 4 bytes:
+ *  0 frame(u32) 1 x 2 y 3 photons 4 sx 5 sy 6 bg 7 lpx 8 lpy 9 ellipticity
+ * 10 net_gradient 11 log_likelihood 12 iterations(u32) 13 photons_unc
+ * 14 bg_unc 15 sx_unc 16 sy_unc   (all float32 unless noted)               */
+#define PMI_LOC_COLUMNS 17
+int pmi_locs_from_fits_dev(const int32_t *d_frame, const int32_t *d_y, const int32_t *d_x,
+                           const float *d_ng, const float *d_thetas, const float *d_crlbs,
+                           const float *d_loglik, const int32_t *d_iterations, int64_t N,
+                           const int64_t *d_n, int box, void *const *d_cols, void *stream);
+
+/* ---- whole path on a resident movie ----------------------------------- *
+ * identify -> fused cut+fit -> table, one asynchronous submission.  d_table is
+ * one device block of PMI_LOC_COLUMNS * cap * 4 bytes (column c starts at
+ * element c*cap).  d_out_n: device int64 row count.                         */
+int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
+                         int box, double min_ng, const int64_t *roi4, int64_t f_lo, int64_t f_hi,
+                         double baseline, double sensitivity, double gain,
+                         double eps, int max_it, int method,
+                         void *d_table, int64_t cap, int64_t *d_out_n, void *stream);
+
+/* ---- timing hooks for bench.py (HIP events on the given stream) ------- */
+int pmi_event_create(void **event);
+int pmi_event_record(void *event, void *stream);
+int pmi_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises on stop */
+int pmi_event_destroy(void *event);
+/* Milliseconds the last pmi_identify_dev / pmi_gaussmle*_dev spent in its
+ * dominant kernel, measured with HIP events around that kernel when enabled. */
+int pmi_set_kernel_timing(int enabled);
+int pmi_last_kernel_ms(float *scan_ms, float *fit_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PICASSO_HIP_H */

@@ -1,0 +1,116 @@
+"""ctypes binding of libpicasso_hip.so (the C ABI in include/picasso_hip.h).
+
+The library is loaded lazily from the package directory, like the reference
+loads Gpufit (picasso/ext/pygpufit/gpufit.py:24-37).  Unlike the reference there
+is NO fallback: if the HIP library is missing or no GPU is visible, every
+compute call raises.  The product path never routes through a CPU
+implementation.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import threading
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libpicasso_hip.so")
+
+PMI_OK = 0
+PMI_ERR_CAPACITY = 1
+PMI_LOC_COLUMNS = 17
+PMI_MAX_BOX = 21
+
+DTYPE_CODES = {
+    np.dtype("uint16"): 0, np.dtype("uint8"): 1, np.dtype("int16"): 2,
+    np.dtype("uint32"): 3, np.dtype("int32"): 4, np.dtype("float32"): 5,
+}
+MLE_METHODS = {"sigma": 0, "sigmaxy": 1}
+
+# every symbol include/picasso_hip.h declares: (name, restype, argtypes)
+_i32, _i64, _f64, _p, _sz = ctypes.c_int, ctypes.c_int64, ctypes.c_double, ctypes.c_void_p, ctypes.c_size_t
+SYMBOLS = {
+    "pmi_version": (_i32, []),
+    "pmi_last_error": (ctypes.c_char_p, []),
+    "pmi_device_count": (_i32, []),
+    "pmi_set_device": (_i32, [_i32]),
+    "pmi_device_info": (_i32, [_p, _sz, _p, _p]),
+    "pmi_malloc": (_i32, [_p, _sz]),
+    "pmi_free": (_i32, [_p]),
+    "pmi_memcpy_h2d": (_i32, [_p, _p, _sz]),
+    "pmi_memcpy_d2h": (_i32, [_p, _p, _sz]),
+    "pmi_stream_synchronize": (_i32, [_p]),
+    "pmi_release_scratch": (_i32, []),
+    "pmi_identify": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
+    "pmi_identify_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _p]),
+    "pmi_get_spots": (_i32, [_p, _i32, _i64, _i64, _i64, _p, _p, _p, _i64, _i32, _f64, _f64, _f64, _p]),
+    "pmi_get_spots_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _p, _p, _p, _i64, _p, _i32, _f64, _f64, _f64, _p, _p]),
+    "pmi_gaussmle": (_i32, [_p, _i64, _i32, _f64, _i32, _i32, _p, _p, _p, _p]),
+    "pmi_gaussmle_dev": (_i32, [_p, _i64, _p, _i32, _f64, _i32, _i32, _p, _p, _p, _p, _p]),
+    "pmi_gaussmle_movie_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _p, _p, _p, _i64, _p, _i32, _f64, _f64, _f64,
+                                      _f64, _i32, _i32, _p, _p, _p, _p, _p]),
+    "pmi_locs_from_fits_dev": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i32, _p, _p]),
+    "pmi_localize_mle_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _f64, _f64, _f64,
+                                    _f64, _i32, _i32, _p, _i64, _p, _p]),
+    "pmi_event_create": (_i32, [_p]),
+    "pmi_event_record": (_i32, [_p, _p]),
+    "pmi_event_elapsed_ms": (_i32, [_p, _p, _p]),
+    "pmi_event_destroy": (_i32, [_p]),
+    "pmi_set_kernel_timing": (_i32, [_i32]),
+    "pmi_last_kernel_ms": (_i32, [_p, _p]),
+}
+
+_lib = None
+_lock = threading.Lock()      # one context per process, calls serialised
+
+
+class HipBackendError(RuntimeError):
+    """Raised when the HIP library reports an error (status != 0)."""
+
+
+def load():
+    """Load libpicasso_hip.so and bind every declared symbol (no GPU needed)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(
+                f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "or `make -C picasso_amd/csrc`.  There is no CPU fallback.")
+        L = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SYMBOLS.items():
+            fn = getattr(L, name)     # AttributeError if the .so lacks a declared symbol
+            fn.restype = res
+            fn.argtypes = args
+        _lib = L
+    return _lib
+
+
+def last_error() -> str:
+    return load().pmi_last_error().decode("utf-8", "replace")
+
+
+def check(rc: int, what: str = ""):
+    if rc != PMI_OK:
+        raise HipBackendError(f"{what or 'libpicasso_hip'}: status {rc}: {last_error()}")
+
+
+def device_count() -> int:
+    return int(load().pmi_device_count())
+
+
+def require_gpu():
+    if device_count() < 1:
+        raise HipBackendError("no HIP device visible: picasso_amd needs an AMD GPU (gfx950); "
+                              "there is no CPU fallback")
+
+
+def ptr(a):
+    """void* of a numpy array (or None)."""
+    if a is None:
+        return None
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def lock():
+    return _lock

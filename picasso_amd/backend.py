@@ -1,0 +1,204 @@
+"""Array-level calls into libpicasso_hip.so (numpy in, numpy out).
+
+This is the thin layer the Picasso-shaped modules (localize.py, gaussmle.py)
+sit on.  Nothing here computes on the CPU: every function ends in a C-ABI call
+and raises if the library or the GPU is missing.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+
+from . import _lib
+
+LOC_COLUMNS = [
+    ("frame", np.uint32), ("x", np.float32), ("y", np.float32), ("photons", np.float32),
+    ("sx", np.float32), ("sy", np.float32), ("bg", np.float32), ("lpx", np.float32),
+    ("lpy", np.float32), ("ellipticity", np.float32), ("net_gradient", np.float32),
+    ("log_likelihood", np.float32), ("iterations", np.uint32), ("photons_unc", np.float32),
+    ("bg_unc", np.float32), ("sx_unc", np.float32), ("sy_unc", np.float32),
+]
+
+
+def dtype_code(dtype) -> int:
+    dt = np.dtype(dtype)
+    if dt not in _lib.DTYPE_CODES:
+        raise TypeError(f"unsupported movie dtype {dt}; supported: "
+                        + ", ".join(str(d) for d in _lib.DTYPE_CODES))
+    return _lib.DTYPE_CODES[dt]
+
+
+def as_movie_array(movie) -> np.ndarray:
+    """C-contiguous native-endian (F, Y, X) view/copy of an ndarray or memmap."""
+    a = np.asarray(movie)
+    if a.ndim != 3:
+        raise ValueError("movie must have shape (frames, height, width)")
+    if not a.dtype.isnative:
+        a = a.astype(a.dtype.newbyteorder("="))
+    dtype_code(a.dtype)
+    return np.ascontiguousarray(a)
+
+
+def normalise_roi(roi, Y, X):
+    """numpy slice semantics of frame[y0:y1, x0:x1] (picasso/localize.py:331)."""
+    if roi is None:
+        return None
+    (y0, x0), (y1, x1) = roi
+    ys, ye, _ = slice(y0, y1).indices(Y)
+    xs, xe, _ = slice(x0, x1).indices(X)
+    return np.array([ys, xs, max(ye, ys), max(xe, xs)], np.int64)
+
+
+def frame_range(frame_bounds, F):
+    """Inclusive range of picasso/localize.py:395-401 -> (lo, hi)."""
+    lo, hi = 0, F
+    if frame_bounds is not None:
+        if frame_bounds[0] is not None:
+            lo = max(frame_bounds[0], lo)
+        if frame_bounds[1] is not None:
+            hi = min(frame_bounds[1], hi)
+    return int(lo), int(hi)
+
+
+def identify_arrays(movie: np.ndarray, min_ng: float, box: int, roi=None, frame_bounds=None,
+                    f_lo=None, f_hi=None):
+    """-> frame, y, x (int32), net_gradient (float32), ordered by (frame, y, x)."""
+    _lib.require_gpu()
+    movie = as_movie_array(movie)
+    F, Y, X = movie.shape
+    r = normalise_roi(roi, Y, X)
+    lo, hi = frame_range(frame_bounds, F)
+    if f_lo is not None:
+        lo = max(lo, f_lo)
+    if f_hi is not None:
+        hi = min(hi, f_hi)
+    L = _lib.load()
+    cap = max(4096, 256 * F)
+    while True:
+        fr = np.empty(cap, np.int32); yy = np.empty(cap, np.int32)
+        xx = np.empty(cap, np.int32); ng = np.empty(cap, np.float32)
+        n = ctypes.c_int64(0)
+        with _lib.lock():
+            rc = L.pmi_identify(_lib.ptr(movie), dtype_code(movie.dtype), F, Y, X, int(box), float(min_ng),
+                                _lib.ptr(r), lo, hi, _lib.ptr(fr), _lib.ptr(yy), _lib.ptr(xx), _lib.ptr(ng),
+                                cap, ctypes.byref(n))
+        if rc == _lib.PMI_ERR_CAPACITY:
+            cap = int(n.value)
+            continue
+        _lib.check(rc, "pmi_identify")
+        k = int(n.value)
+        return fr[:k].copy(), yy[:k].copy(), xx[:k].copy(), ng[:k].copy()
+
+
+def get_spots_array(movie: np.ndarray, frame, y, x, box: int, baseline, sensitivity, gain) -> np.ndarray:
+    _lib.require_gpu()
+    movie = as_movie_array(movie)
+    F, Y, X = movie.shape
+    frame = np.ascontiguousarray(frame, np.int32)
+    y = np.ascontiguousarray(y, np.int32)
+    x = np.ascontiguousarray(x, np.int32)
+    N = len(frame)
+    spots = np.empty((N, box, box), np.float32)
+    with _lib.lock():
+        rc = _lib.load().pmi_get_spots(_lib.ptr(movie), dtype_code(movie.dtype), F, Y, X, _lib.ptr(frame),
+                                       _lib.ptr(y), _lib.ptr(x), N, int(box), float(baseline),
+                                       float(sensitivity), float(gain), _lib.ptr(spots))
+    _lib.check(rc, "pmi_get_spots")
+    return spots
+
+
+def gaussmle_arrays(spots: np.ndarray, eps: float, max_it: int, method: str = "sigmaxy"):
+    """The allocation contract of picasso/gaussmle.py:455-459."""
+    if method not in _lib.MLE_METHODS:
+        raise ValueError("Method not available.")
+    _lib.require_gpu()
+    spots = np.ascontiguousarray(spots, np.float32)
+    if spots.ndim != 3 or spots.shape[1] != spots.shape[2]:
+        raise ValueError("spots must have shape (N, box, box)")
+    N, box, _ = spots.shape
+    thetas = np.zeros((N, 6), np.float32)
+    crlbs = np.full((N, 6), np.inf, np.float32)
+    loglik = np.zeros(N, np.float32)
+    iterations = np.zeros(N, np.int32)
+    with _lib.lock():
+        rc = _lib.load().pmi_gaussmle(_lib.ptr(spots), N, int(box), float(eps), int(max_it),
+                                      _lib.MLE_METHODS[method], _lib.ptr(thetas), _lib.ptr(crlbs),
+                                      _lib.ptr(loglik), _lib.ptr(iterations))
+    _lib.check(rc, "pmi_gaussmle")
+    return thetas, crlbs, loglik, iterations
+
+
+class DeviceMovie:
+    """A movie resident in HBM (pmi_malloc), for repeated calls without H2D."""
+
+    def __init__(self, movie: np.ndarray):
+        _lib.require_gpu()
+        movie = as_movie_array(movie)
+        self.shape = movie.shape
+        self.dtype = movie.dtype
+        self.nbytes = movie.nbytes
+        self._ptr = ctypes.c_void_p()
+        _lib.check(_lib.load().pmi_malloc(ctypes.byref(self._ptr), max(self.nbytes, 1)), "pmi_malloc")
+        _lib.check(_lib.load().pmi_memcpy_h2d(self._ptr, _lib.ptr(movie), self.nbytes), "pmi_memcpy_h2d")
+
+    @property
+    def ptr(self):
+        return self._ptr
+
+    def free(self):
+        if self._ptr:
+            _lib.load().pmi_free(self._ptr)
+            self._ptr = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def localize_mle_device(d_movie_ptr, dtype, shape, box, min_ng, camera, eps=1e-3, max_it=100,
+                        method="sigmaxy", roi=None, frame_bounds=None, cap=None, stream=None,
+                        f_lo=None, f_hi=None):
+    """identify -> fused cut+fit -> table on a resident movie.  Returns a dict of
+    numpy columns (LOC_COLUMNS).  d_movie_ptr: int / c_void_p device address."""
+    _lib.require_gpu()
+    L = _lib.load()
+    F, Y, X = shape
+    r = normalise_roi(roi, Y, X)
+    lo, hi = frame_range(frame_bounds, F)
+    if f_lo is not None:
+        lo = max(lo, f_lo)
+    if f_hi is not None:
+        hi = min(hi, f_hi)
+    cap = int(cap or max(4096, 256 * F))
+    while True:
+        table = ctypes.c_void_p()
+        dn = ctypes.c_void_p()
+        _lib.check(L.pmi_malloc(ctypes.byref(table), _lib.PMI_LOC_COLUMNS * cap * 4), "pmi_malloc")
+        _lib.check(L.pmi_malloc(ctypes.byref(dn), 8), "pmi_malloc")
+        try:
+            with _lib.lock():
+                rc = L.pmi_localize_mle_dev(d_movie_ptr, dtype_code(dtype), F, Y, X, int(box), float(min_ng),
+                                            _lib.ptr(r), lo, hi, float(camera["Baseline"]),
+                                            float(camera["Sensitivity"]), float(camera["Gain"]), float(eps),
+                                            int(max_it), _lib.MLE_METHODS[method], table, cap, dn, stream)
+                _lib.check(rc, "pmi_localize_mle_dev")
+                _lib.check(L.pmi_stream_synchronize(stream), "sync")
+            n = np.zeros(1, np.int64)
+            _lib.check(L.pmi_memcpy_d2h(_lib.ptr(n), dn, 8), "d2h")
+            n = int(n[0])
+            if n > cap:
+                cap = n
+                continue
+            out = {}
+            for c, (name, dt) in enumerate(LOC_COLUMNS):
+                col = np.empty(n, dt)
+                if n:
+                    _lib.check(L.pmi_memcpy_d2h(_lib.ptr(col), ctypes.c_void_p(table.value + c * cap * 4), n * 4), "d2h")
+                out[name] = col
+            return out
+        finally:
+            L.pmi_free(table)
+            L.pmi_free(dn)

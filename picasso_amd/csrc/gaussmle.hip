@@ -1,0 +1,753 @@
+// gaussmle.hip — Poisson-MLE fit of a pixel-integrated 2D Gaussian, one
+// wavefront (64 lanes) per spot, pixel(s)-per-lane, DPP wave reductions.
+//
+// Replaces picasso/gaussmle.py:28-168 (initial parameters), :268-383 (model and
+// derivatives), :533-670 (_mlefit_sigma, _update_theta_sigma), :745-884
+// (_mlefit_sigmaxy, _update_theta_sigmaxy), :673-742 / :887-954 (CRLB, log-
+// likelihood) and, when fed from the movie, picasso/localize.py:917-931
+// (_cut_spots_numba) + :1101-1112 (_to_photons).
+//
+// Arithmetic: the Newton iteration runs in float32 (the reference keeps its
+// state in float32 and promotes intermediates to float64; the difference is
+// below 1e-5 px after convergence).  Initial sums, the Fisher
+// matrix and its inverse are float64 like the reference.  The quirks of the
+// reference are kept: max_step from the INITIAL theta with theta[4] for both x
+// and y; the 10e-3 / 10e4 literals; sign(num)*max_step vs sign(num*max_step)
+// on a zero denominator; the un-multiplied terms of the isotropic second
+// derivative (gaussmle.py:380-382).
+#include <algorithm>
+#include <cmath>
+
+#include "pmi_common.h"
+
+namespace pmi {
+
+constexpr int FIT_WAVES = 4;                 // waves per workgroup
+constexpr int FIT_NT = FIT_WAVES * PMI_WAVE;
+constexpr int FIT_MAXPIX = PMI_MAX_BOX * PMI_MAX_BOX;
+
+struct FitParams {
+    // source: spots (float32) or movie + identifications
+    const float *spots;
+    const void *movie;
+    const int32_t *frame, *y, *x;
+    int dtype;
+    int64_t Y, X;
+    float baseline, sensitivity, gain;
+    // common
+    int64_t N;             // capacity / number of rows
+    const int64_t *d_n;    // optional device row count
+    int box;
+    float eps_f;           // unused (kept for layout)
+    double eps;
+    int max_it;
+    float *thetas, *crlbs, *loglik;
+    int32_t *iterations;
+    unsigned long long *queue;   // dynamic spot queue
+    int *fallback_count;         // spots whose Fisher matrix needs the pinv path
+    int fallback_cap;
+    int *fallback_idx;
+    double *fallback_M;          // 36 doubles per flagged spot
+};
+
+// ---- DPP wave reductions -------------------------------------------------
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ float dpp_f(float v)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
+}
+// sum over the 64 lanes, result uniform (broadcast from lane 63)
+__device__ __forceinline__ float wave_sum(float v)
+{
+    v += dpp_f<0xB1>(v);          // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);          // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);         // row_half_mirror
+    v += dpp_f<0x140>(v);         // row_mirror
+    v += dpp_f<0x142, 0xA>(v);    // row_bcast15 -> rows 1,3
+    v += dpp_f<0x143, 0xC>(v);    // row_bcast31 -> rows 2,3
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+}
+template <int CTRL, int ROW_MASK = 0xf>
+__device__ __forceinline__ double dpp_d(double v)
+{
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_sum_d(double v)
+{
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x141>(v);
+    v += dpp_d<0x140>(v);
+    v += dpp_d<0x142, 0xA>(v);
+    v += dpp_d<0x143, 0xC>(v);
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ float wave_min(float v)
+{
+    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+    return v;
+}
+
+// numpy-style NaN-propagating max/min and sign
+__device__ __forceinline__ float np_maxf(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+__device__ __forceinline__ float np_minf(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+__device__ __forceinline__ float np_signf(float a) { return (a != a) ? a : (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f)); }
+
+// One-dimensional pixel-integrated Gaussian terms for pixel index `i`:
+//   E   = deltaE                      (gaussmle.py:268-280)
+//   A   = dE/dmu,   A2 = d2E/dmu2     (gaussmle.py:283-303, without photons*PSF_other)
+//   S   = dE/dsig,  S2 = d2E/dsig2    (gaussmle.py:306-336)
+struct Terms { float E, A, A2, S, S2; };
+__device__ __forceinline__ Terms gauss_terms(float i, float mu, float sigma)
+{
+    const float is = 1.0f / sigma;
+    const float sn = 0.70710678118654757f * is;
+    const float c1 = 0.3989422804014327f * is;      // 1/(sqrt(2 pi) sigma)
+    const float is2 = is * is;
+    const float dm = i - mu - 0.5f, dp = i - mu + 0.5f;
+    Terms t;
+    t.E = 0.5f * (erff(dp * sn) - erff(dm * sn));
+    const float gm = __expf(-0.5f * dm * dm * is2), gp = __expf(-0.5f * dp * dp * is2);
+    const float q1 = dm * gm - dp * gp;
+    const float q3 = dm * dm * dm * gm - dp * dp * dp * gp;
+    t.A = (gm - gp) * c1;
+    t.A2 = q1 * c1 * is2;
+    t.S = q1 * c1 * is;
+    t.S2 = c1 * is2 * (q3 * is2 - 2.0f * q1);
+    return t;
+}
+
+__device__ __forceinline__ float load_movie_px(const void *movie, int dtype, int64_t idx)
+{
+    switch (dtype) {
+    case PMI_U16: return (float)((const uint16_t *)movie)[idx];
+    case PMI_U8:  return (float)((const uint8_t *)movie)[idx];
+    case PMI_I16: return (float)((const int16_t *)movie)[idx];
+    case PMI_U32: return (float)((const uint32_t *)movie)[idx];
+    case PMI_I32: return (float)((const int32_t *)movie)[idx];
+    default:      return ((const float *)movie)[idx];
+    }
+}
+
+// NP = params (5: "sigma", 6: "sigmaxy"); PPL = pixels per lane = ceil(box^2/64)
+template <int NP, int PPL, bool FROM_MOVIE>
+__global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p)
+{
+    __shared__ float s_spot[FIT_WAVES][FIT_MAXPIX + 7];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    float *sp = s_spot[wid];
+    const int box = p.box, npix = box * box, h = box / 2;
+    int64_t n = p.N;
+    if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+
+    // static per-lane pixel coordinates
+    int pi[PPL], pj[PPL];
+    bool act[PPL];
+#pragma unroll
+    for (int s = 0; s < PPL; s++) {
+        int pix = lane + 64 * s;
+        act[s] = pix < npix;
+        int q = act[s] ? pix : 0;
+        pj[s] = q / box;            // row (y)
+        pi[s] = q - pj[s] * box;    // column (x)
+    }
+
+    for (;;) {
+        unsigned long long sidx = 0;
+        if (lane == 0) sidx = atomicAdd(p.queue, 1ull);
+        sidx = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(sidx >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)(sidx & 0xffffffffu));
+        if ((int64_t)sidx >= n) break;
+
+        // ---- load the spot (photons) -----------------------------------
+        float data[PPL];
+#pragma unroll
+        for (int s = 0; s < PPL; s++) {
+            float v = 0.f;
+            if (act[s]) {
+                if (FROM_MOVIE) {
+                    int64_t fr = p.frame[sidx], yy = p.y[sidx], xx = p.x[sidx];
+                    float raw = load_movie_px(p.movie, p.dtype, (fr * p.Y + (yy - h + pj[s])) * p.X + (xx - h + pi[s]));
+                    // localize.py:1112, float32, in this order (no contraction possible: sub, mul, div)
+                    v = ((raw - p.baseline) * p.sensitivity) / p.gain;
+                } else {
+                    v = p.spots[(int64_t)sidx * npix + lane + 64 * s];
+                }
+                sp[lane + 64 * s] = v;
+            }
+            data[s] = v;
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+
+        // ---- initial parameters (gaussmle.py:28-139) -------------------
+        double ds = 0.0, dsy = 0.0, dsx = 0.0;
+        float fmin_local = INFINITY;
+#pragma unroll
+        for (int s = 0; s < PPL; s++)
+            if (act[s]) {
+                double v = (double)data[s];
+                ds += v; dsy += v * (double)pj[s]; dsx += v * (double)pi[s];
+                // 3x3 edge-clipped mean, float64 sum in (m, n) order, float32 store
+                int k = pj[s], l = pi[s];
+                int m0 = max(0, k - 1), m1 = min(box, k + 2), n0 = max(0, l - 1), n1 = min(box, l + 2);
+                double nsum = 0.0;
+                for (int m = m0; m < m1; m++)
+                    for (int q = n0; q < n1; q++) nsum += (double)sp[m * box + q];
+                float filt = (float)(nsum / (double)((m1 - m0) * (n1 - n0)));
+                fmin_local = fminf(fmin_local, filt);
+            }
+        double sum = wave_sum_d(ds), sy_ = wave_sum_d(dsy), sx_ = wave_sum_d(dsx);
+        const float bg0 = wave_min(fmin_local);
+        double com_y, com_x;
+        if (sum <= 0.0) { sum = 0.01; com_y = (box - 1) / 2.0; com_x = (box - 1) / 2.0; }
+        else { com_y = sy_ / sum; com_x = sx_ / sum; }
+        double photons = sum - (double)(box * box) * (double)bg0;
+        photons = (photons != photons) ? photons : (photons > 1.0 ? photons : 1.0);
+        // centre row / column second moments of (spot - bg) about box//2
+        double a_sdy = 0.0, a_sdx = 0.0, a_sy = 0.0, a_sx = 0.0;
+#pragma unroll
+        for (int s = 0; s < PPL; s++)
+            if (act[s]) {
+                float vm = data[s] - bg0;
+                if (pi[s] == h) { double d2 = (double)((pj[s] - h) * (pj[s] - h)); a_sdy += (double)vm * d2; a_sy += (double)vm; }
+                if (pj[s] == h) { double d2 = (double)((pi[s] - h) * (pi[s] - h)); a_sdx += (double)vm * d2; a_sx += (double)vm; }
+            }
+        a_sdy = wave_sum_d(a_sdy); a_sy = wave_sum_d(a_sy); a_sdx = wave_sum_d(a_sdx); a_sx = wave_sum_d(a_sx);
+        double isy = sqrt(a_sdy / a_sy), isx = sqrt(a_sdx / a_sx);
+        if (!isfinite(isy)) isy = 0.01;
+        if (!isfinite(isx)) isx = 0.01;
+        if (isx == 0) isx = 0.01;
+        if (isy == 0) isy = 0.01;
+
+        float th[6];
+        th[0] = (float)com_x; th[1] = (float)com_y; th[2] = (float)photons; th[3] = bg0;
+        if (NP == 6) { th[4] = (float)isx; th[5] = (float)isy; }
+        else { th[4] = (float)((isx + isy) / 2); th[5] = 0.f; }
+        float ms[6];
+        ms[0] = th[4]; ms[1] = th[4];
+        ms[2] = (float)(0.1 * (double)th[2]); ms[3] = (float)(0.1 * (double)th[3]);
+        ms[4] = (float)(0.2 * (double)th[4]); ms[5] = (float)(0.2 * (double)th[5]);
+
+        float old_x = th[0], old_y = th[1], old_sx = th[4], old_sy = th[5];
+        int kk = 0;
+        while (kk < p.max_it) {
+            kk++;
+            float num[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, den[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            const float sgy = NP == 6 ? th[5] : th[4];
+#pragma unroll
+            for (int s = 0; s < PPL; s++) {
+                Terms tx = gauss_terms((float)pi[s], th[0], th[4]);
+                Terms ty = gauss_terms((float)pj[s], th[1], sgy);
+                const float N_ = th[2];
+                float du[6], d2[6];
+                du[0] = N_ * ty.E * tx.A;  d2[0] = N_ * ty.E * tx.A2;
+                du[1] = N_ * tx.E * ty.A;  d2[1] = N_ * tx.E * ty.A2;
+                du[2] = tx.E * ty.E;       d2[2] = 0.f;
+                du[3] = 1.f;               d2[3] = 0.f;
+                if (NP == 6) {
+                    du[4] = N_ * ty.E * tx.S;  d2[4] = N_ * ty.E * tx.S2;
+                    du[5] = N_ * tx.E * ty.S;  d2[5] = N_ * tx.E * ty.S2;
+                } else {
+                    du[4] = N_ * (ty.E * tx.S + tx.E * ty.S);
+                    d2[4] = N_ * ty.E * tx.S2 + 2.f * tx.S * ty.S + tx.E * ty.S2;   // gaussmle.py:380-382
+                    du[5] = 0.f; d2[5] = 0.f;
+                }
+                const float model = N_ * tx.E * ty.E + th[3];
+                float cf = 0.f, df = 0.f;
+                if (model > 10e-3f) {
+                    const float r = 1.0f / model;
+                    cf = data[s] * r - 1.f;
+                    df = data[s] * r * r;
+                }
+                cf = np_minf(cf, 10e4f);
+                df = np_minf(df, 10e4f);
+                if (!act[s]) { cf = 0.f; df = 0.f; }
+#pragma unroll
+                for (int l = 0; l < NP; l++) {
+                    num[l] += cf * du[l];
+                    den[l] += cf * d2[l] - df * du[l] * du[l];
+                }
+            }
+#pragma unroll
+            for (int l = 0; l < NP; l++) { num[l] = wave_sum(num[l]); den[l] = wave_sum(den[l]); }
+
+            if (NP == 6) {                                  // gaussmle.py:860-884
+#pragma unroll
+                for (int l = 0; l < 6; l++) {
+                    if (den[l] == 0.0f) th[l] = th[l] - np_signf(num[l]) * ms[l];
+                    else th[l] = th[l] - np_minf(np_maxf(num[l] / den[l], -ms[l]), ms[l]);
+                }
+                th[2] = np_maxf(th[2], 1.0f); th[3] = np_maxf(th[3], 0.01f);
+                th[4] = np_maxf(th[4], 0.01f); th[5] = np_maxf(th[5], 0.01f);
+                bool conv = ((double)fabsf(old_x - th[0]) < p.eps) && ((double)fabsf(old_y - th[1]) < p.eps) &&
+                            ((double)fabsf(old_sx - th[4]) < p.eps) && ((double)fabsf(old_sy - th[5]) < p.eps);
+                if (conv) break;
+                old_x = th[0]; old_y = th[1]; old_sx = th[4]; old_sy = th[5];
+            } else {                                        // gaussmle.py:647-670
+#pragma unroll
+                for (int l = 0; l < 5; l++) {
+                    float upd;
+                    if (den[l] == 0.0f) upd = np_signf(num[l] * ms[l]);
+                    else upd = np_minf(np_maxf(num[l] / den[l], -ms[l]), ms[l]);
+                    th[l] = th[l] - upd;
+                }
+                th[2] = np_maxf(th[2], 1.0f); th[3] = np_maxf(th[3], 0.01f);
+                th[4] = np_maxf(th[4], 0.01f); th[4] = np_minf(th[4], (float)box);
+                bool conv = ((double)fabsf(old_x - th[0]) < p.eps) && ((double)fabsf(old_y - th[1]) < p.eps);
+                if (conv) break;
+                old_x = th[0]; old_y = th[1];
+            }
+        }
+
+        // ---- CRLB and log-likelihood (gaussmle.py:673-742, 887-954) ----
+        double Mloc[21];
+#pragma unroll
+        for (int e = 0; e < 21; e++) Mloc[e] = 0.0;
+        float ll_loc = 0.f;
+        {
+            const float sgy = NP == 6 ? th[5] : th[4];
+#pragma unroll
+            for (int s = 0; s < PPL; s++) {
+                Terms tx = gauss_terms((float)pi[s], th[0], th[4]);
+                Terms ty = gauss_terms((float)pj[s], th[1], sgy);
+                const float N_ = th[2];
+                float du[6];
+                du[0] = N_ * ty.E * tx.A;
+                du[1] = N_ * tx.E * ty.A;
+                du[2] = tx.E * ty.E;
+                du[3] = 1.f;
+                if (NP == 6) { du[4] = N_ * ty.E * tx.S; du[5] = N_ * tx.E * ty.S; }
+                else { du[4] = N_ * (ty.E * tx.S + tx.E * ty.S); du[5] = 0.f; }
+                const float model = N_ * tx.E * ty.E + th[3];
+                if (act[s]) {
+                    const double inv = 1.0 / (double)model;
+                    int e = 0;
+#pragma unroll
+                    for (int k = 0; k < NP; k++)
+#pragma unroll
+                        for (int l = k; l < NP; l++) { Mloc[e] += (double)(du[l] * du[k]) * inv; e++; }
+                    if (model > 0.f) {
+                        const float d = data[s];
+                        if (d > 0.f) ll_loc += d * __logf(model / d) - (model - d);
+                        else ll_loc += -model;
+                    }
+                }
+            }
+        }
+        double M[36];
+        {
+            int e = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++)
+#pragma unroll
+                for (int l = k; l < NP; l++) { double v = wave_sum_d(Mloc[e]); M[k * NP + l] = v; M[l * NP + k] = v; e++; }
+        }
+        const float ll = wave_sum(ll_loc);
+
+        // LDL^T inverse diagonal; flagged for the pinv kernel when the matrix is not
+        // safely invertible in the sense of np.linalg.pinv's 1e-15 cutoff.
+        double L[36], D[6], diag[6];
+        bool bad = false;
+        double trM = 0.0;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            trM += M[i * NP + i];
+#pragma unroll
+            for (int j = 0; j <= i; j++) {
+                double a = M[i * NP + j];
+#pragma unroll
+                for (int k = 0; k < j; k++) a -= L[i * NP + k] * L[j * NP + k] * D[k];
+                if (j == i) { D[i] = a; if (!(a > 0.0)) bad = true; }
+                else L[i * NP + j] = a / D[j];
+            }
+        }
+        // Linv = inverse of unit lower-triangular L; diag(M^-1)_i = sum_k Linv[k][i]^2 / D[k]
+        double Li[36];
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+#pragma unroll
+            for (int j = 0; j < NP; j++) Li[i * NP + j] = (i == j) ? 1.0 : 0.0;
+#pragma unroll
+        for (int j = 0; j < NP; j++)
+#pragma unroll
+            for (int i = j + 1; i < NP; i++) {
+                double a = 0.0;
+#pragma unroll
+                for (int k = j; k < i; k++) a -= L[i * NP + k] * Li[k * NP + j];
+                Li[i * NP + j] = a;
+            }
+        double trInv = 0.0;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = i; k < NP; k++) a += Li[k * NP + i] * Li[k * NP + i] / D[k];
+            diag[i] = a;
+            trInv += a;
+        }
+        if (!(trM * trInv < 1e12)) bad = true;     // eigenvalue ratio could reach pinv's cutoff (or NaN)
+
+        if (lane == 0) {
+            float *to = p.thetas + sidx * 6, *co = p.crlbs + sidx * 6;
+#pragma unroll
+            for (int l = 0; l < 5; l++) to[l] = th[l];
+            to[5] = NP == 6 ? th[5] : th[4];
+#pragma unroll
+            for (int l = 0; l < NP; l++) co[l] = (float)diag[l];
+            if (NP == 5) co[5] = (float)diag[4];
+            p.loglik[sidx] = ll;
+            p.iterations[sidx] = kk;
+            if (bad) {
+                int slot = atomicAdd(p.fallback_count, 1);
+                if (slot < p.fallback_cap) {
+                    p.fallback_idx[slot] = (int)sidx;
+                    double *Mo = p.fallback_M + (size_t)slot * 36;
+                    for (int e = 0; e < NP * NP; e++) Mo[e] = M[e];
+                }
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// np.linalg.pinv diagonal for the flagged Fisher matrices (cyclic Jacobi,
+// singular values <= 1e-15 * max dropped).  One thread per flagged spot.
+template <int NP>
+__global__ void crlb_pinv_kernel(const int *__restrict__ count, int cap, const int *__restrict__ idx,
+                                 const double *__restrict__ Ms, float *__restrict__ crlbs)
+{
+    int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= *count || t >= cap) return;
+    double A[36], V[36];
+    bool nonfinite = false;
+    for (int i = 0; i < NP * NP; i++) { A[i] = Ms[(size_t)t * 36 + i]; if (!isfinite(A[i])) nonfinite = true; }
+    float *co = crlbs + (size_t)idx[t] * 6;
+    if (nonfinite) { for (int i = 0; i < 6; i++) co[i] = NAN; return; }
+    for (int i = 0; i < NP; i++) for (int j = 0; j < NP; j++) V[i * NP + j] = (i == j) ? 1.0 : 0.0;
+    for (int sweep = 0; sweep < 60; sweep++) {
+        double off = 0.0;
+        for (int a = 0; a < NP; a++) for (int b = a + 1; b < NP; b++) off += A[a * NP + b] * A[a * NP + b];
+        if (off == 0.0) break;
+        for (int a = 0; a < NP; a++)
+            for (int b = a + 1; b < NP; b++) {
+                double apq = A[a * NP + b];
+                if (apq == 0.0) continue;
+                double tau = (A[b * NP + b] - A[a * NP + a]) / (2.0 * apq);
+                double tt = (tau >= 0 ? 1.0 : -1.0) / (fabs(tau) + sqrt(1.0 + tau * tau));
+                double c = 1.0 / sqrt(1.0 + tt * tt), s = tt * c;
+                for (int k = 0; k < NP; k++) { double x = A[k * NP + a], y = A[k * NP + b]; A[k * NP + a] = c * x - s * y; A[k * NP + b] = s * x + c * y; }
+                for (int k = 0; k < NP; k++) { double x = A[a * NP + k], y = A[b * NP + k]; A[a * NP + k] = c * x - s * y; A[b * NP + k] = s * x + c * y; }
+                for (int k = 0; k < NP; k++) { double x = V[k * NP + a], y = V[k * NP + b]; V[k * NP + a] = c * x - s * y; V[k * NP + b] = s * x + c * y; }
+            }
+    }
+    double smax = 0.0;
+    for (int i = 0; i < NP; i++) smax = fmax(smax, fabs(A[i * NP + i]));
+    const double cutoff = 1e-15 * smax;
+    double diag[6];
+    for (int i = 0; i < NP; i++) {
+        double acc = 0.0;
+        for (int k = 0; k < NP; k++) { double lam = A[k * NP + k]; if (fabs(lam) > cutoff) acc += V[i * NP + k] * V[i * NP + k] / lam; }
+        diag[i] = acc;
+    }
+    for (int i = 0; i < NP; i++) co[i] = (float)diag[i];
+    if (NP == 5) co[5] = (float)diag[4];
+}
+
+template <int NP, bool FROM_MOVIE>
+static void launch_fit_ppl(int ppl, dim3 grid, hipStream_t s, const FitParams &p)
+{
+    switch (ppl) {
+    case 1: hipLaunchKernelGGL((mle_fit_kernel<NP, 1, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
+    case 2: hipLaunchKernelGGL((mle_fit_kernel<NP, 2, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
+    case 3: hipLaunchKernelGGL((mle_fit_kernel<NP, 3, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
+    case 4: hipLaunchKernelGGL((mle_fit_kernel<NP, 4, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
+    case 5: hipLaunchKernelGGL((mle_fit_kernel<NP, 5, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
+    case 6: hipLaunchKernelGGL((mle_fit_kernel<NP, 6, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
+    default: hipLaunchKernelGGL((mle_fit_kernel<NP, 7, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
+    }
+}
+
+static int g_cu_count = 0;
+
+int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
+{
+    if (p.box < 3 || p.box > PMI_MAX_BOX || (p.box & 1) == 0) { set_error("box must be odd, 3..%d (got %d)", PMI_MAX_BOX, p.box); return PMI_ERR_ARG; }
+    if (method != PMI_MLE_SIGMA && method != PMI_MLE_SIGMAXY) { set_error("Method not available."); return PMI_ERR_ARG; }
+    if (p.N < 0) { set_error("negative N"); return PMI_ERR_ARG; }
+    if (p.N == 0) return PMI_OK;
+    if (p.N > 0x7fffffffLL) { set_error("too many spots for one call"); return PMI_ERR_ARG; }
+    if (!g_cu_count) {
+        int dev = 0;
+        PMI_HIP(hipGetDevice(&dev));
+        PMI_HIP(hipDeviceGetAttribute(&g_cu_count, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    void *ptr = nullptr;
+    int rc;
+    // queue counter + fallback counter, then fallback index list and matrices
+    // The pinv fallback store is sized for the worst case only for small batches; large
+    // batches cap it (ill-conditioned Fisher matrices are rare) and flags beyond the cap
+    // keep their LDL^T result.
+    size_t fb_cap = (size_t)std::min<int64_t>(p.N, 1 << 18);
+    p.fallback_cap = (int)fb_cap;
+    if ((rc = scratch(SCR_FIT, 64 + fb_cap * sizeof(int) + 64, &ptr)) != PMI_OK) return rc;
+    p.queue = (unsigned long long *)ptr;
+    p.fallback_count = (int *)((char *)ptr + 16);
+    p.fallback_idx = (int *)((char *)ptr + 64);
+    void *mptr = nullptr;
+    if ((rc = scratch(SCR_STAGE_D, fb_cap * 36 * sizeof(double), &mptr)) != PMI_OK) return rc;
+    p.fallback_M = (double *)mptr;
+    PMI_HIP(hipMemsetAsync(ptr, 0, 64, s));
+
+    const int ppl = (p.box * p.box + 63) / 64;
+    int64_t blocks = std::min<int64_t>((p.N + FIT_WAVES - 1) / FIT_WAVES, (int64_t)g_cu_count * 8);
+    dim3 grid((unsigned)std::max<int64_t>(blocks, 1));
+    {
+        ScopedKernelTimer tm(s, &g_last_times.fit_ms);
+        if (method == PMI_MLE_SIGMAXY) {
+            if (from_movie) launch_fit_ppl<6, true>(ppl, grid, s, p); else launch_fit_ppl<6, false>(ppl, grid, s, p);
+        } else {
+            if (from_movie) launch_fit_ppl<5, true>(ppl, grid, s, p); else launch_fit_ppl<5, false>(ppl, grid, s, p);
+        }
+        tm.stop();
+    }
+    PMI_HIP(hipGetLastError());
+    unsigned fb_blocks = (unsigned)((fb_cap + 63) / 64);
+    if (method == PMI_MLE_SIGMAXY)
+        hipLaunchKernelGGL((crlb_pinv_kernel<6>), dim3(fb_blocks), dim3(64), 0, s, p.fallback_count, p.fallback_cap, p.fallback_idx, p.fallback_M, p.crlbs);
+    else
+        hipLaunchKernelGGL((crlb_pinv_kernel<5>), dim3(fb_blocks), dim3(64), 0, s, p.fallback_count, p.fallback_cap, p.fallback_idx, p.fallback_M, p.crlbs);
+    PMI_HIP(hipGetLastError());
+    return PMI_OK;
+}
+
+// ---- get_spots -----------------------------------------------------------
+__global__ void cut_spots_kernel(const void *__restrict__ movie, int dtype, int64_t Y, int64_t X,
+                                 const int32_t *__restrict__ frame, const int32_t *__restrict__ y,
+                                 const int32_t *__restrict__ x, int64_t N, const int64_t *__restrict__ d_n,
+                                 int box, float baseline, float sensitivity, float gain, float *__restrict__ spots)
+{
+    int64_t n = N;
+    if (d_n) { int64_t dn = *d_n; n = dn < n ? dn : n; }
+    const int npix = box * box, h = box / 2;
+    int64_t total = n * npix;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (int64_t)gridDim.x * blockDim.x) {
+        int64_t i = t / npix;
+        int q = (int)(t - i * npix);
+        int a = q / box, c = q - a * box;
+        float raw = load_movie_px(movie, dtype, ((int64_t)frame[i] * Y + (y[i] - h + a)) * X + (x[i] - h + c));
+        spots[t] = ((raw - baseline) * sensitivity) / gain;
+    }
+}
+
+// ---- locs_from_fits (gaussmle.py:957-1037) -------------------------------
+struct LocCols { void *c[PMI_LOC_COLUMNS]; };
+__global__ void locs_from_fits_kernel(const int32_t *__restrict__ frame, const int32_t *__restrict__ y,
+                                      const int32_t *__restrict__ x, const float *__restrict__ ng,
+                                      const float *__restrict__ th, const float *__restrict__ cr,
+                                      const float *__restrict__ ll, const int32_t *__restrict__ it, int64_t N,
+                                      const int64_t *__restrict__ d_n, int box, LocCols cols)
+{
+    int64_t n = N;
+    if (d_n) { int64_t dn = *d_n; n = dn < n ? dn : n; }
+    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int off = box / 2;
+    const float *t = th + i * 6, *c = cr + i * 6;
+    // float32 theta + int64 coordinate -> float64 in pandas, then - offset, then cast
+    ((uint32_t *)cols.c[0])[i] = (uint32_t)frame[i];
+    ((float *)cols.c[1])[i] = (float)((double)t[0] + (double)x[i] - (double)off);
+    ((float *)cols.c[2])[i] = (float)((double)t[1] + (double)y[i] - (double)off);
+    ((float *)cols.c[3])[i] = t[2];
+    ((float *)cols.c[4])[i] = t[4];
+    ((float *)cols.c[5])[i] = t[5];
+    ((float *)cols.c[6])[i] = t[3];
+    ((float *)cols.c[7])[i] = sqrtf(c[0]);
+    ((float *)cols.c[8])[i] = sqrtf(c[1]);
+    float a = np_maxf(t[4], t[5]), b = np_minf(t[4], t[5]);
+    ((float *)cols.c[9])[i] = (a - b) / a;
+    ((float *)cols.c[10])[i] = ng[i];
+    ((float *)cols.c[11])[i] = ll[i];
+    ((uint32_t *)cols.c[12])[i] = (uint32_t)it[i];
+    ((float *)cols.c[13])[i] = sqrtf(c[2]);
+    ((float *)cols.c[14])[i] = sqrtf(c[3]);
+    ((float *)cols.c[15])[i] = sqrtf(c[4]);
+    ((float *)cols.c[16])[i] = sqrtf(c[5]);
+}
+
+int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X, int box, double min_ng,
+                  const int64_t *roi4, int64_t f_lo, int64_t f_hi, int64_t label_offset,
+                  int32_t *d_frame, int32_t *d_y, int32_t *d_x, float *d_ng, int64_t cap, int64_t *d_out_n,
+                  hipStream_t s);
+
+}  // namespace pmi
+
+extern "C" {
+
+int pmi_gaussmle_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box, double eps, int max_it,
+                     int method, float *d_thetas, float *d_crlbs, float *d_loglik, int32_t *d_iterations,
+                     void *stream)
+{
+    pmi::FitParams p = {};
+    p.spots = d_spots; p.N = N; p.d_n = d_n; p.box = box; p.eps = eps; p.max_it = max_it;
+    p.thetas = d_thetas; p.crlbs = d_crlbs; p.loglik = d_loglik; p.iterations = d_iterations;
+    return pmi::fit_impl(p, method, false, (hipStream_t)stream);
+}
+
+int pmi_gaussmle_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
+                           const int32_t *d_frame, const int32_t *d_y, const int32_t *d_x, int64_t N,
+                           const int64_t *d_n, int box, double baseline, double sensitivity, double gain,
+                           double eps, int max_it, int method, float *d_thetas, float *d_crlbs,
+                           float *d_loglik, int32_t *d_iterations, void *stream)
+{
+    (void)F;
+    if (dtype < 0 || dtype > PMI_F32) { pmi::set_error("unknown dtype code %d", dtype); return PMI_ERR_ARG; }
+    pmi::FitParams p = {};
+    p.movie = d_movie; p.dtype = dtype; p.Y = Y; p.X = X; p.frame = d_frame; p.y = d_y; p.x = d_x;
+    p.baseline = (float)baseline; p.sensitivity = (float)sensitivity; p.gain = (float)gain;
+    p.N = N; p.d_n = d_n; p.box = box; p.eps = eps; p.max_it = max_it;
+    p.thetas = d_thetas; p.crlbs = d_crlbs; p.loglik = d_loglik; p.iterations = d_iterations;
+    return pmi::fit_impl(p, method, true, (hipStream_t)stream);
+}
+
+int pmi_gaussmle(const float *spots, int64_t N, int box, double eps, int max_it, int method, float *thetas,
+                 float *crlbs, float *loglik, int32_t *iterations)
+{
+    using namespace pmi;
+    if (pmi_device_count() < 1) { set_error("no HIP device"); return PMI_ERR_NODEVICE; }
+    if (method != PMI_MLE_SIGMA && method != PMI_MLE_SIGMAXY) { set_error("Method not available."); return PMI_ERR_ARG; }
+    if (N == 0) return PMI_OK;
+    if (!spots || !thetas || !crlbs || !loglik || !iterations) { set_error("null pointer"); return PMI_ERR_ARG; }
+    void *d_in = nullptr, *d_out = nullptr;
+    int rc;
+    size_t in_bytes = (size_t)N * box * box * sizeof(float);
+    if ((rc = scratch(SCR_STAGE_A, in_bytes, &d_in)) != PMI_OK) return rc;
+    if ((rc = scratch(SCR_STAGE_B, (size_t)N * 14 * 4, &d_out)) != PMI_OK) return rc;
+    float *d_th = (float *)d_out, *d_cr = d_th + N * 6, *d_ll = d_cr + N * 6;
+    int32_t *d_it = (int32_t *)(d_ll + N);
+    PMI_HIP(hipMemcpy(d_in, spots, in_bytes, hipMemcpyHostToDevice));
+    rc = pmi_gaussmle_dev((const float *)d_in, N, nullptr, box, eps, max_it, method, d_th, d_cr, d_ll, d_it, nullptr);
+    if (rc != PMI_OK) return rc;
+    PMI_HIP(hipMemcpy(thetas, d_th, (size_t)N * 24, hipMemcpyDeviceToHost));
+    PMI_HIP(hipMemcpy(crlbs, d_cr, (size_t)N * 24, hipMemcpyDeviceToHost));
+    PMI_HIP(hipMemcpy(loglik, d_ll, (size_t)N * 4, hipMemcpyDeviceToHost));
+    PMI_HIP(hipMemcpy(iterations, d_it, (size_t)N * 4, hipMemcpyDeviceToHost));
+    return PMI_OK;
+}
+
+int pmi_get_spots_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X, const int32_t *d_frame,
+                      const int32_t *d_y, const int32_t *d_x, int64_t N, const int64_t *d_n, int box,
+                      double baseline, double sensitivity, double gain, float *d_spots, void *stream)
+{
+    (void)F;
+    using namespace pmi;
+    if (box < 1 || box > PMI_MAX_BOX) { set_error("bad box %d", box); return PMI_ERR_ARG; }
+    if (dtype < 0 || dtype > PMI_F32) { set_error("unknown dtype code %d", dtype); return PMI_ERR_ARG; }
+    if (N <= 0) return PMI_OK;
+    int64_t total = N * box * box;
+    unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 64);
+    hipLaunchKernelGGL(cut_spots_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_movie, dtype, Y, X,
+                       d_frame, d_y, d_x, N, d_n, box, (float)baseline, (float)sensitivity, (float)gain, d_spots);
+    PMI_HIP(hipGetLastError());
+    return PMI_OK;
+}
+
+static size_t px_size(int dtype) { return dtype == PMI_U8 ? 1 : ((dtype == PMI_U16 || dtype == PMI_I16) ? 2 : 4); }
+
+// Host form: uploads only the frames the identifications touch, one chunk at a time.
+int pmi_get_spots(const void *movie, int dtype, int64_t F, int64_t Y, int64_t X, const int32_t *frame,
+                  const int32_t *y, const int32_t *x, int64_t N, int box, double baseline, double sensitivity,
+                  double gain, float *out_spots)
+{
+    using namespace pmi;
+    if (pmi_device_count() < 1) { set_error("no HIP device"); return PMI_ERR_NODEVICE; }
+    if (N == 0) return PMI_OK;
+    if (!movie || !frame || !y || !x || !out_spots) { set_error("null pointer"); return PMI_ERR_ARG; }
+    if (dtype < 0 || dtype > PMI_F32) { set_error("unknown dtype code %d", dtype); return PMI_ERR_ARG; }
+    const int r = box / 2;
+    for (int64_t i = 0; i < N; i++)
+        if (frame[i] < 0 || frame[i] >= F || y[i] - r < 0 || y[i] + r >= Y || x[i] - r < 0 || x[i] + r >= X) {
+            set_error("identification %lld lies outside the movie", (long long)i);
+            return PMI_ERR_ARG;
+        }
+    const size_t frame_bytes = (size_t)Y * X * px_size(dtype);
+    const int64_t chunk = std::max<int64_t>(1, (int64_t)((size_t)1 << 30) / (int64_t)frame_bytes);
+    void *d_chunk = nullptr, *d_ids = nullptr, *d_sp = nullptr;
+    int rc;
+    if ((rc = scratch(SCR_STAGE_A, (size_t)std::min<int64_t>(chunk, F) * frame_bytes, &d_chunk)) != PMI_OK) return rc;
+    if ((rc = scratch(SCR_STAGE_B, (size_t)N * 12, &d_ids)) != PMI_OK) return rc;
+    if ((rc = scratch(SCR_STAGE_C, (size_t)N * box * box * 4, &d_sp)) != PMI_OK) return rc;
+    int32_t *d_f = (int32_t *)d_ids, *d_y = d_f + N, *d_x = d_y + N;
+    // identifications are normally frame-sorted; process maximal runs that fit one chunk
+    std::vector<int32_t> rel(N);
+    int64_t i0 = 0;
+    while (i0 < N) {
+        int64_t fmin = frame[i0], fmax = frame[i0], i1 = i0 + 1;
+        while (i1 < N) {
+            int64_t lo = std::min<int64_t>(fmin, frame[i1]), hi = std::max<int64_t>(fmax, frame[i1]);
+            if (hi - lo + 1 > chunk) break;
+            fmin = lo; fmax = hi; i1++;
+        }
+        int64_t cnt = i1 - i0, nfc = fmax - fmin + 1;
+        for (int64_t i = i0; i < i1; i++) rel[i - i0] = (int32_t)(frame[i] - fmin);
+        PMI_HIP(hipMemcpy(d_chunk, (const char *)movie + (size_t)fmin * frame_bytes, (size_t)nfc * frame_bytes, hipMemcpyHostToDevice));
+        PMI_HIP(hipMemcpy(d_f, rel.data(), (size_t)cnt * 4, hipMemcpyHostToDevice));
+        PMI_HIP(hipMemcpy(d_y, y + i0, (size_t)cnt * 4, hipMemcpyHostToDevice));
+        PMI_HIP(hipMemcpy(d_x, x + i0, (size_t)cnt * 4, hipMemcpyHostToDevice));
+        rc = pmi_get_spots_dev(d_chunk, dtype, nfc, Y, X, d_f, d_y, d_x, cnt, nullptr, box, baseline, sensitivity, gain, (float *)d_sp, nullptr);
+        if (rc != PMI_OK) return rc;
+        PMI_HIP(hipMemcpy(out_spots + (size_t)i0 * box * box, d_sp, (size_t)cnt * box * box * 4, hipMemcpyDeviceToHost));
+        i0 = i1;
+    }
+    return PMI_OK;
+}
+
+int pmi_locs_from_fits_dev(const int32_t *d_frame, const int32_t *d_y, const int32_t *d_x, const float *d_ng,
+                           const float *d_thetas, const float *d_crlbs, const float *d_loglik,
+                           const int32_t *d_iterations, int64_t N, const int64_t *d_n, int box,
+                           void *const *d_cols, void *stream)
+{
+    using namespace pmi;
+    if (N <= 0) return PMI_OK;
+    LocCols cols;
+    for (int c = 0; c < PMI_LOC_COLUMNS; c++) cols.c[c] = d_cols[c];
+    unsigned blocks = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(locs_from_fits_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_frame, d_y, d_x,
+                       d_ng, d_thetas, d_crlbs, d_loglik, d_iterations, N, d_n, box, cols);
+    PMI_HIP(hipGetLastError());
+    return PMI_OK;
+}
+
+int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X, int box, double min_ng,
+                         const int64_t *roi4, int64_t f_lo, int64_t f_hi, double baseline, double sensitivity,
+                         double gain, double eps, int max_it, int method, void *d_table, int64_t cap,
+                         int64_t *d_out_n, void *stream)
+{
+    using namespace pmi;
+    if (cap <= 0) { set_error("capacity must be positive"); return PMI_ERR_ARG; }
+    hipStream_t s = (hipStream_t)stream;
+    void *ptr = nullptr;
+    int rc;
+    if ((rc = scratch(SCR_IDS, (size_t)cap * (16 + 14 * 4), &ptr)) != PMI_OK) return rc;
+    int32_t *d_f = (int32_t *)ptr, *d_y = d_f + cap, *d_x = d_y + cap;
+    float *d_ng = (float *)(d_x + cap);
+    float *d_th = d_ng + cap, *d_cr = d_th + cap * 6, *d_ll = d_cr + cap * 6;
+    int32_t *d_it = (int32_t *)(d_ll + cap);
+    rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, f_lo, f_hi, 0, d_f, d_y, d_x, d_ng, cap, d_out_n, s);
+    if (rc != PMI_OK) return rc;
+    rc = pmi_gaussmle_movie_dev(d_movie, dtype, F, Y, X, d_f, d_y, d_x, cap, d_out_n, box, baseline, sensitivity,
+                                gain, eps, max_it, method, d_th, d_cr, d_ll, d_it, stream);
+    if (rc != PMI_OK) return rc;
+    void *cols[PMI_LOC_COLUMNS];
+    for (int c = 0; c < PMI_LOC_COLUMNS; c++) cols[c] = (char *)d_table + (size_t)c * cap * 4;
+    return pmi_locs_from_fits_dev(d_f, d_y, d_x, d_ng, d_th, d_cr, d_ll, d_it, cap, d_out_n, box, cols, stream);
+}
+
+}  // extern "C"

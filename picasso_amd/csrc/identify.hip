@@ -1,0 +1,414 @@
+// identify.hip — spot identification on a frame stack (HBM-bound stage).
+//
+// Replaces picasso/localize.py:97-134 (_local_maxima), :202-244 (_net_gradient),
+// :247-292 (identify_in_image), :295-337 (ROI crop + float32 cast) and the
+// frame loop of :604-636.  One workgroup owns one TH x TW tile of one frame:
+//   1. tile + (h+1)-pixel halo -> LDS as float32 (wrapping row/col -1 to the
+//      last row/col exactly like numba's negative indexing at :179-180);
+//   2. separable first-argmax test: a pixel is a maximum iff it is strictly
+//      greater than everything before it in row-major window order and >=
+//      everything after it (np.argmax returns the FIRST maximum);
+//   3. net gradient of every surviving candidate, float32, in the reference's
+//      (k, l) order with unfused multiply/add so the value is bit-identical;
+//   4. survivors (ng > min_ng) appended to an unordered record list.
+// Three small kernels then order the records by (frame, y, x): per-frame
+// counts -> exclusive scan -> scatter by frame -> rank sort inside each frame.
+#include <algorithm>
+#include <cmath>
+#include <vector>
+
+#include "pmi_common.h"
+
+// The net gradient must round like the reference's unfused float32 arithmetic:
+// no a*b+c contraction anywhere in this translation unit.
+#pragma clang fp contract(off)
+
+namespace pmi {
+
+constexpr int ID_TH = 32;    // tile rows
+constexpr int ID_TW = 128;   // tile cols
+constexpr int ID_NT = 256;   // threads per workgroup
+
+struct IdParams {
+    int64_t Y, X;        // full frame
+    int y0, x0, cy, cx;  // crop (ROI) origin and size
+    int64_t f_lo;        // label of the first frame scanned
+    int64_t frame_label_offset;  // added to labels (host chunking)
+    int nframes;
+    int box;
+    int tiles_y, tiles_x;
+    double min_ng;
+};
+
+template <typename T>
+__global__ __launch_bounds__(ID_NT) void identify_scan_kernel(
+    const T *__restrict__ movie, IdParams p, const float *__restrict__ uxy,
+    Record *__restrict__ recs, long long cap, unsigned long long *__restrict__ n_total,
+    int *__restrict__ frame_count)
+{
+    extern __shared__ float smem[];
+    const int box = p.box, h = box / 2, halo = h + 1;
+    const int LW = ID_TW + 2 * halo, LH = ID_TH + 2 * halo;
+    float *f = smem;                       // LH x LW pixels
+    float *H = f + LH * LW;                // LH x LW row-window maxima
+    float *sux = H + LH * LW;              // box x box
+    float *suy = sux + box * box;
+    unsigned *cand = (unsigned *)(suy + box * box);
+    __shared__ int ncand;
+
+    const int tid = threadIdx.x;
+    const int tiles = p.tiles_y * p.tiles_x;
+    const int fi = blockIdx.x / tiles;
+    const int t = blockIdx.x - fi * tiles;
+    const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
+    const T *src = movie + ((int64_t)(p.f_lo + fi) * p.Y + p.y0) * p.X + p.x0;
+
+    if (tid == 0) ncand = 0;
+    for (int idx = tid; idx < LH * LW; idx += ID_NT) {
+        int r = idx / LW, c = idx - r * LW;
+        int gy = ty * ID_TH - halo + r, gx = tx * ID_TW - halo + c;
+        if (gy < 0) gy += p.cy;            // numba negative-index wrap
+        if (gx < 0) gx += p.cx;
+        gy = min(max(gy, 0), p.cy - 1);    // rows/cols past the far edge are never read
+        gx = min(max(gx, 0), p.cx - 1);
+        f[idx] = px_f32(src, (int64_t)gy * p.X + gx);
+    }
+    for (int idx = tid; idx < box * box; idx += ID_NT) {
+        sux[idx] = uxy[idx];
+        suy[idx] = uxy[box * box + idx];
+    }
+    __syncthreads();
+
+    // pass A: horizontal window maximum for LDS rows 1 .. LH-2
+    for (int idx = tid; idx < (ID_TH + 2 * h) * ID_TW; idx += ID_NT) {
+        int r = 1 + idx / ID_TW, c = halo + idx % ID_TW;
+        const float *row = f + r * LW + c;
+        float m = row[-h];
+        for (int d = -h + 1; d <= h; d++) m = fmaxf(m, row[d]);
+        H[r * LW + c] = m;
+    }
+    __syncthreads();
+
+    // pass B: first-argmax test
+    for (int idx = tid; idx < ID_TH * ID_TW; idx += ID_NT) {
+        int rr = idx / ID_TW, cc = idx - rr * ID_TW;
+        int i = ty * ID_TH + rr, j = tx * ID_TW + cc;
+        bool valid = i >= h && i < p.cy - h - 1 && j >= h && j < p.cx - h - 1;   // localize.py:122-123
+        if (!valid) continue;
+        int r = halo + rr, c = halo + cc;
+        float v = f[r * LW + c];
+        float before = H[(r - 1) * LW + c], after = H[(r + 1) * LW + c];
+        for (int d = 2; d <= h; d++) {
+            before = fmaxf(before, H[(r - d) * LW + c]);
+            after = fmaxf(after, H[(r + d) * LW + c]);
+        }
+        for (int d = 1; d <= h; d++) {
+            before = fmaxf(before, f[r * LW + c - d]);
+            after = fmaxf(after, f[r * LW + c + d]);
+        }
+        if (v > before && v >= after) {
+            int slot = atomicAdd(&ncand, 1);
+            cand[slot] = ((unsigned)rr << 16) | (unsigned)cc;
+        }
+    }
+    __syncthreads();
+
+    // net gradient of each candidate: float32, (k, l) order, no FMA contraction
+    const int nc = ncand;
+    for (int q = tid; q < nc; q += ID_NT) {
+        int rr = cand[q] >> 16, cc = cand[q] & 0xffff;
+        int r = halo + rr, c = halo + cc;
+        float ng = 0.0f;
+        for (int k = 0; k < box; k++) {
+            const float *rowm = f + (r - h + k - 1) * LW + (c - h);
+            const float *row0 = rowm + LW;
+            const float *rowp = row0 + LW;
+            for (int l = 0; l < box; l++) {
+                if (k == h && l == h) continue;
+                float gy = __fsub_rn(rowp[l], rowm[l]);
+                float gx = __fsub_rn(row0[l + 1], row0[l - 1]);
+                float s = __fadd_rn(__fmul_rn(gy, suy[k * box + l]), __fmul_rn(gx, sux[k * box + l]));
+                ng = __fadd_rn(ng, s);
+            }
+        }
+        if ((double)ng > p.min_ng) {                                   // localize.py:288
+            unsigned long long pos = atomicAdd(n_total, 1ull);
+            atomicAdd(&frame_count[fi], 1);
+            if ((long long)pos < cap) {
+                Record rec;
+                rec.frame = (int32_t)(p.f_lo + fi + p.frame_label_offset);
+                rec.y = ty * ID_TH + rr + p.y0;
+                rec.x = tx * ID_TW + cc + p.x0;
+                rec.ng = ng;
+                recs[pos] = rec;
+            }
+        }
+    }
+}
+
+// exclusive scan of per-frame counts (single workgroup), also publishes the total
+__global__ __launch_bounds__(1024) void frame_scan_kernel(const int *__restrict__ count, int *__restrict__ base,
+                                                          int *__restrict__ cursor, int nframes,
+                                                          const unsigned long long *__restrict__ n_total,
+                                                          long long *__restrict__ out_n)
+{
+    __shared__ int buf[1024];
+    __shared__ int carry;
+    const int tid = threadIdx.x;
+    if (tid == 0) carry = 0;
+    __syncthreads();
+    for (int start = 0; start < nframes; start += 1024) {
+        int i = start + tid;
+        int v = i < nframes ? count[i] : 0;
+        buf[tid] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int add = tid >= off ? buf[tid - off] : 0;
+            __syncthreads();
+            buf[tid] += add;
+            __syncthreads();
+        }
+        int incl = buf[tid];
+        if (i < nframes) { base[i] = carry + incl - v; cursor[i] = 0; }
+        __syncthreads();
+        if (tid == 1023) carry += incl;
+        __syncthreads();
+    }
+    if (tid == 0 && out_n) *out_n = (long long)*n_total;
+}
+
+__global__ void scatter_by_frame_kernel(const Record *__restrict__ recs, const unsigned long long *__restrict__ n_total,
+                                        long long cap, long long f_first, const int *__restrict__ base,
+                                        int *__restrict__ cursor, Record *__restrict__ grouped)
+{
+    long long n = (long long)*n_total;
+    if (n > cap) n = cap;
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Record r = recs[i];
+    int fi = (int)(r.frame - f_first);
+    int slot = base[fi] + atomicAdd(&cursor[fi], 1);
+    grouped[slot] = r;
+}
+
+// one wave per frame: rank of each record among the frame's records by (y, x)
+__global__ __launch_bounds__(PMI_WAVE) void sort_in_frame_kernel(const Record *__restrict__ grouped,
+                                                                 const int *__restrict__ base,
+                                                                 const int *__restrict__ count,
+                                                                 const unsigned long long *__restrict__ n_total,
+                                                                 long long cap,
+                                                                 int32_t *__restrict__ o_frame, int32_t *__restrict__ o_y,
+                                                                 int32_t *__restrict__ o_x, float *__restrict__ o_ng)
+{
+    if ((long long)*n_total > cap) return;   // overflow: the caller retries with a larger capacity
+    const int fi = blockIdx.x;
+    const int m = count[fi], b = base[fi];
+    for (int q = threadIdx.x; q < m; q += PMI_WAVE) {
+        Record r = grouped[b + q];
+        long long key = ((long long)r.y << 32) | (unsigned)r.x;
+        int rank = 0;
+        for (int t = 0; t < m; t++) {
+            Record o = grouped[b + t];
+            long long ok = ((long long)o.y << 32) | (unsigned)o.x;
+            rank += ok < key;
+        }
+        o_frame[b + rank] = r.frame;
+        o_y[b + rank] = r.y;
+        o_x[b + rank] = r.x;
+        o_ng[b + rank] = r.ng;
+    }
+}
+
+// float32 unit-vector tables, built on the host with IEEE float ops exactly as
+// localize.py:279-286 does, cached on the device per box size.
+static float *g_unit_tables[PMI_MAX_BOX + 1] = {nullptr};
+
+static int unit_table(int box, const float **d_tab)
+{
+    if (!g_unit_tables[box]) {
+        std::vector<float> tab(2 * box * box);
+        int h = box / 2;
+        for (int k = 0; k < box; k++)
+            for (int l = 0; l < box; l++) {
+                volatile float vx = (float)(h - l), vy = (float)(h - k);
+                volatile float n2 = vx * vx + vy * vy;
+                volatile float n = sqrtf(n2);
+                tab[k * box + l] = vx / n;
+                tab[box * box + k * box + l] = vy / n;
+            }
+        float *d = nullptr;
+        PMI_HIP(hipMalloc(&d, tab.size() * sizeof(float)));
+        PMI_HIP(hipMemcpy(d, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
+        g_unit_tables[box] = d;
+    }
+    *d_tab = g_unit_tables[box];
+    return PMI_OK;
+}
+
+static size_t scan_lds_bytes(int box)
+{
+    int halo = box / 2 + 1;
+    size_t LW = ID_TW + 2 * halo, LH = ID_TH + 2 * halo;
+    return (2 * LW * LH + 2 * box * box) * sizeof(float) + (size_t)(ID_TH * ID_TW / 4 + 64) * sizeof(unsigned);
+}
+
+template <typename T>
+static int launch_scan(const void *d_movie, const IdParams &p, const float *d_tab, Record *recs, long long cap,
+                       unsigned long long *n_total, int *frame_count, hipStream_t s)
+{
+    size_t lds = scan_lds_bytes(p.box);
+    static bool attr_set[8] = {false};
+    (void)attr_set;
+    PMI_HIP(hipFuncSetAttribute((const void *)identify_scan_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    long long blocks = (long long)p.nframes * p.tiles_y * p.tiles_x;
+    if (blocks > 0x7fffffffLL) { set_error("identify: too many tiles (%lld)", blocks); return PMI_ERR_ARG; }
+    hipLaunchKernelGGL(identify_scan_kernel<T>, dim3((unsigned)blocks), dim3(ID_NT), lds, s,
+                       (const T *)d_movie, p, d_tab, recs, cap, n_total, frame_count);
+    PMI_HIP(hipGetLastError());
+    return PMI_OK;
+}
+
+// d_movie points at frame 0 of a stack holding at least frames [f_lo, f_hi].
+// Labels written = frame index + label_offset.
+int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X, int box, double min_ng,
+                  const int64_t *roi4, int64_t f_lo, int64_t f_hi, int64_t label_offset,
+                  int32_t *d_frame, int32_t *d_y, int32_t *d_x, float *d_ng, int64_t cap, int64_t *d_out_n,
+                  hipStream_t s)
+{
+    if (box < 3 || box > PMI_MAX_BOX || (box & 1) == 0) { set_error("box must be odd, 3..%d (got %d)", PMI_MAX_BOX, box); return PMI_ERR_ARG; }
+    if (F < 0 || Y <= 0 || X <= 0 || Y > 65535 || X > 65535) { set_error("bad movie shape (%lld,%lld,%lld)", (long long)F, (long long)Y, (long long)X); return PMI_ERR_ARG; }
+    if (cap < 0) { set_error("negative capacity"); return PMI_ERR_ARG; }
+    int64_t y0 = 0, x0 = 0, y1 = Y, x1 = X;
+    if (roi4) { y0 = roi4[0]; x0 = roi4[1]; y1 = roi4[2]; x1 = roi4[3]; }
+    if (y0 < 0 || x0 < 0 || y1 > Y || x1 > X) { set_error("roi outside the frame"); return PMI_ERR_ARG; }
+    if (f_lo < 0) f_lo = 0;
+    if (f_hi > F - 1) f_hi = F - 1;
+    int64_t nf = f_hi - f_lo + 1;
+    int64_t cy = y1 - y0, cx = x1 - x0;
+
+    unsigned long long *d_total = nullptr;
+    void *ptr = nullptr;
+    int rc;
+    if ((rc = scratch(SCR_COUNTERS, 64, &ptr)) != PMI_OK) return rc;
+    d_total = (unsigned long long *)ptr;
+    PMI_HIP(hipMemsetAsync(d_total, 0, 64, s));
+    if (nf <= 0 || cy < box + 1 || cx < box + 1) {   // no interior pixel can be scanned
+        PMI_HIP(hipMemsetAsync(d_out_n, 0, sizeof(int64_t), s));
+        return PMI_OK;
+    }
+    if (nf > 0x7fffffffLL) { set_error("too many frames"); return PMI_ERR_ARG; }
+
+    IdParams p;
+    p.Y = Y; p.X = X; p.y0 = (int)y0; p.x0 = (int)x0; p.cy = (int)cy; p.cx = (int)cx;
+    p.f_lo = f_lo; p.frame_label_offset = label_offset; p.nframes = (int)nf; p.box = box;
+    p.tiles_y = (int)((cy + ID_TH - 1) / ID_TH); p.tiles_x = (int)((cx + ID_TW - 1) / ID_TW);
+    p.min_ng = min_ng;
+
+    const float *d_tab = nullptr;
+    if ((rc = unit_table(box, &d_tab)) != PMI_OK) return rc;
+    Record *recs = nullptr, *grouped = nullptr;
+    int *fc = nullptr;
+    size_t rec_bytes = (size_t)std::max<int64_t>(cap, 1) * sizeof(Record);
+    if ((rc = scratch(SCR_RECORDS, rec_bytes, &ptr)) != PMI_OK) return rc; recs = (Record *)ptr;
+    if ((rc = scratch(SCR_RECORDS2, rec_bytes, &ptr)) != PMI_OK) return rc; grouped = (Record *)ptr;
+    if ((rc = scratch(SCR_FRAME_COUNT, (size_t)nf * 3 * sizeof(int), &ptr)) != PMI_OK) return rc; fc = (int *)ptr;
+    int *count = fc, *base = fc + nf, *cursor = fc + 2 * nf;
+    PMI_HIP(hipMemsetAsync(count, 0, (size_t)nf * sizeof(int), s));
+
+    {
+        ScopedKernelTimer tm(s, &g_last_times.scan_ms);
+        switch (dtype) {
+        case PMI_U16: rc = launch_scan<uint16_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;
+        case PMI_U8:  rc = launch_scan<uint8_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;
+        case PMI_I16: rc = launch_scan<int16_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;
+        case PMI_U32: rc = launch_scan<uint32_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;
+        case PMI_I32: rc = launch_scan<int32_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;
+        case PMI_F32: rc = launch_scan<float>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;
+        default: set_error("unknown dtype code %d", dtype); rc = PMI_ERR_ARG;
+        }
+        tm.stop();
+        if (rc != PMI_OK) return rc;
+    }
+    hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(1024), 0, s, count, base, cursor, (int)nf, d_total,
+                       (long long *)d_out_n);
+    if (cap > 0) {
+        unsigned sb = (unsigned)((cap + 255) / 256);
+        hipLaunchKernelGGL(scatter_by_frame_kernel, dim3(sb), dim3(256), 0, s, recs, d_total, (long long)cap,
+                           (long long)(f_lo + label_offset), base, cursor, grouped);
+        hipLaunchKernelGGL(sort_in_frame_kernel, dim3((unsigned)nf), dim3(PMI_WAVE), 0, s, grouped, base, count,
+                           d_total, (long long)cap, d_frame, d_y, d_x, d_ng);
+    }
+    PMI_HIP(hipGetLastError());
+    return PMI_OK;
+}
+
+}  // namespace pmi
+
+extern "C" {
+
+int pmi_identify_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X, int box, double min_ng,
+                     const int64_t *roi4, int64_t f_lo, int64_t f_hi, int32_t *d_frame, int32_t *d_y,
+                     int32_t *d_x, float *d_ng, int64_t cap, int64_t *d_out_n, void *stream)
+{
+    return pmi::identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, f_lo, f_hi, 0, d_frame, d_y, d_x, d_ng,
+                              cap, d_out_n, (hipStream_t)stream);
+}
+
+static size_t dtype_size(int dtype)
+{
+    switch (dtype) {
+    case PMI_U8: return 1;
+    case PMI_U16: case PMI_I16: return 2;
+    default: return 4;
+    }
+}
+
+// Host-buffer form: streams the movie through HBM in frame chunks.
+int pmi_identify(const void *movie, int dtype, int64_t F, int64_t Y, int64_t X, int box, double min_ng,
+                 const int64_t *roi4, int64_t f_lo, int64_t f_hi, int32_t *out_frame, int32_t *out_y,
+                 int32_t *out_x, float *out_ng, int64_t cap, int64_t *out_n)
+{
+    using namespace pmi;
+    if (pmi_device_count() < 1) { set_error("no HIP device"); return PMI_ERR_NODEVICE; }
+    if (!movie || !out_n) { set_error("null pointer"); return PMI_ERR_ARG; }
+    if (dtype < 0 || dtype > PMI_F32) { set_error("unknown dtype code %d", dtype); return PMI_ERR_ARG; }
+    if (f_lo < 0) f_lo = 0;
+    if (f_hi > F - 1) f_hi = F - 1;
+    *out_n = 0;
+    if (f_hi < f_lo) return PMI_OK;
+    const size_t frame_bytes = (size_t)Y * X * dtype_size(dtype);
+    const int64_t chunk = std::max<int64_t>(1, (int64_t)((size_t)1 << 30) / (int64_t)frame_bytes);   // ~1 GiB of frames
+    void *d_chunk = nullptr, *ptr = nullptr;
+    int rc;
+    if ((rc = scratch(SCR_STAGE_A, (size_t)std::min<int64_t>(chunk, f_hi - f_lo + 1) * frame_bytes, &d_chunk)) != PMI_OK) return rc;
+    int64_t dcap = std::max<int64_t>(cap, 1);
+    if ((rc = scratch(SCR_STAGE_B, (size_t)dcap * 16 + 64, &ptr)) != PMI_OK) return rc;
+    int32_t *d_frame = (int32_t *)ptr, *d_y = d_frame + dcap, *d_x = d_y + dcap;
+    float *d_ng = (float *)(d_x + dcap);
+    int64_t *d_n = (int64_t *)(d_ng + dcap);
+    int64_t total = 0;
+    bool overflow = false;
+    for (int64_t c0 = f_lo; c0 <= f_hi; c0 += chunk) {
+        int64_t c1 = std::min(f_hi, c0 + chunk - 1), nfc = c1 - c0 + 1;
+        PMI_HIP(hipMemcpy(d_chunk, (const char *)movie + (size_t)c0 * frame_bytes, (size_t)nfc * frame_bytes, hipMemcpyHostToDevice));
+        int64_t room = overflow ? 0 : std::max<int64_t>(cap - total, 0);
+        rc = identify_impl(d_chunk, dtype, nfc, Y, X, box, min_ng, roi4, 0, nfc - 1, c0, d_frame, d_y, d_x, d_ng,
+                           room, d_n, nullptr);
+        if (rc != PMI_OK) return rc;
+        int64_t n = 0;
+        PMI_HIP(hipMemcpy(&n, d_n, sizeof(n), hipMemcpyDeviceToHost));
+        if (n > room) overflow = true;
+        else if (n > 0) {
+            PMI_HIP(hipMemcpy(out_frame + total, d_frame, (size_t)n * 4, hipMemcpyDeviceToHost));
+            PMI_HIP(hipMemcpy(out_y + total, d_y, (size_t)n * 4, hipMemcpyDeviceToHost));
+            PMI_HIP(hipMemcpy(out_x + total, d_x, (size_t)n * 4, hipMemcpyDeviceToHost));
+            PMI_HIP(hipMemcpy(out_ng + total, d_ng, (size_t)n * 4, hipMemcpyDeviceToHost));
+        }
+        total += n;
+    }
+    *out_n = total;
+    if (overflow) { set_error("identify: capacity %lld too small, %lld rows needed", (long long)cap, (long long)total); return PMI_ERR_CAPACITY; }
+    return PMI_OK;
+}
+
+}  // extern "C"

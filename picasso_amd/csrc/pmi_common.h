@@ -1,0 +1,74 @@
+// pmi_common.h — shared host/device helpers for libpicasso_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/picasso_hip.h"
+
+#define PMI_WAVE 64
+
+namespace pmi {
+
+void set_error(const char *fmt, ...);
+int hip_fail(hipError_t e, const char *what, const char *file, int line);
+
+#define PMI_HIP(call)                                                          \
+    do {                                                                       \
+        hipError_t e_ = (call);                                                \
+        if (e_ != hipSuccess) return pmi::hip_fail(e_, #call, __FILE__, __LINE__); \
+    } while (0)
+
+// Grow-only scratch arena per process (one GPU per process).  slot = purpose id.
+enum ScratchSlot {
+    SCR_RECORDS = 0,      // unordered identification records
+    SCR_RECORDS2,         // frame-grouped records
+    SCR_FRAME_COUNT,      // per-frame counts + cursors + bases
+    SCR_COUNTERS,         // small counters
+    SCR_IDS,              // frame/y/x/ng for the fused pipeline
+    SCR_FIT,              // thetas/crlbs/ll/it for the fused pipeline
+    SCR_STAGE_A,          // host-API staging (movie chunks)
+    SCR_STAGE_B,
+    SCR_STAGE_C,
+    SCR_STAGE_D,
+    SCR_NUM
+};
+int scratch(int slot, size_t bytes, void **ptr);
+int scratch_release_all();
+
+struct Record {   // one identification, 16 B
+    int32_t frame, y, x;
+    float ng;
+};
+
+// pixel load as float32 (the reference's np.float32(frame), localize.py:332)
+template <typename T>
+__device__ __forceinline__ float px_f32(const T *p, int64_t i) { return (float)p[i]; }
+
+struct KernelTimes { float scan_ms, fit_ms; };
+extern bool g_kernel_timing;
+extern KernelTimes g_last_times;
+
+struct ScopedKernelTimer {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t s;
+    float *dst;
+    ScopedKernelTimer(hipStream_t stream, float *dst_) : s(stream), dst(dst_) {
+        if (g_kernel_timing) { (void)hipEventCreate(&a); (void)hipEventCreate(&b); (void)hipEventRecord(a, s); }
+    }
+    void stop() {
+        if (a) { (void)hipEventRecord(b, s); }
+    }
+    ~ScopedKernelTimer() {
+        if (a) {
+            (void)hipEventSynchronize(b);
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, a, b);
+            *dst = ms;
+            (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+        }
+    }
+};
+
+}  // namespace pmi

@@ -1,0 +1,118 @@
+// runtime.hip — library state: errors, device selection, memory, scratch, events.
+#include <stdarg.h>
+
+#include <mutex>
+
+#include "pmi_common.h"
+
+namespace pmi {
+
+static thread_local char g_err[512] = "";
+bool g_kernel_timing = false;
+KernelTimes g_last_times = {0.f, 0.f};
+
+void set_error(const char *fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+int hip_fail(hipError_t e, const char *what, const char *file, int line)
+{
+    set_error("HIP error %d (%s) in %s at %s:%d", (int)e, hipGetErrorString(e), what, file, line);
+    return PMI_ERR_HIP;
+}
+
+struct ScratchBuf { void *p = nullptr; size_t bytes = 0; };
+static ScratchBuf g_scratch[SCR_NUM];
+static std::mutex g_scratch_mu;
+
+int scratch(int slot, size_t bytes, void **ptr)
+{
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    ScratchBuf &b = g_scratch[slot];
+    if (b.bytes < bytes) {
+        if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+        size_t want = bytes + bytes / 4 + 4096;   // headroom so repeated calls stop reallocating
+        PMI_HIP(hipMalloc(&b.p, want));
+        b.bytes = want;
+    }
+    *ptr = b.p;
+    return PMI_OK;
+}
+
+int scratch_release_all()
+{
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    for (auto &b : g_scratch)
+        if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    return PMI_OK;
+}
+
+}  // namespace pmi
+
+extern "C" {
+
+int pmi_version(void) { return 100; }   // 0.1.0
+
+const char *pmi_last_error(void) { return pmi::g_err; }
+
+int pmi_device_count(void)
+{
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+int pmi_set_device(int device)
+{
+    PMI_HIP(hipSetDevice(device));
+    return PMI_OK;
+}
+
+int pmi_device_info(char *name, size_t name_len, int *compute_units, size_t *total_mem_bytes)
+{
+    int dev = 0;
+    PMI_HIP(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    PMI_HIP(hipGetDeviceProperties(&prop, dev));
+    if (name && name_len) { strncpy(name, prop.gcnArchName, name_len - 1); name[name_len - 1] = 0; }
+    if (compute_units) *compute_units = prop.multiProcessorCount;
+    if (total_mem_bytes) *total_mem_bytes = prop.totalGlobalMem;
+    return PMI_OK;
+}
+
+int pmi_malloc(void **dptr, size_t bytes) { PMI_HIP(hipMalloc(dptr, bytes)); return PMI_OK; }
+int pmi_free(void *dptr) { PMI_HIP(hipFree(dptr)); return PMI_OK; }
+int pmi_memcpy_h2d(void *d, const void *h, size_t bytes) { PMI_HIP(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return PMI_OK; }
+int pmi_memcpy_d2h(void *h, const void *d, size_t bytes) { PMI_HIP(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); return PMI_OK; }
+int pmi_stream_synchronize(void *stream) { PMI_HIP(hipStreamSynchronize((hipStream_t)stream)); return PMI_OK; }
+int pmi_release_scratch(void) { return pmi::scratch_release_all(); }
+
+int pmi_event_create(void **event)
+{
+    hipEvent_t e;
+    PMI_HIP(hipEventCreate(&e));
+    *event = (void *)e;
+    return PMI_OK;
+}
+int pmi_event_record(void *event, void *stream) { PMI_HIP(hipEventRecord((hipEvent_t)event, (hipStream_t)stream)); return PMI_OK; }
+int pmi_event_elapsed_ms(void *start, void *stop, float *ms)
+{
+    PMI_HIP(hipEventSynchronize((hipEvent_t)stop));
+    PMI_HIP(hipEventElapsedTime(ms, (hipEvent_t)start, (hipEvent_t)stop));
+    return PMI_OK;
+}
+int pmi_event_destroy(void *event) { PMI_HIP(hipEventDestroy((hipEvent_t)event)); return PMI_OK; }
+
+int pmi_set_kernel_timing(int enabled) { pmi::g_kernel_timing = enabled != 0; return PMI_OK; }
+int pmi_last_kernel_ms(float *scan_ms, float *fit_ms)
+{
+    if (scan_ms) *scan_ms = pmi::g_last_times.scan_ms;
+    if (fit_ms) *fit_ms = pmi::g_last_times.fit_ms;
+    return PMI_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+"""GPU tier: the HIP path (through the C ABI) against the oracle and the goldens.
+
+Run on the MI355X box: python -m pytest tests -m gpu -x -q
+Tolerances (BASELINE.json north_star): x, y, sigma within 1e-3 px, photons
+within 1e-2 (relative 1e-5 here, tighter), identical identification set.
+Integer/index work and the float32 net gradient are bit-exact.
+"""
+import numpy as np
+import pytest
+
+from conftest import DEGENERATE_LOOSE, MLE_DATASETS, bounds_from, golden, roi_from
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def be():
+    from picasso_amd import backend
+    return backend
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import oracle
+    return oracle
+
+
+def _sorted(g, k):
+    o = np.lexsort((g[k + "_x"], g[k + "_y"], g[k + "_frame"]))
+    return g[k + "_frame"][o], g[k + "_y"][o], g[k + "_x"][o], g[k + "_ng"][o]
+
+
+@pytest.mark.parametrize("case", list("abcdefgh"))
+def test_identify_testdata_bit_exact(be, testdata_movie, case):
+    g = golden("identify_testdata")
+    fr, y, x, ng = be.identify_arrays(testdata_movie, float(g[case + "_min_ng"]), int(g[case + "_box"]),
+                                      roi_from(g[case + "_roi"]), bounds_from(g[case + "_frame_bounds"]))
+    gf, gy, gx, gn = _sorted(g, case)
+    assert len(fr) == len(gf)
+    assert np.array_equal(fr, gf) and np.array_equal(y, gy) and np.array_equal(x, gx)
+    assert np.array_equal(ng, gn)
+
+
+@pytest.mark.parametrize("case", list("abcd"))
+def test_identify_adversarial_bit_exact(be, case):
+    g = golden("identify_adversarial")
+    fr, y, x, ng = be.identify_arrays(g["movie"], float(g[case + "_min_ng"]), int(g[case + "_box"]),
+                                      roi_from(g[case + "_roi"]), None)
+    gf, gy, gx, gn = _sorted(g, case)
+    assert np.array_equal(fr, gf) and np.array_equal(y, gy) and np.array_equal(x, gx)
+    assert np.array_equal(ng, gn)
+
+
+def test_identify_matches_real_numba_table(be, testdata_movie):
+    nb = golden("numba_identifications_testdata")
+    fr, y, x, ng = be.identify_arrays(testdata_movie, 5000, 7)
+    assert np.array_equal(fr, nb["frame"]) and np.array_equal(ng, nb["net_gradient"])
+
+
+@pytest.mark.parametrize("dtype", ["uint16", "uint8", "int16", "uint32", "int32", "float32"])
+@pytest.mark.parametrize("shape,box", [((5, 67, 131), 7), ((3, 200, 300), 9), ((4, 40, 33), 5), ((2, 257, 129), 13)])
+def test_identify_random_movies_vs_oracle(be, orc, dtype, shape, box):
+    """Ragged shapes (tile edges), every pixel type, ties everywhere."""
+    rng = np.random.default_rng(hash((dtype, shape, box)) % 2**32)
+    hi = 200 if dtype == "uint8" else 3000
+    mov = rng.integers(0, hi, size=shape).astype(dtype)
+    mov[:, ::7, ::5] = mov[:, ::7, ::5] // 2 * 2    # more ties
+    for min_ng in (-1e9, 0.3 * hi * box):
+        a = be.identify_arrays(mov, min_ng, box)
+        b = orc.identify(mov, min_ng, box, threads=4)
+        assert len(a[0]) == len(b[0])
+        assert all(np.array_equal(p, q) for p, q in zip(a, b))
+
+
+def test_identify_empty_and_tiny(be):
+    z = np.zeros((3, 16, 16), np.uint16)
+    fr, y, x, ng = be.identify_arrays(z, 100, 7)
+    assert len(fr) == 0
+    fr, y, x, ng = be.identify_arrays(np.ones((2, 7, 7), np.uint16), -1, 7)   # no interior pixel
+    assert len(fr) == 0
+    fr, y, x, ng = be.identify_arrays(np.zeros((0, 32, 32), np.uint16), 1, 7)
+    assert len(fr) == 0
+
+
+def test_get_spots_bit_exact(be, testdata_movie):
+    s = golden("get_spots_testdata")
+    for key in ("unit", "emccd", "scmos"):
+        b, se, g = s["cam_" + key]
+        sp = be.get_spots_array(testdata_movie, s["frame"], s["y"], s["x"], 7, b, se, g)
+        assert np.array_equal(sp, s["spots_" + key])
+    sp = be.get_spots_array(testdata_movie, s["box9_frame"], s["box9_y"], s["box9_x"], 9, 0, 1, 1)
+    assert np.array_equal(sp, s["box9_spots"])
+
+
+def _check_fit(th, cr, ll, it, gth, gcr, gll, git, loose=(), flip_frac=0.03, max_flip=1):
+    d_it = np.abs(it.astype(int) - git.astype(int))
+    assert d_it.max() <= max_flip, f"iteration difference {d_it.max()}"
+    assert np.mean(d_it != 0) <= flip_frac + 1.0 / len(it)
+    keep = np.array([i not in loose for i in range(len(it))]) & (d_it == 0) & (git < 100)
+    assert np.nanmax(np.abs(th[keep, :2] - gth[keep, :2])) < 1e-3          # x, y [px]
+    assert np.nanmax(np.abs(th[keep, 4:] - gth[keep, 4:])) < 1e-3          # sigma [px]
+    rel = np.abs(th[keep, 2] - gth[keep, 2]) / np.maximum(np.abs(gth[keep, 2]), 1.0)
+    assert np.nanmax(rel) < 1e-4                                            # photons
+    assert np.nanmax(np.abs(th[keep, 2] - gth[keep, 2])) < 0.25
+    assert np.nanmax(np.abs(th[keep, 3] - gth[keep, 3])) < 1e-2            # background
+    with np.errstate(invalid="ignore"):
+        lp, glp = np.sqrt(cr[keep]), np.sqrt(gcr[keep])
+    ok = np.isfinite(glp) & (glp > 0)
+    assert np.nanmax(np.abs(lp[ok] - glp[ok]) / glp[ok]) < 2e-3
+    assert np.nanmax(np.abs(ll[keep] - gll[keep])) < 0.05 + 2e-5 * np.nanmax(np.abs(gll[keep]))
+
+
+@pytest.mark.parametrize("name", MLE_DATASETS)
+@pytest.mark.parametrize("method", ["sigmaxy", "sigma"])
+def test_gaussmle_vs_goldens_and_oracle(be, orc, name, method):
+    d = golden("gaussmle_" + name)
+    th, cr, ll, it = be.gaussmle_arrays(d["spots"], 1e-3, 100, method)
+    assert th.dtype == np.float32 and th.shape == (len(d["spots"]), 6) and it.dtype == np.int32
+    loose = DEGENERATE_LOOSE | {6, 7, 10, 11} if name == "degenerate7" else ()
+    _check_fit(th, cr, ll, it, d[method + "_theta"], d[method + "_crlb"], d[method + "_loglik"],
+               d[method + "_iterations"], loose)
+    o = orc.gaussmle(d["spots"], 1e-3, 100, method, threads=4)
+    _check_fit(th, cr, ll, it, *o, loose)
+    if method == "sigma":
+        assert np.array_equal(th[:, 4], th[:, 5])
+
+
+@pytest.mark.parametrize("box", [5, 7, 9, 11, 13, 15, 17, 19, 21])
+def test_gaussmle_all_boxes_vs_oracle(be, orc, box):
+    from math import erf, sqrt
+    rng = np.random.default_rng(box)
+    n, c = 96, box // 2
+    spots = np.empty((n, box, box), np.float32)
+    idx = np.arange(box)
+    for i in range(n):
+        x0, y0 = c + rng.uniform(-0.8, 0.8), c + rng.uniform(-0.8, 0.8)
+        sx, sy = rng.uniform(0.9, 0.25 * box), rng.uniform(0.9, 0.25 * box)
+        ex = np.array([0.5 * (erf((k - x0 + .5) / (sqrt(2) * sx)) - erf((k - x0 - .5) / (sqrt(2) * sx))) for k in idx])
+        ey = np.array([0.5 * (erf((k - y0 + .5) / (sqrt(2) * sy)) - erf((k - y0 - .5) / (sqrt(2) * sy))) for k in idx])
+        spots[i] = rng.poisson(rng.uniform(1500, 9000) * np.outer(ey, ex) + rng.uniform(2, 30))
+    for method in ("sigmaxy", "sigma"):
+        a = be.gaussmle_arrays(spots, 1e-3, 100, method)
+        b = orc.gaussmle(spots, 1e-3, 100, method, threads=4)
+        _check_fit(*a, *b)
+
+
+def test_gaussmle_edge_cases(be):
+    th, cr, ll, it = be.gaussmle_arrays(np.zeros((0, 7, 7), np.float32), 1e-3, 100)
+    assert th.shape == (0, 6) and it.shape == (0,)
+    with pytest.raises(ValueError, match="Method not available"):
+        be.gaussmle_arrays(np.zeros((1, 7, 7), np.float32), 1e-3, 100, "nope")
+    d = golden("gaussmle_poisson5")
+    th, cr, ll, it = be.gaussmle_arrays(d["spots"][:5], 1e-3, 3)
+    assert it.max() <= 3
+
+
+def test_localize_pipeline_on_resident_movie(be, orc, testdata_movie):
+    """identify -> fused cut+fit -> table, all on device, vs oracle composition."""
+    cam = {"Baseline": 100.0, "Sensitivity": 0.5, "Gain": 2.0}
+    dm = be.DeviceMovie(testdata_movie)
+    try:
+        t = be.localize_mle_device(dm.ptr, dm.dtype, dm.shape, 7, 1500, cam)
+    finally:
+        dm.free()
+    fr, y, x, ng = orc.identify(testdata_movie, 1500, 7)
+    spots = orc.get_spots(testdata_movie, fr, y, x, 7, cam)
+    th, cr, ll, it = orc.gaussmle(spots, 1e-3, 100, "sigmaxy")
+    assert len(t["frame"]) == len(fr)
+    assert np.array_equal(t["frame"], fr.astype(np.uint32))
+    assert np.array_equal(t["net_gradient"], ng)
+    same = t["iterations"] == it
+    assert same.mean() > 0.95
+    assert np.max(np.abs(t["x"] - (th[:, 0] + x - 3))[same]) < 1e-3
+    assert np.max(np.abs(t["y"] - (th[:, 1] + y - 3))[same]) < 1e-3
+    assert np.max(np.abs(t["photons"] - th[:, 2])[same] / th[same, 2]) < 1e-4
+    assert np.max(np.abs(t["sx"] - th[:, 4])[same]) < 1e-3

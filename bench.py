@@ -1,0 +1,217 @@
+#!/usr/bin/env python3
+"""Headline benchmark: localizations/s, 7x7 ROI Poisson-MLE, on MI355X.
+
+One step = one pass of the whole hot path (identify -> fused ROI cut + photon
+conversion + MLE fit -> localization table) over the rank's resident synthetic
+movie (BASELINE.json configs[1]: 10k frames, 512x512 uint16, ~1e6 spots).  With
+N > 1 every rank owns its own movie shard (frames shard without a halo, weak
+scaling) and each step ends with the RCCL all-gather of the localization table
+the north star asks for.
+
+    python bench.py --gpus 1 --steps 10 --warmup 2
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
+FIT_BYTES_PER_SPOT_7 = 166.0   # 98 px + 12 id + 56 result
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--frames", type=int, default=10000)
+    ap.add_argument("--size", type=int, default=512)
+    ap.add_argument("--emitters", type=int, default=116, help="emitters per frame (~86%% pass min_ng 5000)")
+    ap.add_argument("--box", type=int, default=7)
+    ap.add_argument("--min-ng", type=float, default=5000.0)
+    ap.add_argument("--method", default="sigmaxy")
+    ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="extra instrumented steps for per-kernel time")
+    return ap.parse_args()
+
+
+def main():
+    args = parse()
+    import torch
+    import torch.distributed as dist
+
+    from picasso_amd import _lib, backend, synth
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")      # "nccl" is RCCL on ROCm
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    L = _lib.load()
+    _lib.require_gpu()
+    _lib.check(L.pmi_set_device(local_rank), "pmi_set_device")
+
+    F, H, W, box = args.frames, args.size, args.size, args.box
+    cam = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
+    movie = synth.simulate_movie(F, H, W, emitters_per_frame=args.emitters,
+                                 seed=synth.DEFAULT_SEED + rank, device=dev)
+    torch.cuda.synchronize()
+    movie_bytes = movie.numel() * movie.element_size()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    method = _lib.MLE_METHODS[args.method]
+
+    def run(table, d_n, cap):
+        rc = L.pmi_localize_mle_dev(ctypes.c_void_p(movie.data_ptr()), 0, F, H, W, box, args.min_ng, None, 0, F - 1,
+                                    cam["Baseline"], cam["Sensitivity"], cam["Gain"], 1e-3, 100, method,
+                                    ctypes.c_void_p(table.data_ptr()), cap, ctypes.c_void_p(d_n.data_ptr()), stream)
+        _lib.check(rc, "pmi_localize_mle_dev")
+
+    # sizing pass: learn the row count, then keep the table tight for the all-gather
+    cap = max(4096, 400 * F)
+    d_n = torch.zeros(1, dtype=torch.int64, device=dev)
+    table = torch.empty((_lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device=dev)
+    run(table, d_n, cap)
+    torch.cuda.synchronize()
+    n_local = int(d_n.item())
+    assert 0 < n_local <= cap, f"sizing pass found {n_local} rows (cap {cap})"
+    cap = int(n_local * 1.02) + 1024
+    if world > 1:
+        capt = torch.tensor([cap], dtype=torch.int64, device=dev)
+        dist.all_reduce(capt, op=dist.ReduceOp.MAX)
+        cap = int(capt.item())
+    del table
+    table = torch.empty((_lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device=dev)
+    gathered = gathered_n = None
+    if world > 1:
+        gathered = torch.empty((world, _lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device=dev)
+        gathered_n = torch.empty((world,), dtype=torch.int64, device=dev)
+
+    def step():
+        run(table, d_n, cap)
+        if world > 1:      # localization table of every shard on every GPU (RCCL over xGMI)
+            dist.all_gather_into_tensor(gathered_n, d_n)
+            dist.all_gather_into_tensor(gathered, table)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    nt = torch.tensor([int(d_n.item())], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(et, op=dist.ReduceOp.MAX)
+        dist.all_reduce(nt, op=dist.ReduceOp.SUM)
+    elapsed = float(et.item())
+    n_total = int(nt.item())
+    value = n_total * args.steps / elapsed
+
+    # per-kernel durations: HIP events around the kernels on the launch stream (library-side)
+    scan_ms = fit_ms = float("nan")
+    if args.profile_steps > 0:
+        L.pmi_set_kernel_timing(1)
+        s_acc, f_acc = [], []
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        for _ in range(args.profile_steps):
+            run(table, d_n, cap)
+            torch.cuda.synchronize()
+            L.pmi_last_kernel_ms(ctypes.byref(a), ctypes.byref(b))
+            s_acc.append(a.value); f_acc.append(b.value)
+        L.pmi_set_kernel_timing(0)
+        scan_ms, fit_ms = float(np.mean(s_acc)), float(np.mean(f_acc))
+
+    result = None
+    if rank == 0:
+        n_rank0 = int(d_n.item())
+        kernels = {
+            "identify_scan": {"ms": scan_ms, "algorithmic_bytes": movie_bytes,
+                              "GB/s": movie_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms == scan_ms else None},
+            "mle_fit": {"ms": fit_ms, "algorithmic_bytes": FIT_BYTES_PER_SPOT_7 * n_rank0,
+                        "GB/s": FIT_BYTES_PER_SPOT_7 * n_rank0 / (fit_ms * 1e-3) / 1e9 if fit_ms == fit_ms else None,
+                        "spots_per_s": n_rank0 / (fit_ms * 1e-3) if fit_ms == fit_ms else None},
+        }
+        dom = "identify_scan" if not (fit_ms > scan_ms) else "mle_fit"
+        ach = kernels[dom]["GB/s"]
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": (ach / HBM_PEAK_GBS) if ach else None, "traffic": None, "kernels": kernels}
+        cpu = None
+        if world == 1 and args.cpu_seconds > 0:
+            cpu = cpu_baseline(movie, cam, box, args.min_ng, args.method, args.cpu_seconds)
+        result = {
+            "metric": "localizations/sec (7x7 ROI, MLE)", "value": value, "unit": "localizations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"{F}-frame {H}x{W} uint16 simulated DNA-PAINT movie per GPU, "
+                                   f"{n_total // world} spots per GPU, {box}x{box} ROI MLE ({args.method}), "
+                                   "identify+cut+fit+table resident in HBM"
+                                   + (", + RCCL all-gather of the table" if world > 1 else ""),
+                       "frames": F, "height": H, "width": W, "box": box, "min_net_gradient": args.min_ng,
+                       "eps": 1e-3, "max_it": 100, "localizations_total": n_total,
+                       "sharding": f"frames x{world}"},
+            "roofline": roofline,
+            "cpu_baseline": cpu,
+        }
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return result
+
+
+def cpu_baseline(movie, cam, box, min_ng, method, budget_s):
+    """The CPU oracle (C restatement of the reference algorithm) on this box's host
+    cores, on a bounded sample of the same movie: identify + get_spots + gaussmle."""
+    from oracle import oracle as orc
+    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except Exception:
+        pass
+
+    def run(nframes):
+        host = movie[:nframes].cpu().numpy()
+        t0 = time.perf_counter()
+        fr, y, x, ng = orc.identify(host, min_ng, box, threads=threads)
+        spots = orc.get_spots(host, fr, y, x, box, cam)
+        orc.gaussmle(spots, 1e-3, 100, method, threads=threads)
+        return len(fr), time.perf_counter() - t0
+
+    probe = min(32, movie.shape[0])
+    n, dt = run(probe)                     # also warms the OpenMP pool
+    frames = int(min(movie.shape[0], max(probe, probe * budget_s / max(dt, 1e-3))))
+    n, dt = run(frames)
+    return {"value": n / dt, "unit": "localizations/s", "cores": threads, "kind": "port",
+            "sample": f"first {frames} frames of the same movie ({n} spots), identify+get_spots+gaussmle "
+                      f"({method}, eps 1e-3, max_it 100), C/OpenMP restatement of the reference algorithm, "
+                      f"{dt:.1f} s"}
+
+
+if __name__ == "__main__":
+    main()

@@ -77,6 +77,13 @@ def load():
             raise ImportError(
                 f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "or `make -C picasso_amd/csrc`.  There is no CPU fallback.")
+        # One HIP runtime per process: torch bundles its own libamdhip64.so.7 (same SONAME as
+        # /opt/rocm's).  Whichever loads first wins, and torch cannot see the GPU through the
+        # system copy, so when torch is installed it must be imported before our library.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SYMBOLS.items():
             fn = getattr(L, name)     # AttributeError if the .so lacks a declared symbol

@@ -100,7 +100,7 @@ def main():
     table = torch.empty((_lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device=dev)
     gathered = gathered_n = None
     if world > 1:
-        gathered = torch.empty((world, _lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device=dev)
+        gathered = torch.empty((world * _lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device=dev)
         gathered_n = torch.empty((world,), dtype=torch.int64, device=dev)
 
     def step():

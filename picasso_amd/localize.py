@@ -1,0 +1,318 @@
+"""picasso.localize surface on the HIP backend.
+
+Drop-in for the hot-path functions of picasso/localize.py: ``identify``
+(:639-749), ``identify_by_frame_number`` (:340-421), ``identify_in_frame``
+(:295-337), ``identify_in_image`` (:247-292), ``get_spots`` (:1115-1145),
+``fit2D`` (:1344-1506) and ``localize`` (:1682-1815) — same signatures,
+defaults, return types, metadata dictionaries, assertion messages and
+abort/progress contracts.  The work is done by libpicasso_hip.so; there is no
+CPU path.  ``install()`` rebinds the reference package's functions to these.
+"""
+from __future__ import annotations
+
+import time
+import warnings
+from typing import Callable, Literal
+
+import numpy as np
+import pandas as pd
+
+from . import __version__, backend, gaussmle
+
+_CHUNK_BYTES = 1 << 30      # movie bytes per device call = progress / abort granularity
+FITTING_METHODS = ["gausslq", "gausslq-gpu", "gaussmle", "avg"]
+
+
+def _deprecation_warning(message: str) -> None:
+    warnings.warn(message, DeprecationWarning, stacklevel=3)
+
+
+# ---------------------------------------------------------------------------
+# movie access
+# ---------------------------------------------------------------------------
+def _is_array_movie(movie) -> bool:
+    return isinstance(movie, np.ndarray)          # includes np.memmap (.raw movies)
+
+
+def _accepted_movie(movie) -> bool:
+    """What picasso.io.load_movie returns: a memmap or an AbstractPicassoMovie
+    (duck-typed here: len(), [i] -> 2-D frame, .dtype)."""
+    if isinstance(movie, np.memmap):
+        return True
+    if isinstance(movie, np.ndarray):
+        return False                               # reference rejects bare ndarrays (localize.py:1416-1424)
+    return hasattr(movie, "__len__") and hasattr(movie, "__getitem__") and hasattr(movie, "dtype")
+
+
+def _frames_block(movie, f0: int, f1: int) -> np.ndarray:
+    """Frames [f0, f1) as one C-contiguous array (zero-copy for ndarrays)."""
+    if _is_array_movie(movie):
+        return backend.as_movie_array(movie[f0:f1])
+    return backend.as_movie_array(np.stack([np.asarray(movie[i]) for i in range(f0, f1)]))
+
+
+def _movie_shape(movie):
+    n = len(movie)
+    if _is_array_movie(movie):
+        return n, movie.shape[1], movie.shape[2]
+    f = np.asarray(movie[0]) if n else np.zeros((0, 0))
+    return n, f.shape[0], f.shape[1]
+
+
+def _chunk_frames(movie) -> int:
+    n, Y, X = _movie_shape(movie)
+    per_frame = max(1, Y * X * np.dtype(movie.dtype).itemsize)
+    return max(1, _CHUNK_BYTES // per_frame)
+
+
+def _empty_identifications() -> pd.DataFrame:
+    return pd.DataFrame({"frame": pd.Series(dtype=int), "x": pd.Series(dtype=int), "y": pd.Series(dtype=int),
+                         "net_gradient": pd.Series(dtype=np.float32)})
+
+
+def _ids_frame(fr, y, x, ng) -> pd.DataFrame:
+    # column order and dtypes of localize.py:413-420
+    return pd.DataFrame({"frame": fr.astype(int), "x": x.astype(int), "y": y.astype(int),
+                         "net_gradient": ng.astype(np.float32)})
+
+
+# ---------------------------------------------------------------------------
+# identify
+# ---------------------------------------------------------------------------
+def identify_in_image(image, minimum_ng: float, box: int):
+    """Local maxima + net gradient of one float32 image -> y, x, ng."""
+    img = np.ascontiguousarray(image, dtype=np.float32)[None]
+    fr, y, x, ng = backend.identify_arrays(img, minimum_ng, box)
+    return y.astype(np.int64), x.astype(np.int64), ng
+
+
+def identify_in_frame(frame, minimum_ng: float, box: int, roi=None):
+    """One frame, optional ROI ((y0, x0), (y1, x1)); coordinates are frame coordinates."""
+    fr, y, x, ng = backend.identify_arrays(np.asarray(frame)[None], minimum_ng, box, roi=roi)
+    return y.astype(np.int64), x.astype(np.int64), ng
+
+
+def identify_by_frame_number(movie, minimum_ng: float, box: int, frame_number: int, *, roi=None,
+                             frame_bounds=None, lock=None) -> pd.DataFrame:
+    if lock is not None:
+        with lock:
+            frame = movie[frame_number]
+    else:
+        frame = movie[frame_number]
+    lo, hi = backend.frame_range(frame_bounds, len(movie))
+    if frame_bounds is not None and not (lo <= frame_number <= hi):
+        return _empty_identifications()
+    y, x, ng = identify_in_frame(frame, minimum_ng, box, roi)
+    return _ids_frame(frame_number * np.ones(len(x)), y, x, ng)
+
+
+def identify(movie, minimum_ng: float, box: int, *, roi=None, frame_bounds=None, threaded: bool = True,
+             progress_callback=None, abort_callback=None, return_info: bool = None):
+    """Identify spots in every frame (picasso/localize.py:639-749).
+
+    ``threaded`` is accepted for compatibility (the device call is one batch per
+    ~1 GiB of frames either way); ``progress_callback`` receives the number of
+    frames done, ``"console"`` shows a tqdm bar; when ``abort_callback()`` turns
+    true between batches the function returns ``None`` like the reference.
+    """
+    if return_info is None:
+        return_info = False
+        _deprecation_warning(
+            "Warning: In Picasso v0.11.0, picasso.localize.identify() will return both the identifications "
+            "and a metadata dictionary by default.\nBefore v0.12.0, when using picasso.localize.identify(), "
+            "please add the argument 'return_info' explicitly as True or False.\nIn version 0.12, this "
+            "argument will also be removed such that picasso.localize.identify() will always return both "
+            "the identifications and the metadata dictionary.")
+    N = len(movie)
+    lo, hi = backend.frame_range(frame_bounds, N)
+    hi = min(hi, N - 1)
+    bar = None
+    if progress_callback == "console":
+        from tqdm import tqdm
+        bar = tqdm(total=N, desc="Identifying spots", unit="frame")
+    parts = []
+    step = _chunk_frames(movie) if N else 1
+    f0 = max(lo, 0)
+    while f0 <= hi:
+        if threaded and abort_callback is not None and abort_callback():
+            if bar is not None:
+                bar.close()
+            return None
+        f1 = min(hi + 1, f0 + step)
+        block = _frames_block(movie, f0, f1)
+        fr, y, x, ng = backend.identify_arrays(block, minimum_ng, box, roi=roi)
+        parts.append(_ids_frame(fr.astype(np.int64) + f0, y, x, ng))
+        if bar is not None:
+            bar.update(f1 - f0)
+        elif callable(progress_callback):
+            progress_callback(f1 if threaded else f1 - 1)
+        f0 = f1
+    if bar is not None:
+        bar.update(N - bar.n)
+        bar.close()
+    ids = pd.concat(parts, ignore_index=True) if parts else _empty_identifications()
+    if return_info:
+        info = {"Generated by": f"Picasso: v{__version__} Identify (picasso_amd HIP backend)",
+                "Min. Net Gradient": minimum_ng, "Box Size": box, "ROI": roi, "Frame Bounds": frame_bounds}
+        return ids, info
+    return ids
+
+
+# ---------------------------------------------------------------------------
+# spots
+# ---------------------------------------------------------------------------
+def get_spots(movie, identifications: pd.DataFrame, box: int, camera_info: dict) -> np.ndarray:
+    """ROI extraction + camera-signal -> photon conversion (localize.py:1115-1145)."""
+    frame = identifications["frame"].to_numpy().astype(np.int64)
+    y = identifications["y"].to_numpy().astype(np.int64)      # picks-derived ids may be floats: truncation like int indexing
+    x = identifications["x"].to_numpy().astype(np.int64)
+    N = len(frame)
+    cam = (camera_info["Baseline"], camera_info["Sensitivity"], camera_info["Gain"])
+    if N == 0:
+        return np.zeros((0, box, box), np.float32)
+    if _is_array_movie(movie):
+        return backend.get_spots_array(movie, frame, y, x, box, *cam)
+    # frame-by-frame movies: upload runs of frames (assumes frame-ordered ids, as the reference does)
+    spots = np.empty((N, box, box), np.float32)
+    step = _chunk_frames(movie)
+    order = np.argsort(frame, kind="stable")
+    fs = frame[order]
+    i0 = 0
+    while i0 < N:
+        f0 = int(fs[i0])
+        i1 = int(np.searchsorted(fs, f0 + step, side="left"))
+        f1 = int(fs[i1 - 1]) + 1
+        block = _frames_block(movie, f0, f1)
+        sel = order[i0:i1]
+        spots[sel] = backend.get_spots_array(block, frame[sel] - f0, y[sel], x[sel], box, *cam)
+        i0 = i1
+    return spots
+
+
+# ---------------------------------------------------------------------------
+# fit
+# ---------------------------------------------------------------------------
+def _fit2d_gaussmle(spots, identifications, box, eps=0.001, max_it=100, mle_method="sigmaxy", multiprocess=True,
+                    progress_callback=None, abort_callback=None):
+    N = len(identifications)
+    bar = None
+    if progress_callback == "console":
+        from tqdm import tqdm
+        bar = tqdm(total=N, desc="Fitting", unit="spot")
+    if multiprocess:
+        curr, thetas, CRLBs, llhoods, iterations = gaussmle.gaussmle_async(spots, eps, max_it, method=mle_method)
+        last = 0
+        while curr[0] < N:
+            if callable(abort_callback) and abort_callback():
+                if bar is not None:
+                    bar.close()
+                return None
+            if bar is not None:
+                bar.update(curr[0] - last)
+                last = curr[0]
+            elif callable(progress_callback):
+                progress_callback(curr[0])
+            time.sleep(0.02)
+        gaussmle.wait_async(curr)
+        if bar is not None:
+            bar.update(N - last)
+            bar.close()
+    else:
+        thetas, CRLBs, llhoods, iterations = gaussmle.gaussmle(spots, eps, max_it, mle_method, progress_callback)
+    return gaussmle.locs_from_fits(identifications, thetas, CRLBs, llhoods, iterations, box)
+
+
+def fit2D(movie, movie_info, camera_info: dict, identifications: pd.DataFrame, box: int,
+          fitting_method: Literal["gausslq", "gausslq-gpu", "gaussmle", "avg"] = "gausslq", eps: float = 0.001,
+          max_it: int = 100, mle_method: Literal["sigma", "sigmaxy"] = "sigmaxy", multiprocess: bool = True,
+          progress_callback=None, abort_callback=None):
+    """Fit 2D localizations (picasso/localize.py:1344-1506).  Returns (locs | None, new_info)."""
+    assert _accepted_movie(movie), "movie must be a movie loaded by picasso.io.load_movie"
+    assert isinstance(movie_info, list), "movie_info must be a list"
+    assert isinstance(camera_info, dict), "camera_info must be a dict"
+    assert isinstance(identifications, pd.DataFrame), "identifications must be a DataFrame"
+    assert isinstance(box, int) and box > 0, "box must be a positive integer"
+    assert fitting_method in FITTING_METHODS, (
+        "fitting_method must be one of 'gausslq', 'gausslq-gpu', 'gaussmle', or 'avg'")
+    assert isinstance(eps, (int, float)) and eps > 0, "eps must be a positive number"
+    assert isinstance(max_it, int) and max_it > 0, "max_it must be a positive integer"
+    assert mle_method in ["sigma", "sigmaxy"], "mle_method must be 'sigma' or 'sigmaxy'"
+    assert isinstance(multiprocess, bool), "multiprocess must be a boolean"
+    if "Pixelsize" not in camera_info:
+        warnings.warn("Camera info in picasso.localize.fit2D does not contain 'Pixelsize', i.e., effective "
+                      "camera pixel size in nm. Assuming 130.")
+        camera_info["Pixelsize"] = 130
+
+    if fitting_method != "gaussmle":
+        raise NotImplementedError(
+            f"fitting_method={fitting_method!r} has no HIP kernel yet in picasso_amd (only 'gaussmle'); "
+            "there is no CPU fallback — use the reference for this method")
+    spots = get_spots(movie, identifications, box, camera_info)
+    locs = _fit2d_gaussmle(spots, identifications, box, eps, max_it, mle_method, multiprocess,
+                           progress_callback, abort_callback)
+    localize_info = {"Generated by": f"Picasso: v{__version__} Fit 2D (picasso_amd HIP backend)",
+                     "Fit method": fitting_method}
+    if fitting_method == "gaussmle":
+        localize_info["Convergence criterion"] = eps
+        localize_info["Max iterations"] = max_it
+    return locs, localize_info | camera_info
+
+
+def localize(movie, camera_info: dict, parameters: dict, *, roi=None, frame_bounds=None, movie_info=None,
+             fitting_method: Literal["gausslq", "gausslq-gpu", "gaussmle", "avg"] = "gausslq", eps: float = 0.001,
+             max_it: int = 100, mle_method: Literal["sigma", "sigmaxy"] = "sigmaxy", threaded: bool = True,
+             identification_progress_callback=None, fit_progress_callback=None, return_info: bool = None):
+    """identify + fit2D (picasso/localize.py:1682-1815)."""
+    if return_info is None:
+        return_info = False
+        _deprecation_warning(
+            "Warning: In Picasso v0.11.0, picasso.localize.localize() will return both the localizations and "
+            "a metadata dictionary by default.\nBefore v0.12.0, when using picasso.localize.localize(), please "
+            "add the argument 'return_info' explicitly as True or False.\nIn version 0.12, this argument will "
+            "also be removed such that picasso.localize.localize() will always return both the localizations "
+            "and the metadata dictionary.")
+    if movie_info is None:
+        movie_info = []
+    identifications, identify_info = identify(movie, parameters["Min. Net Gradient"], parameters["Box Size"],
+                                              roi=roi, frame_bounds=frame_bounds, threaded=threaded,
+                                              progress_callback=identification_progress_callback,
+                                              return_info=True)
+    locs, fit_info = fit2D(movie=movie, movie_info=movie_info, camera_info=camera_info,
+                           identifications=identifications, box=parameters["Box Size"],
+                           fitting_method=fitting_method, eps=eps, max_it=max_it, mle_method=mle_method,
+                           multiprocess=threaded, progress_callback=fit_progress_callback)
+    info = movie_info + [identify_info] + [fit_info]
+    if return_info:
+        return locs, info
+    return locs
+
+
+def localize_resident(movie: np.ndarray, camera_info: dict, parameters: dict, *, roi=None, frame_bounds=None,
+                      eps: float = 0.001, max_it: int = 100, mle_method: str = "sigmaxy") -> pd.DataFrame:
+    """The fused device pipeline (identify -> cut+fit -> table, one submission, no
+    host round trip) for a movie that fits in HBM.  Same table as ``localize`` with
+    ``fitting_method="gaussmle"``; this is what bench.py times."""
+    dm = backend.DeviceMovie(movie)
+    try:
+        cols = backend.localize_mle_device(dm.ptr, dm.dtype, dm.shape, parameters["Box Size"],
+                                           parameters["Min. Net Gradient"], camera_info, eps, max_it, mle_method,
+                                           roi=roi, frame_bounds=frame_bounds)
+    finally:
+        dm.free()
+    return pd.DataFrame(cols)
+
+
+def install(picasso_localize=None, picasso_gaussmle=None) -> None:
+    """Rebind the reference package's hot-path functions to this backend, so that
+    picasso.__main__ and the GUI run on the GPU unchanged."""
+    if picasso_localize is None:
+        import picasso.localize as picasso_localize       # the installed reference
+    if picasso_gaussmle is None:
+        import picasso.gaussmle as picasso_gaussmle
+    import sys
+    me = sys.modules[__name__]
+    for name in ("identify", "identify_by_frame_number", "identify_in_frame", "identify_in_image", "get_spots"):
+        setattr(picasso_localize, name, getattr(me, name))
+    picasso_localize._fit2d_gaussmle = _fit2d_gaussmle
+    for name in ("gaussmle", "gaussmle_async"):
+        setattr(picasso_gaussmle, name, getattr(gaussmle, name))

@@ -1,0 +1,134 @@
+"""CPU tier: host-side logic of the Picasso-shaped surface (no device compute)."""
+import warnings
+
+import numpy as np
+import pandas as pd
+import pytest
+
+from conftest import golden
+from picasso_amd import backend, gaussmle, localize
+
+
+def test_locs_from_fits_matches_reference_table():
+    """Columns, dtypes, formulas and order of picasso/gaussmle.py:957-1037, against the
+    table the reference produced for the bundled movie."""
+    g = golden("locs_from_fits_mle")
+    fit = golden("gaussmle_testdata_real")
+    ids = golden("get_spots_testdata")
+    idf = pd.DataFrame({"frame": ids["frame"], "x": ids["x"], "y": ids["y"], "net_gradient": ids["ng"]})
+    locs = gaussmle.locs_from_fits(idf, fit["sigmaxy_theta"], fit["sigmaxy_crlb"], fit["sigmaxy_loglik"],
+                                   fit["sigmaxy_iterations"], 7)
+    assert list(locs.columns) == list(g["columns"])
+    assert [str(locs[c].dtype) for c in locs.columns] == list(g["dtypes"])
+    assert [c for c, _ in backend.LOC_COLUMNS] == list(g["columns"])
+    for c in locs.columns:
+        assert np.array_equal(locs[c].to_numpy(), g[c], equal_nan=True), c
+
+
+def test_locs_from_fits_n_id_sort():
+    idf = pd.DataFrame({"frame": [3, 1, 2], "x": [5, 6, 7], "y": [8, 9, 10],
+                        "net_gradient": np.float32([1, 2, 3]), "n_id": [2, 0, 1]})
+    th = np.ones((3, 6), np.float32); cr = np.ones((3, 6), np.float32)
+    locs = gaussmle.locs_from_fits(idf, th, cr, np.zeros(3, np.float32), np.ones(3, np.int32), 7)
+    assert list(locs["n_id"]) == [0, 1, 2] and locs["n_id"].dtype == np.uint32
+    assert list(locs["frame"]) == [1, 2, 3]
+
+
+def test_frame_range_and_roi_normalisation():
+    assert backend.frame_range(None, 100) == (0, 100)
+    assert backend.frame_range((10, 50), 100) == (10, 50)
+    assert backend.frame_range((None, 50), 100) == (0, 50)
+    assert backend.frame_range((5, None), 100) == (5, 100)
+    assert backend.frame_range((-3, 1000), 100) == (0, 100)
+    assert backend.normalise_roi(None, 32, 32) is None
+    assert list(backend.normalise_roi(((2, 1), (31, 32)), 32, 32)) == [2, 1, 31, 32]
+    assert list(backend.normalise_roi(((2, 1), (100, 100)), 32, 40)) == [2, 1, 32, 40]
+    assert list(backend.normalise_roi(((-4, -3), (-1, -1)), 32, 40)) == [28, 37, 31, 39]
+
+
+def test_unsupported_dtype_and_shape():
+    with pytest.raises(TypeError, match="unsupported movie dtype"):
+        backend.dtype_code(np.float64)
+    with pytest.raises(ValueError):
+        backend.as_movie_array(np.zeros((4, 4), np.uint16))
+    big = np.zeros((2, 8, 8), dtype=">u2")
+    assert backend.as_movie_array(big).dtype.isnative
+
+
+def test_method_validation_happens_before_any_device_work():
+    with pytest.raises(ValueError, match="Method not available"):
+        gaussmle.gaussmle(np.zeros((1, 7, 7), np.float32), 1e-3, 10, method="bogus")
+    with pytest.raises(ValueError, match="Method not available"):
+        gaussmle.gaussmle_async(np.zeros((1, 7, 7), np.float32), 1e-3, 10, method="bogus")
+
+
+class _Movie:
+    """AbstractPicassoMovie-like wrapper (reference tests/conftest.py:259-319)."""
+    def __init__(self, a): self._a = a; self.dtype = a.dtype
+    def __len__(self): return len(self._a)
+    def __getitem__(self, i): return self._a[i]
+    def __iter__(self): return iter(self._a)
+
+
+def _fit2d_args(movie):
+    ids = pd.DataFrame({"frame": [0], "x": [10], "y": [10], "net_gradient": np.float32([1])})
+    return dict(movie=movie, movie_info=[{}], camera_info={"Baseline": 0, "Sensitivity": 1, "Gain": 1, "Pixelsize": 130},
+                identifications=ids, box=7)
+
+
+def test_fit2d_input_assertions(testdata_movie):
+    """Messages of picasso/localize.py:1416-1445 (reference tests/test_localize.py:907-952)."""
+    mov = _Movie(testdata_movie)
+    a = _fit2d_args(mov)
+    with pytest.raises(AssertionError, match="fitting_method must be one of"):
+        localize.fit2D(**a, fitting_method="bogus")
+    with pytest.raises(AssertionError, match="eps must be a positive number"):
+        localize.fit2D(**a, fitting_method="gaussmle", eps=-1.0)
+    with pytest.raises(AssertionError, match="max_it must be a positive integer"):
+        localize.fit2D(**a, fitting_method="gaussmle", max_it=0)
+    with pytest.raises(AssertionError, match="mle_method"):
+        localize.fit2D(**a, fitting_method="gaussmle", mle_method="x")
+    with pytest.raises(AssertionError, match="movie must be a movie loaded"):
+        localize.fit2D(**{**a, "movie": np.asarray(testdata_movie)}, fitting_method="gaussmle")
+    with pytest.raises(AssertionError, match="movie_info must be a list"):
+        localize.fit2D(**{**a, "movie_info": {}}, fitting_method="gaussmle")
+    with pytest.raises(AssertionError, match="box must be a positive integer"):
+        localize.fit2D(**{**a, "box": 7.0}, fitting_method="gaussmle")
+
+
+def test_fit2d_missing_pixelsize_warns_then_fails_loudly_without_gpu(testdata_movie):
+    from picasso_amd import _lib
+    a = _fit2d_args(_Movie(testdata_movie))
+    a["camera_info"] = {"Baseline": 0, "Sensitivity": 1, "Gain": 1}
+    with pytest.warns(UserWarning, match="Pixelsize"):
+        try:
+            localize.fit2D(**a, fitting_method="gaussmle", multiprocess=False)
+        except _lib.HipBackendError:
+            assert _lib.device_count() == 0      # no GPU here: loud failure, no CPU fallback
+    assert a["camera_info"]["Pixelsize"] == 130
+
+
+def test_methods_without_a_kernel_raise_not_implemented(testdata_movie):
+    a = _fit2d_args(_Movie(testdata_movie))
+    for m in ("gausslq", "gausslq-gpu", "avg"):
+        with pytest.raises(NotImplementedError, match="no HIP kernel yet"):
+            localize.fit2D(**a, fitting_method=m)
+
+
+def test_identify_deprecation_and_abort(testdata_movie):
+    with pytest.warns(DeprecationWarning, match="return_info"):
+        try:
+            localize.identify(testdata_movie, 5000, 7, abort_callback=lambda: True)
+        except Exception:
+            pass
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        assert localize.identify(testdata_movie, 5000, 7, abort_callback=lambda: True, return_info=True) is None
+
+
+def test_sigma_uncertainty_formula():
+    s, so, n, bg = np.float64(1.1), np.float64(1.2), np.float64(5000.0), np.float64(20.0)
+    sa2 = s**2 + 1 / 12
+    tau = 2 * np.pi * sa2 * bg / n
+    want = np.sqrt((s**2 / (4 * n)) * (1 + 8 * tau + np.sqrt(8 * tau / (1 + 2 * tau))))
+    assert np.isclose(gaussmle.sigma_uncertainty(s, so, n, bg), want, rtol=1e-12)

@@ -25,9 +25,17 @@
 
 namespace pmi {
 
+// float32 ops that must round exactly like the reference's unfused arithmetic.  They are
+// defined HERE, under the pragma above, so the instructions carry no `contract` flag
+// (the __f*_rn helpers of the HIP headers are compiled with contraction allowed).
+static __device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+static __device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+static __device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+
 constexpr int ID_TH = 32;    // tile rows
 constexpr int ID_TW = 128;   // tile cols
 constexpr int ID_NT = 256;   // threads per workgroup
+constexpr int ID_SHARDS = 8; // record-list shards (= XCDs); counters[0..7] = shard counts, counters[8] = total
 
 struct IdParams {
     int64_t Y, X;        // full frame
@@ -43,7 +51,7 @@ struct IdParams {
 template <typename T>
 __global__ __launch_bounds__(ID_NT) void identify_scan_kernel(
     const T *__restrict__ movie, IdParams p, const float *__restrict__ uxy,
-    Record *__restrict__ recs, long long cap, unsigned long long *__restrict__ n_total,
+    Record *__restrict__ recs, long long cap, unsigned long long *__restrict__ shard_cnt,
     int *__restrict__ frame_count)
 {
     extern __shared__ float smem[];
@@ -125,14 +133,15 @@ __global__ __launch_bounds__(ID_NT) void identify_scan_kernel(
             const float *rowp = row0 + LW;
             for (int l = 0; l < box; l++) {
                 if (k == h && l == h) continue;
-                float gy = __fsub_rn(rowp[l], rowm[l]);
-                float gx = __fsub_rn(row0[l + 1], row0[l - 1]);
-                float s = __fadd_rn(__fmul_rn(gy, suy[k * box + l]), __fmul_rn(gx, sux[k * box + l]));
-                ng = __fadd_rn(ng, s);
+                float gy = sub_rn(rowp[l], rowm[l]);
+                float gx = sub_rn(row0[l + 1], row0[l - 1]);
+                float s = add_rn(mul_rn(gy, suy[k * box + l]), mul_rn(gx, sux[k * box + l]));
+                ng = add_rn(ng, s);
             }
         }
         if ((double)ng > p.min_ng) {                                   // localize.py:288
-            unsigned long long pos = atomicAdd(n_total, 1ull);
+            const int shard = blockIdx.x & (ID_SHARDS - 1);     // one slot counter per XCD: a single hot word
+            unsigned long long pos = atomicAdd(&shard_cnt[shard], 1ull);   // saturates at ~88 atomics/us
             atomicAdd(&frame_count[fi], 1);
             if ((long long)pos < cap) {
                 Record rec;
@@ -140,7 +149,7 @@ __global__ __launch_bounds__(ID_NT) void identify_scan_kernel(
                 rec.y = ty * ID_TH + rr + p.y0;
                 rec.x = tx * ID_TW + cc + p.x0;
                 rec.ng = ng;
-                recs[pos] = rec;
+                recs[(long long)shard * cap + pos] = rec;
             }
         }
     }
@@ -149,7 +158,7 @@ __global__ __launch_bounds__(ID_NT) void identify_scan_kernel(
 // exclusive scan of per-frame counts (single workgroup), also publishes the total
 __global__ __launch_bounds__(1024) void frame_scan_kernel(const int *__restrict__ count, int *__restrict__ base,
                                                           int *__restrict__ cursor, int nframes,
-                                                          const unsigned long long *__restrict__ n_total,
+                                                          unsigned long long *__restrict__ counters,
                                                           long long *__restrict__ out_n)
 {
     __shared__ int buf[1024];
@@ -174,18 +183,23 @@ __global__ __launch_bounds__(1024) void frame_scan_kernel(const int *__restrict_
         if (tid == 1023) carry += incl;
         __syncthreads();
     }
-    if (tid == 0 && out_n) *out_n = (long long)*n_total;
+    if (tid == 0) {
+        unsigned long long total = 0;
+        for (int sh = 0; sh < ID_SHARDS; sh++) total += counters[sh];
+        counters[ID_SHARDS] = total;
+        if (out_n) *out_n = (long long)total;
+    }
 }
 
-__global__ void scatter_by_frame_kernel(const Record *__restrict__ recs, const unsigned long long *__restrict__ n_total,
+__global__ void scatter_by_frame_kernel(const Record *__restrict__ recs, const unsigned long long *__restrict__ counters,
                                         long long cap, long long f_first, const int *__restrict__ base,
                                         int *__restrict__ cursor, Record *__restrict__ grouped)
 {
-    long long n = (long long)*n_total;
-    if (n > cap) n = cap;
+    if ((long long)counters[ID_SHARDS] > cap) return;   // overflow: the caller retries with a larger capacity
+    const int shard = blockIdx.y;
     long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    Record r = recs[i];
+    if (i >= (long long)counters[shard]) return;
+    Record r = recs[(long long)shard * cap + i];
     int fi = (int)(r.frame - f_first);
     int slot = base[fi] + atomicAdd(&cursor[fi], 1);
     grouped[slot] = r;
@@ -195,12 +209,12 @@ __global__ void scatter_by_frame_kernel(const Record *__restrict__ recs, const u
 __global__ __launch_bounds__(PMI_WAVE) void sort_in_frame_kernel(const Record *__restrict__ grouped,
                                                                  const int *__restrict__ base,
                                                                  const int *__restrict__ count,
-                                                                 const unsigned long long *__restrict__ n_total,
+                                                                 const unsigned long long *__restrict__ counters,
                                                                  long long cap,
                                                                  int32_t *__restrict__ o_frame, int32_t *__restrict__ o_y,
                                                                  int32_t *__restrict__ o_x, float *__restrict__ o_ng)
 {
-    if ((long long)*n_total > cap) return;   // overflow: the caller retries with a larger capacity
+    if ((long long)counters[ID_SHARDS] > cap) return;   // overflow: the caller retries with a larger capacity
     const int fi = blockIdx.x;
     const int m = count[fi], b = base[fi];
     for (int q = threadIdx.x; q < m; q += PMI_WAVE) {
@@ -268,6 +282,10 @@ static int launch_scan(const void *d_movie, const IdParams &p, const float *d_ta
     return PMI_OK;
 }
 
+int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
+                         int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
+                         long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled);
+
 // d_movie points at frame 0 of a stack holding at least frames [f_lo, f_hi].
 // Labels written = frame index + label_offset.
 int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X, int box, double min_ng,
@@ -289,9 +307,9 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
     unsigned long long *d_total = nullptr;
     void *ptr = nullptr;
     int rc;
-    if ((rc = scratch(SCR_COUNTERS, 64, &ptr)) != PMI_OK) return rc;
+    if ((rc = scratch(SCR_COUNTERS, 128, &ptr)) != PMI_OK) return rc;
     d_total = (unsigned long long *)ptr;
-    PMI_HIP(hipMemsetAsync(d_total, 0, 64, s));
+    PMI_HIP(hipMemsetAsync(d_total, 0, 128, s));
     if (nf <= 0 || cy < box + 1 || cx < box + 1) {   // no interior pixel can be scanned
         PMI_HIP(hipMemsetAsync(d_out_n, 0, sizeof(int64_t), s));
         return PMI_OK;
@@ -309,7 +327,7 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
     Record *recs = nullptr, *grouped = nullptr;
     int *fc = nullptr;
     size_t rec_bytes = (size_t)std::max<int64_t>(cap, 1) * sizeof(Record);
-    if ((rc = scratch(SCR_RECORDS, rec_bytes, &ptr)) != PMI_OK) return rc; recs = (Record *)ptr;
+    if ((rc = scratch(SCR_RECORDS, rec_bytes * ID_SHARDS, &ptr)) != PMI_OK) return rc; recs = (Record *)ptr;
     if ((rc = scratch(SCR_RECORDS2, rec_bytes, &ptr)) != PMI_OK) return rc; grouped = (Record *)ptr;
     if ((rc = scratch(SCR_FRAME_COUNT, (size_t)nf * 3 * sizeof(int), &ptr)) != PMI_OK) return rc; fc = (int *)ptr;
     int *count = fc, *base = fc + nf, *cursor = fc + 2 * nf;
@@ -317,7 +335,12 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
 
     {
         ScopedKernelTimer tm(s, &g_last_times.scan_ms);
-        switch (dtype) {
+        bool fast = false;
+        rc = PMI_OK;
+        if (dtype == PMI_U16)      // register-pipelined packed-u16 scan (identify_fast.hip) when the layout allows
+            rc = launch_scan_u16_fast(d_movie, Y, X, p.y0, p.x0, p.cy, p.cx, f_lo, label_offset, p.nframes, box, min_ng,
+                                      d_tab, recs, cap, d_total, count, s, &fast);
+        if (rc == PMI_OK && !fast) switch (dtype) {
         case PMI_U16: rc = launch_scan<uint16_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;
         case PMI_U8:  rc = launch_scan<uint8_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;
         case PMI_I16: rc = launch_scan<int16_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;
@@ -333,7 +356,7 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
                        (long long *)d_out_n);
     if (cap > 0) {
         unsigned sb = (unsigned)((cap + 255) / 256);
-        hipLaunchKernelGGL(scatter_by_frame_kernel, dim3(sb), dim3(256), 0, s, recs, d_total, (long long)cap,
+        hipLaunchKernelGGL(scatter_by_frame_kernel, dim3(sb, ID_SHARDS), dim3(256), 0, s, recs, d_total, (long long)cap,
                            (long long)(f_lo + label_offset), base, cursor, grouped);
         hipLaunchKernelGGL(sort_in_frame_kernel, dim3((unsigned)nf), dim3(PMI_WAVE), 0, s, grouped, base, count,
                            d_total, (long long)cap, d_frame, d_y, d_x, d_ng);

@@ -1,0 +1,490 @@
+// identify_fast.hip — the uint16 fast path of identify: a register-pipelined,
+// packed-u16 first-argmax scan streaming rows straight from HBM (no LDS staging).
+//
+// Same semantics as identify_scan_kernel in identify.hip (picasso/localize.py:97-134
+// _local_maxima, :202-244 _net_gradient, :288 threshold); only the schedule differs:
+//
+//   * one wavefront owns a band of RB rows x 512 columns of one frame; lane l holds
+//     8 consecutive pixels of the current row as four packed u16x2 registers plus
+//     4 pixels of each neighbour chunk (one 16-byte and two 8-byte global loads per
+//     row, the neighbour loads are L1/L2 hits);
+//   * horizontal: L = max of the h pixels left of each pixel, R = max of the h to
+//     the right, Hrow = max(L, v, R), all as v_pk_max_u16 on aligned/odd pixel pairs
+//     (odd pairs by v_alignbit);
+//   * vertical: U[r] = max(Hrow[r-h+1..r]) from a register ring; a pixel of row r'
+//     is the FIRST maximum of its window iff v > max(U[r'-1], L) and
+//     v >= max(R, U[r'+h]); the first half is folded into pre = max(sat(bef+1), R)
+//     at row r', the second is tested h rows later: sat(max(pre, U) - v) == 0;
+//   * candidates (~2 % of pixels on shot noise) go to a per-wave LDS list; a range
+//     bound |ng| <= C_box * (max - min over the band-local 24-column neighbourhood)
+//     rejects the ones that cannot reach min_ng without touching memory again; the
+//     survivors get the exact float32 net gradient in the reference's (k,l) order.
+//
+// HBM traffic: every pixel is fetched once per band plus 2(h+2) halo rows
+// (RB = 64: +12.5 %, absorbed by L2/MALL because a frame's bands run on one XCD).
+#include <algorithm>
+#include <cstdlib>
+
+#include "pmi_common.h"
+
+#pragma clang fp contract(off)
+
+namespace pmi {
+
+// float32 ops that must round exactly like the reference's unfused arithmetic.  They are
+// defined HERE, under the pragma above, so the instructions carry no `contract` flag
+// (the __f*_rn helpers of the HIP headers are compiled with contraction allowed).
+static __device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
+static __device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
+static __device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+
+typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
+typedef unsigned int u32;
+
+__device__ __forceinline__ u32 pk_max(u32 a, u32 b)
+{
+    return __builtin_bit_cast(u32, __builtin_elementwise_max(__builtin_bit_cast(u16x2_t, a), __builtin_bit_cast(u16x2_t, b)));
+}
+__device__ __forceinline__ u32 pk_min(u32 a, u32 b)
+{
+    u32 d;     // asm: min(x, 1) would otherwise be rewritten into per-half compare/select (SDWA + nops)
+    asm("v_pk_min_u16 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+// v_pk_{add,sub}_u16 with the clamp bit (saturating); written as asm because the elementwise
+// saturating builtins expand into compare/select sequences on this toolchain
+__device__ __forceinline__ u32 pk_add_sat(u32 a, u32 b)
+{
+    u32 d;
+    asm("v_pk_add_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+__device__ __forceinline__ u32 pk_sub_sat(u32 a, u32 b)
+{
+    u32 d;
+    asm("v_pk_sub_u16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
+    return d;
+}
+
+struct FastParams {
+    const uint16_t *movie;
+    int64_t Y, X;
+    int y0, x0, cy, cx;
+    int64_t f_lo, label_off;
+    int nframes;
+    int bands, segs, bpf;      // bands per frame, 512-col segments per row, blocks per frame
+    int box;
+    double min_ng;
+    double bound_c;            // C_box: sum over the window of |ux|+|uy|, with margin
+};
+
+constexpr int FAST_WAVES = 4;
+
+// pair `s` = pixels (s, s+1) relative to the lane's first pixel; A[k] holds (2k-4, 2k-3),
+// Bp[k] = (2k-5, 2k-4)
+template <int S>
+__device__ __forceinline__ u32 pair_at(const u32 (&A)[8], const u32 (&Bp)[8])
+{
+    if constexpr (((S + 4) & 1) == 0) return A[(S + 4) / 2];
+    else return Bp[(S + 5) / 2];
+}
+
+template <int H, int K, int T>
+struct LR {
+    static __device__ __forceinline__ u32 left(const u32 (&A)[8], const u32 (&Bp)[8])
+    {
+        constexpr int c0 = 2 * K - 4;
+        u32 v = pair_at<c0 - H + T>(A, Bp);
+        if constexpr (T + 1 < H) return pk_max(v, LR<H, K, T + 1>::left(A, Bp));
+        else return v;
+    }
+    static __device__ __forceinline__ u32 right(const u32 (&A)[8], const u32 (&Bp)[8])
+    {
+        constexpr int c0 = 2 * K - 4;
+        u32 v = pair_at<c0 + 1 + T>(A, Bp);
+        if constexpr (T + 1 < H) return pk_max(v, LR<H, K, T + 1>::right(A, Bp));
+        else return v;
+    }
+};
+
+struct RowRegs { uint4 m; uint2 l, r; };
+
+// Exact float32 net gradient of one candidate whose stencil does not wrap, in the reference's
+// (k, l) order, from a sliding three-row register window (each pixel is loaded once).
+template <int H>
+__device__ __forceinline__ float exact_ng_noWrap(const uint16_t *__restrict__ src, int64_t X, int i, int j,
+                                                 const float *__restrict__ sux, const float *__restrict__ suy)
+{
+    constexpr int BOX = 2 * H + 1, W = 2 * H + 3;
+    const uint16_t *base = src + (int64_t)(i - H - 1) * X + (j - H - 1);
+    float rowA[W], rowB[W], rowC[W];      // rows k, k+1, k+2 of the (2H+3)^2 neighbourhood
+#pragma unroll
+    for (int b = 0; b < W; b++) { rowA[b] = (float)base[b]; rowB[b] = (float)base[X + b]; }
+    float ng = 0.0f;
+#pragma unroll
+    for (int k = 0; k < BOX; k++) {
+#pragma unroll
+        for (int b = 0; b < W; b++) rowC[b] = (float)base[(int64_t)(k + 2) * X + b];
+#pragma unroll
+        for (int l = 0; l < BOX; l++) {
+            if (k == H && l == H) continue;
+            // window pixel (k, l) sits at neighbourhood (k+1, l+1): rowB[l+1]
+            float gy = sub_rn(rowC[l + 1], rowA[l + 1]);
+            float gx = sub_rn(rowB[l + 2], rowB[l]);
+            float sacc = add_rn(mul_rn(gy, suy[k * BOX + l]), mul_rn(gx, sux[k * BOX + l]));
+            ng = add_rn(ng, sacc);
+        }
+#pragma unroll
+        for (int b = 0; b < W; b++) { rowA[b] = rowB[b]; rowB[b] = rowC[b]; }
+    }
+    return ng;
+}
+
+template <int H, int RB>
+__global__ __launch_bounds__(FAST_WAVES * 64) void identify_scan_u16_fast_kernel(
+    FastParams p, const float *__restrict__ uxy, Record *__restrict__ recs, long long cap,
+    unsigned long long *__restrict__ shard_cnt, int *__restrict__ frame_count)
+{
+    constexpr int BOX = 2 * H + 1;
+    constexpr int HR = H > 1 ? H - 1 : 1;                 // Hrow ring length (unused when H == 1)
+    constexpr int U_ = (H == 1) ? 2 : H * (H - 1);         // unroll period of both rings
+    constexpr int D = (U_ % 3 == 0) ? 3 : 2;               // rows of loads in flight
+    constexpr int GS = U_ >= 6 ? U_ : 8;                   // rows per min/max statistics group
+    constexpr int NR = RB + 2 * H + 2;                     // pipeline rows: band + H halo + 1 stats row each side
+    constexpr int NRP = ((NR + GS - 1) / GS) * GS;
+    constexpr int NG = NRP / GS;
+    constexpr int LIST = RB * 512 / ((H + 1) * (H + 1)) + 64;   // local maxima are > H apart
+
+    __shared__ unsigned s_list[FAST_WAVES][LIST];
+    __shared__ int s_cnt[FAST_WAVES];
+    __shared__ unsigned s_stat[FAST_WAVES][NG][64];       // (max << 16) | min of each lane's 8-column strip per row group
+    __shared__ float s_u[2 * BOX * BOX];
+
+    const int lane = threadIdx.x & 63;
+    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id as a scalar: row addressing stays on the SALU
+    for (int i = threadIdx.x; i < 2 * BOX * BOX; i += FAST_WAVES * 64) s_u[i] = uxy[i];
+    if (lane == 0) s_cnt[w] = 0;
+    __syncthreads();
+
+    // XCD-aware mapping: all blocks of a frame share blockIdx % 8 (= the XCD they run on)
+    const int m = blockIdx.x >> 3, xcd = blockIdx.x & 7;
+    const int fi = (m / p.bpf) * 8 + xcd;
+    const int unit = (m % p.bpf) * FAST_WAVES + w;
+    if (fi >= p.nframes || unit >= p.bands * p.segs) return;
+    const int band = unit / p.segs, seg = unit - band * p.segs;
+
+    const int nch = p.cx >> 3;                        // 8-pixel chunks per row
+    const int c8 = seg * 64 + lane;
+    const bool lane_valid = c8 < nch;
+    const int cm = min(c8, nch - 1);
+    const uint16_t *src = p.movie + ((int64_t)(p.f_lo + fi) * p.Y + p.y0) * p.X + p.x0;
+    const int col_m = cm * 8;
+    const int col_l = cm > 0 ? col_m - 4 : col_m;                 // clamped copies feed invalid pixels only
+    const int col_r = cm + 1 < nch ? col_m + 8 : col_m + 4;
+    const int band_lo = band * RB, band_hi = min(band_lo + RB, p.cy);
+    const int row_lo = max(band_lo, H), row_hi = min(band_hi, p.cy - H - 1);   // rows that may hold a maximum
+    const int rs0 = band_lo - H - 1;
+
+    // which of the lane's 8 pixels may hold a maximum: even pixels -> bits 0..3, odd -> bits 16..19,
+    // replicated for the four row slots of the candidate accumulator
+    u32 colmask = 0;
+    if (lane_valid) {
+#pragma unroll
+        for (int b = 0; b < 8; b++) {
+            int j = c8 * 8 + b;
+            if (j >= H && j < p.cx - H - 1) colmask |= 1u << ((b >> 1) + 16 * (b & 1));
+        }
+        colmask *= 0x1111u;
+    }
+
+    auto load_row = [&](int r) -> RowRegs {
+        int rc = min(max(r, 0), p.cy - 1);
+        const uint16_t *row = src + (int64_t)rc * p.X;
+        RowRegs o;
+        o.m = *reinterpret_cast<const uint4 *>(row + col_m);
+        o.l = *reinterpret_cast<const uint2 *>(row + col_l);
+        o.r = *reinterpret_cast<const uint2 *>(row + col_r);
+        return o;
+    };
+
+    u32 Hring[HR][4], Uprev[4], Dv[H][4], Dpre[H][4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        Uprev[q] = 0xffffffffu;
+#pragma unroll
+        for (int t = 0; t < HR; t++) Hring[t][q] = 0xffffffffu;
+#pragma unroll
+        for (int t = 0; t < H; t++) { Dv[t][q] = 0u; Dpre[t][q] = 0xffffffffu; }
+    }
+    u32 mn = 0xffffffffu, mx = 0u;
+    u32 acc = 0;                                      // "failed the test" bits of up to four rows
+
+    RowRegs pf[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) pf[d] = load_row(rs0 + d);
+
+    for (int sb = 0; sb < NRP; sb += U_) {
+#pragma unroll
+        for (int u = 0; u < U_; u++) {
+            const int st = sb + u;                    // pipeline step; row r = rs0 + st
+            const RowRegs cur = pf[u % D];
+            pf[u % D] = load_row(rs0 + st + D);
+            u32 A[8] = {cur.l.x, cur.l.y, cur.m.x, cur.m.y, cur.m.z, cur.m.w, cur.r.x, cur.r.y};
+            u32 Bp[8];
+            Bp[0] = 0;
+#pragma unroll
+            for (int k = 1; k < 8; k++) Bp[k] = __builtin_amdgcn_alignbit(A[k], A[k - 1], 16);
+            mn = pk_min(pk_min(mn, pk_min(A[2], A[3])), pk_min(A[4], A[5]));
+            mx = pk_max(pk_max(mx, pk_max(A[2], A[3])), pk_max(A[4], A[5]));
+
+            u32 L[4], R[4];
+            L[0] = LR<H, 2, 0>::left(A, Bp); R[0] = LR<H, 2, 0>::right(A, Bp);
+            L[1] = LR<H, 3, 0>::left(A, Bp); R[1] = LR<H, 3, 0>::right(A, Bp);
+            L[2] = LR<H, 4, 0>::left(A, Bp); R[2] = LR<H, 4, 0>::right(A, Bp);
+            L[3] = LR<H, 5, 0>::left(A, Bp); R[3] = LR<H, 5, 0>::right(A, Bp);
+            u32 tq[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                const u32 v = A[q + 2];
+                const u32 hrow = pk_max(pk_max(L[q], v), R[q]);
+                u32 Ucur = hrow;
+                if (H > 1) {
+#pragma unroll
+                    for (int t = 0; t < HR; t++) Ucur = pk_max(Ucur, Hring[t][q]);
+                }
+                const u32 bef = pk_max(Uprev[q], L[q]);
+                const u32 pre = pk_max(pk_add_sat(bef, 0x00010001u), R[q]);
+                // decision for the row H steps back (same ring slot): 0 in a half = passed
+                const u32 thr = pk_max(Dpre[u % H][q], Ucur);
+                tq[q] = pk_min(pk_sub_sat(thr, Dv[u % H][q]), 0x00010001u);
+                Dv[u % H][q] = v;
+                Dpre[u % H][q] = pre;
+                if (H > 1) Hring[u % HR][q] = hrow;
+                Uprev[q] = Ucur;
+            }
+            const int t4 = u % 4;                      // row slot inside the accumulator
+            acc |= (tq[0] | (tq[1] << 1) | (tq[2] << 2) | (tq[3] << 3)) << (4 * t4);
+            if (t4 == 3 || u == U_ - 1) {              // flush the candidates of the last t4+1 rows
+                const int rd0 = rs0 + (st - t4) - H;   // decision row of slot 0
+                u32 rowmask = 0;
+#pragma unroll
+                for (int tt = 0; tt <= t4; tt++)
+                    if (rd0 + tt >= row_lo && rd0 + tt < row_hi) rowmask |= 0x000f000fu << (4 * tt);
+                u32 pass = ~acc & rowmask & colmask;
+                acc = 0;
+                if (pass) {
+                    int slot = atomicAdd(&s_cnt[w], __popc(pass));
+                    while (pass) {
+                        const int b = __ffs(pass) - 1;
+                        pass &= pass - 1;
+                        const int within = b & 15;
+                        const int rd = rd0 + (within >> 2);
+                        const int j = c8 * 8 + ((within & 3) << 1) + (b >> 4);
+                        if (slot < LIST) s_list[w][slot] = ((unsigned)rd << 16) | (unsigned)j;
+                        slot++;
+                    }
+                }
+            }
+        }
+        if (((sb + U_) % GS) == 0) {                   // close a statistics group
+            const u32 lo = min(mn & 0xffffu, mn >> 16), hi = max(mx & 0xffffu, mx >> 16);
+            s_stat[w][(sb + U_) / GS - 1][lane] = (hi << 16) | lo;
+            mn = 0xffffffffu; mx = 0u;
+        }
+    }
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+
+    const float *sux = s_u, *suy = s_u + BOX * BOX;
+    // Results are buffered in registers and appended KBUF at a time: ONE slot-allocating atomic per
+    // flush per wave, on the counter of this block's shard (= XCD).  A single hot counter costs
+    // ~11 ns per atomic and was 40 % of the kernel.
+    constexpr int KBUF = 4;
+    int buf_i[KBUF], buf_j[KBUF], nbuf = 0;
+    float buf_ng[KBUF];
+    const int shard = blockIdx.x & 7;
+    auto flush = [&]() {
+        unsigned long long bal[KBUF];
+        int total = 0;
+#pragma unroll
+        for (int k = 0; k < KBUF; k++) { bal[k] = __ballot(k < nbuf); total += __popcll(bal[k]); }
+        if (total) {
+            unsigned long long basepos = 0;
+            if (lane == 0) { basepos = atomicAdd(&shard_cnt[shard], (unsigned long long)total); atomicAdd(&frame_count[fi], total); }
+            basepos = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(basepos >> 32)) << 32) |
+                      (unsigned)__builtin_amdgcn_readfirstlane((int)(basepos & 0xffffffffu));
+            int off = 0;
+#pragma unroll
+            for (int k = 0; k < KBUF; k++) {
+                if (k < nbuf) {
+                    const long long pos = (long long)basepos + off + __popcll(bal[k] & ((1ull << lane) - 1ull));
+                    if (pos < cap) {
+                        Record rec;
+                        rec.frame = (int32_t)(p.f_lo + fi + p.label_off);
+                        rec.y = buf_i[k] + p.y0;
+                        rec.x = buf_j[k] + p.x0;
+                        rec.ng = buf_ng[k];
+                        recs[(long long)shard * cap + pos] = rec;
+                    }
+                }
+                off += __popcll(bal[k]);
+            }
+        }
+        nbuf = 0;
+    };
+    auto append = [&](int i, int j, float ng) {
+        if ((double)ng > p.min_ng) {                   // localize.py:288
+#pragma unroll
+            for (int k = 0; k < KBUF; k++) if (k == nbuf) { buf_i[k] = i; buf_j[k] = j; buf_ng[k] = ng; }
+            nbuf++;
+        }
+    };
+    // slow exact path: wrapped stencils, saturated pixels, overflow rescans
+    auto process_slow = [&](int i, int j, bool recheck) {
+        const float v = (float)src[(int64_t)i * p.X + j];
+        if (recheck) {
+#pragma unroll 1
+            for (int k = -H; k <= H; k++)
+#pragma unroll 1
+                for (int l = -H; l <= H; l++) {
+                    float o = (float)src[(int64_t)(i + k) * p.X + (j + l)];
+                    if ((k < 0 || (k == 0 && l < 0)) ? !(v > o) : !(v >= o)) return;
+                }
+        }
+        float ng = 0.0f;
+#pragma unroll 1
+        for (int k = 0; k < BOX; k++) {
+            const int rk = i - H + k;
+            const int rm = rk - 1 < 0 ? rk - 1 + p.cy : rk - 1;          // numba negative-index wrap
+            const uint16_t *rowm = src + (int64_t)rm * p.X;
+            const uint16_t *row0 = src + (int64_t)rk * p.X;
+            const uint16_t *rowp = src + (int64_t)(rk + 1) * p.X;
+#pragma unroll 1
+            for (int l = 0; l < BOX; l++) {
+                if (k == H && l == H) continue;
+                const int cl = j - H + l;
+                const int clm = cl - 1 < 0 ? cl - 1 + p.cx : cl - 1;
+                float gy = sub_rn((float)rowp[cl], (float)rowm[cl]);
+                float gx = sub_rn((float)row0[cl + 1], (float)row0[clm]);
+                float sacc = add_rn(mul_rn(gy, suy[k * BOX + l]), mul_rn(gx, sux[k * BOX + l]));
+                ng = add_rn(ng, sacc);
+            }
+        }
+        append(i, j, ng);
+    };
+
+    const int found = s_cnt[w];
+    if (found <= LIST) {
+        // pass 1: cheap level-1 bound on every candidate; survivors are compacted in place
+        // (ballot + prefix count) so that the exact evaluation runs with full lanes
+        int kept = 0;
+        for (int q0 = 0; q0 < found; q0 += 64) {
+            const int q = q0 + lane;
+            bool keep = false;
+            unsigned e = 0;
+            if (q < found) {
+                e = s_list[w][q];
+                const int i = (int)(e >> 16), j = (int)(e & 0xffffu);
+                keep = true;
+                if (i != H && j != H) {       // |ng| <= C_box * (max - min) over the statistics cells covering the stencil
+                    const int ol = (j >> 3) & 63;
+                    const bool need_l = (j & 7) < H + 1, need_r = (j & 7) + H + 1 > 7;
+                    const int l0 = ol - (need_l ? 1 : 0), l1 = ol + (need_r ? 1 : 0);
+                    if (l0 >= 0 && l1 <= 63) {
+                        const int g0 = (i - H - 1 - rs0) / GS, g1 = (i + H + 1 - rs0) / GS;
+                        unsigned lo = 0xffffu, hi = 0u;
+                        for (int g = g0; g <= g1; g++)
+                            for (int l = l0; l <= l1; l++) {
+                                const unsigned sv = s_stat[w][g][l];
+                                lo = min(lo, sv & 0xffffu); hi = max(hi, sv >> 16);
+                            }
+                        if ((double)(hi - lo) * p.bound_c < p.min_ng) keep = false;
+                    }
+                }
+            }
+            const unsigned long long bal = __ballot(keep);
+            const int pos = kept + __popcll(bal & ((1ull << lane) - 1ull));
+            __builtin_amdgcn_wave_barrier();
+            if (keep) s_list[w][pos] = e;     // pos <= q: never overwrites an unread entry of a later chunk
+            kept += __popcll(bal);
+        }
+        __builtin_amdgcn_wave_barrier();
+        __threadfence_block();
+        // pass 2: exact float32 net gradient
+        int rounds = 0;
+        for (int q0 = 0; q0 < kept; q0 += 64) {
+            const int q = q0 + lane;
+            if (q < kept) {
+                const unsigned e = s_list[w][q];
+                const int i = (int)(e >> 16), j = (int)(e & 0xffffu);
+                const bool wraps = (i == H) || (j == H);
+                // the packed test cannot see ties at 65535 (saturating +1): those are rechecked exactly
+                const bool saturated = src[(int64_t)i * p.X + j] == 0xffffu;
+                if (!wraps && !saturated) append(i, j, exact_ng_noWrap<H>(src, p.X, i, j, sux, suy));
+                else process_slow(i, j, saturated);
+            }
+            if (++rounds == KBUF) { flush(); rounds = 0; }
+        }
+        flush();
+    } else {
+        // More candidates than local maxima can exist: a saturated (65535) plateau flooded the
+        // packed test.  Rescan this band pixel by pixel with the exact test (slow, rare).
+        const int j0 = seg * 512, j1 = min(j0 + 512, p.cx);
+        for (int idx0 = 0; idx0 < RB * 512; idx0 += 64) {
+            const int idx = idx0 + lane;
+            const int i = band_lo + idx / 512, j = j0 + (idx & 511);
+            if (i >= row_lo && i < row_hi && j < j1 && j >= H && j < p.cx - H - 1) process_slow(i, j, true);
+            flush();
+        }
+    }
+}
+
+template <int H, int RB>
+static int launch_fast(const FastParams &p, const float *d_tab, Record *recs, long long cap,
+                       unsigned long long *shard_cnt, int *frame_count, hipStream_t s)
+{
+    long long blocks = 8LL * p.bpf * ((p.nframes + 7) / 8);
+    if (blocks > 0x7fffffffLL) { set_error("identify: too many blocks (%lld)", blocks); return PMI_ERR_ARG; }
+    hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, RB>), dim3((unsigned)blocks), dim3(FAST_WAVES * 64), 0, s,
+                       p, d_tab, recs, cap, shard_cnt, frame_count);
+    PMI_HIP(hipGetLastError());
+    return PMI_OK;
+}
+
+// Returns PMI_OK and sets *handled when the fast path applies.
+int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
+                         int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
+                         long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled)
+{
+    *handled = false;
+    static const bool force_generic = getenv("PMI_IDENTIFY_GENERIC") != nullptr;
+    if (force_generic) return PMI_OK;
+    const int h = box / 2;
+    if (h < 1 || h > 4) return PMI_OK;
+    if ((X & 7) || (x0 & 7) || (cx & 7) || cx < 16 || ((uintptr_t)d_movie & 15)) return PMI_OK;
+    if (cy > 65535 || cx > 65535) return PMI_OK;
+    const int RB = h == 1 ? 16 : (h == 2 ? 32 : 64);     // keeps the per-wave candidate list <= 8.5 KB of LDS
+    FastParams p;
+    p.movie = (const uint16_t *)d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;
+    p.f_lo = f_lo; p.label_off = label_off; p.nframes = nframes; p.box = box; p.min_ng = min_ng;
+    p.bands = (cy + RB - 1) / RB;
+    p.segs = (cx / 8 + 63) / 64;
+    p.bpf = (p.bands * p.segs + FAST_WAVES - 1) / FAST_WAVES;
+    // C_box = sum over the window (centre excluded) of |ux| + |uy|, in double, +0.1 % margin
+    double c = 0.0;
+    for (int k = -h; k <= h; k++)
+        for (int l = -h; l <= h; l++)
+            if (k || l) c += (std::abs((double)k) + std::abs((double)l)) / std::sqrt((double)(k * k + l * l));
+    p.bound_c = c * 1.001;
+    int rc;
+    switch (h) {
+    case 1: rc = launch_fast<1, 16>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 2: rc = launch_fast<2, 32>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 3: rc = launch_fast<3, 64>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    default: rc = launch_fast<4, 64>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    }
+    if (rc == PMI_OK) *handled = true;
+    return rc;
+}
+
+}  // namespace pmi

@@ -174,3 +174,56 @@ def test_localize_pipeline_on_resident_movie(be, orc, testdata_movie):
     assert np.max(np.abs(t["y"] - (th[:, 1] + y - 3))[same]) < 1e-3
     assert np.max(np.abs(t["photons"] - th[:, 2])[same] / th[same, 2]) < 1e-4
     assert np.max(np.abs(t["sx"] - th[:, 4])[same]) < 1e-3
+
+
+@pytest.mark.parametrize("shape,box", [((3, 96, 128), 7), ((2, 200, 520), 7), ((2, 70, 1032), 5), ((1, 130, 64), 9),
+                                      ((4, 64, 16), 3), ((2, 137, 512), 7), ((2, 66, 1536), 9), ((3, 40, 24), 7)])
+def test_identify_fast_path_vs_oracle(be, orc, shape, box):
+    """uint16 movies whose width is a multiple of 8 take the register-pipelined scan
+    (identify_fast.hip): multi-segment rows, partial bands, partial last segment, ties,
+    saturated plateaus, ROI crops aligned to 8 columns, low/high thresholds."""
+    rng = np.random.default_rng(hash((shape, box)) % 2**32)
+    mov = rng.poisson(30, size=shape).astype(np.uint16) + 100
+    F, Y, X = shape
+    for f in range(F):                                   # bright blobs, some on the border bands
+        for _ in range(max(2, Y * X // 1500)):
+            y, x = int(rng.integers(1, Y - 1)), int(rng.integers(1, X - 1))
+            amp = int(rng.integers(200, 4000))
+            mov[f, max(0, y - 1):y + 2, max(0, x - 1):x + 2] += np.uint16(amp // 3)
+            mov[f, y, x] += np.uint16(amp)
+    mov[0, 10:14, 8:14] = 65535                          # saturated plateau (ties at the clamp value)
+    mov[-1, Y // 2, : X // 2] = 65535
+    mov[:, ::9, ::4] = mov[:, ::9, ::4] // 8 * 8         # ties
+    for min_ng in (-1e9, 300.0, 20000.0):
+        a = be.identify_arrays(mov, min_ng, box)
+        b = orc.identify(mov, min_ng, box, threads=4)
+        assert len(a[0]) == len(b[0]), (min_ng, len(a[0]), len(b[0]))
+        assert all(np.array_equal(p, q) for p, q in zip(a, b))
+    if X >= 32:
+        roi = ((3, 8), (Y - 2, X - 8))
+        a = be.identify_arrays(mov, 300.0, box, roi=roi)
+        b = orc.identify(mov, 300.0, box, roi=roi, threads=4)
+        assert all(np.array_equal(p, q) for p, q in zip(a, b))
+
+
+def test_identify_fast_path_all_zero_and_all_saturated(be, orc):
+    for val in (0, 65535, 777):
+        mov = np.full((2, 80, 256), val, np.uint16)
+        a = be.identify_arrays(mov, -1e9, 7)
+        b = orc.identify(mov, -1e9, 7, threads=2)
+        assert len(a[0]) == len(b[0]) == 0
+    mov = np.zeros((1, 80, 256), np.uint16)
+    mov[0, 40, 100] = 65535; mov[0, 40, 101] = 65535; mov[0, 3, 3] = 9; mov[0, 75, 251] = 9
+    a = be.identify_arrays(mov, -1e9, 7)
+    b = orc.identify(mov, -1e9, 7, threads=2)
+    assert all(np.array_equal(p, q) for p, q in zip(a, b)) and len(a[0]) >= 3
+
+
+def test_identify_capacity_retry(be, orc, testdata_movie):
+    """More rows than the first capacity guess: PMI_ERR_CAPACITY -> retry with the exact count."""
+    rng = np.random.default_rng(5)
+    mov = rng.integers(0, 4000, size=(3, 256, 256)).astype(np.uint16)
+    a = be.identify_arrays(mov, -1e9, 3)       # ~1/9 of all pixels are maxima: far above 4096 rows
+    b = orc.identify(mov, -1e9, 3, threads=4)
+    assert len(a[0]) == len(b[0]) > 4096
+    assert all(np.array_equal(p, q) for p, q in zip(a, b))

@@ -17,124 +17,11 @@
 // derivative (gaussmle.py:380-382).
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 
-#include "pmi_common.h"
+#include "fit_common.h"
 
 namespace pmi {
-
-constexpr int FIT_WAVES = 4;                 // waves per workgroup
-constexpr int FIT_NT = FIT_WAVES * PMI_WAVE;
-constexpr int FIT_MAXPIX = PMI_MAX_BOX * PMI_MAX_BOX;
-
-struct FitParams {
-    // source: spots (float32) or movie + identifications
-    const float *spots;
-    const void *movie;
-    const int32_t *frame, *y, *x;
-    int dtype;
-    int64_t Y, X;
-    float baseline, sensitivity, gain;
-    // common
-    int64_t N;             // capacity / number of rows
-    const int64_t *d_n;    // optional device row count
-    int box;
-    float eps_f;           // unused (kept for layout)
-    double eps;
-    int max_it;
-    float *thetas, *crlbs, *loglik;
-    int32_t *iterations;
-    unsigned long long *queue;   // dynamic spot queue
-    int *fallback_count;         // spots whose Fisher matrix needs the pinv path
-    int fallback_cap;
-    int *fallback_idx;
-    double *fallback_M;          // 36 doubles per flagged spot
-};
-
-// ---- DPP wave reductions -------------------------------------------------
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ float dpp_f(float v)
-{
-    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xf, false));
-}
-// sum over the 64 lanes, result uniform (broadcast from lane 63)
-__device__ __forceinline__ float wave_sum(float v)
-{
-    v += dpp_f<0xB1>(v);          // quad_perm [1,0,3,2]
-    v += dpp_f<0x4E>(v);          // quad_perm [2,3,0,1]
-    v += dpp_f<0x141>(v);         // row_half_mirror
-    v += dpp_f<0x140>(v);         // row_mirror
-    v += dpp_f<0x142, 0xA>(v);    // row_bcast15 -> rows 1,3
-    v += dpp_f<0x143, 0xC>(v);    // row_bcast31 -> rows 2,3
-    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
-}
-template <int CTRL, int ROW_MASK = 0xf>
-__device__ __forceinline__ double dpp_d(double v)
-{
-    long long b = __builtin_bit_cast(long long, v);
-    int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ double wave_sum_d(double v)
-{
-    v += dpp_d<0xB1>(v);
-    v += dpp_d<0x4E>(v);
-    v += dpp_d<0x141>(v);
-    v += dpp_d<0x140>(v);
-    v += dpp_d<0x142, 0xA>(v);
-    v += dpp_d<0x143, 0xC>(v);
-    long long b = __builtin_bit_cast(long long, v);
-    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
-    int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ float wave_min(float v)
-{
-    for (int off = 32; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-    return v;
-}
-
-// numpy-style NaN-propagating max/min and sign
-__device__ __forceinline__ float np_maxf(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
-__device__ __forceinline__ float np_minf(float a, float b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
-__device__ __forceinline__ float np_signf(float a) { return (a != a) ? a : (a > 0.f ? 1.f : (a < 0.f ? -1.f : 0.f)); }
-
-// One-dimensional pixel-integrated Gaussian terms for pixel index `i`:
-//   E   = deltaE                      (gaussmle.py:268-280)
-//   A   = dE/dmu,   A2 = d2E/dmu2     (gaussmle.py:283-303, without photons*PSF_other)
-//   S   = dE/dsig,  S2 = d2E/dsig2    (gaussmle.py:306-336)
-struct Terms { float E, A, A2, S, S2; };
-__device__ __forceinline__ Terms gauss_terms(float i, float mu, float sigma)
-{
-    const float is = 1.0f / sigma;
-    const float sn = 0.70710678118654757f * is;
-    const float c1 = 0.3989422804014327f * is;      // 1/(sqrt(2 pi) sigma)
-    const float is2 = is * is;
-    const float dm = i - mu - 0.5f, dp = i - mu + 0.5f;
-    Terms t;
-    t.E = 0.5f * (erff(dp * sn) - erff(dm * sn));
-    const float gm = __expf(-0.5f * dm * dm * is2), gp = __expf(-0.5f * dp * dp * is2);
-    const float q1 = dm * gm - dp * gp;
-    const float q3 = dm * dm * dm * gm - dp * dp * dp * gp;
-    t.A = (gm - gp) * c1;
-    t.A2 = q1 * c1 * is2;
-    t.S = q1 * c1 * is;
-    t.S2 = c1 * is2 * (q3 * is2 - 2.0f * q1);
-    return t;
-}
-
-__device__ __forceinline__ float load_movie_px(const void *movie, int dtype, int64_t idx)
-{
-    switch (dtype) {
-    case PMI_U16: return (float)((const uint16_t *)movie)[idx];
-    case PMI_U8:  return (float)((const uint8_t *)movie)[idx];
-    case PMI_I16: return (float)((const int16_t *)movie)[idx];
-    case PMI_U32: return (float)((const uint32_t *)movie)[idx];
-    case PMI_I32: return (float)((const int32_t *)movie)[idx];
-    default:      return ((const float *)movie)[idx];
-    }
-}
 
 // NP = params (5: "sigma", 6: "sigmaxy"); PPL = pixels per lane = ceil(box^2/64)
 template <int NP, int PPL, bool FROM_MOVIE>
@@ -477,6 +364,8 @@ static void launch_fit_ppl(int ppl, dim3 grid, hipStream_t s, const FitParams &p
 
 static int g_cu_count = 0;
 
+bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, hipStream_t s);   // gaussmle_g8.hip
+
 int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
 {
     if (p.box < 3 || p.box > PMI_MAX_BOX || (p.box & 1) == 0) { set_error("box must be odd, 3..%d (got %d)", PMI_MAX_BOX, p.box); return PMI_ERR_ARG; }
@@ -511,7 +400,10 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     dim3 grid((unsigned)std::max<int64_t>(blocks, 1));
     {
         ScopedKernelTimer tm(s, &g_last_times.fit_ms);
-        if (method == PMI_MLE_SIGMAXY) {
+        static const bool force_wave_per_spot = getenv("PMI_FIT_WAVE_PER_SPOT") != nullptr;
+        // boxes <= 7: eight spots per wavefront (gaussmle_g8.hip); larger boxes: one wavefront per spot
+        if (!force_wave_per_spot && launch_fit_g8(p, method, from_movie, g_cu_count, s)) {
+        } else if (method == PMI_MLE_SIGMAXY) {
             if (from_movie) launch_fit_ppl<6, true>(ppl, grid, s, p); else launch_fit_ppl<6, false>(ppl, grid, s, p);
         } else {
             if (from_movie) launch_fit_ppl<5, true>(ppl, grid, s, p); else launch_fit_ppl<5, false>(ppl, grid, s, p);

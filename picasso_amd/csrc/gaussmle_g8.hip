@@ -1,0 +1,433 @@
+// gaussmle_g8.hip — MLE fit for boxes up to 7x7: eight lanes per spot, eight spots
+// per wavefront, one ROW of the spot per lane.
+//
+// Same algorithm and quirks as mle_fit_kernel (gaussmle.hip; picasso/gaussmle.py
+// :28-168, :268-383, :533-954); only the mapping to the machine differs:
+//
+//   * lane (g, j): group g = lane / 8 fits one spot, lane j holds row j (B pixels in
+//     registers, j < B).  All eight lanes of a group are busy in the transcendental
+//     stage: lane j evaluates the pixel BOUNDARY j (erf and exp at j - 1/2 - mu) for
+//     x and for y — B+1 <= 8 boundaries serve all B pixels, a 7x cut over evaluating
+//     four erf per pixel;
+//   * boundary k+1 comes from lane j+1 by DPP row_shl:1; the per-column x terms of all
+//     B columns are exchanged inside the group through 160 B of LDS;
+//   * the model is separable, so each lane accumulates ten row-local sums over its B
+//     pixels and multiplies by its row constants once; 12 group reductions of three
+//     DPP steps (quad_perm, quad_perm, row_half_mirror) serve 8 spots at once;
+//   * Newton state is uniform inside a group; converged groups idle until the slowest
+//     of the eight finishes.
+//
+// Float32 Newton loop, float64 initial sums / Fisher matrix / LDL^T, like the
+// wave-per-spot kernel.
+#include <algorithm>
+
+#include "fit_common.h"
+
+namespace pmi {
+
+// 8-lane group reductions: every lane of the group ends with the result
+__device__ __forceinline__ float sum8(float v)
+{
+    v += dpp_f<0xB1>(v);      // quad_perm [1,0,3,2]
+    v += dpp_f<0x4E>(v);      // quad_perm [2,3,0,1]
+    v += dpp_f<0x141>(v);     // row_half_mirror
+    return v;
+}
+__device__ __forceinline__ float min8(float v)
+{
+    v = fminf(v, dpp_f<0xB1>(v));
+    v = fminf(v, dpp_f<0x4E>(v));
+    v = fminf(v, dpp_f<0x141>(v));
+    return v;
+}
+__device__ __forceinline__ double sum8_d(double v)
+{
+    v += dpp_d<0xB1>(v);
+    v += dpp_d<0x4E>(v);
+    v += dpp_d<0x141>(v);
+    return v;
+}
+// value of lane+1 / lane-1 (0 past the 16-lane DPP row; callers mask the group edges)
+__device__ __forceinline__ float from_next(float v) { return dpp_f<0x101>(v); }   // row_shl:1
+__device__ __forceinline__ double from_next_d(double v) { return dpp_d<0x101>(v); }
+__device__ __forceinline__ double from_prev_d(double v) { return dpp_d<0x111>(v); } // row_shr:1
+
+// erf(x), < 1 ulp, branch-free (two polynomial branches + select); one v_exp_f32
+__device__ __forceinline__ float erf_f32(float a)
+{
+    const float t = fabsf(a), s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    const float big = copysignf(1.0f - __expf(r), a);
+    float q = -5.96761703e-4f;
+    q = fmaf(q, s, 4.99119423e-3f);
+    q = fmaf(q, s, -2.67681349e-2f);
+    q = fmaf(q, s, 1.12819925e-1f);
+    q = fmaf(q, s, -3.76125336e-1f);
+    q = fmaf(q, s, 1.28379166e-1f);
+    const float small = fmaf(q, a, a);
+    return t > 0.921875f ? big : small;
+}
+
+struct BTerms { float E, A, A2, S, S2; };
+// per-pixel terms of index j from the boundary values of lane j (k = j) and lane j+1
+__device__ __forceinline__ BTerms boundary_terms(float jf, float mu, float sigma)
+{
+    const float is = 1.0f / sigma;
+    const float sn = 0.70710678118654757f * is, c1 = 0.3989422804014327f * is, is2 = is * is;
+    const float u0 = jf - 0.5f - mu;
+    const float e0 = erf_f32(u0 * sn);
+    const float g0 = __expf(-0.5f * u0 * u0 * is2);
+    const float e1 = from_next(e0), g1 = from_next(g0);
+    const float u1 = u0 + 1.0f;
+    const float q1 = u0 * g0 - u1 * g1;
+    const float q3 = u0 * u0 * u0 * g0 - u1 * u1 * u1 * g1;
+    BTerms t;
+    t.E = 0.5f * (e1 - e0);
+    t.A = (g0 - g1) * c1;
+    t.A2 = q1 * c1 * is2;
+    t.S = q1 * c1 * is;
+    t.S2 = c1 * is2 * (q3 * is2 - 2.0f * q1);
+    return t;
+}
+
+template <int NP, int B, bool FROM_MOVIE>
+__global__ __launch_bounds__(FIT_NT) void mle_fit_g8_kernel(FitParams p)
+{
+    // x terms of every column, per group: [wave][group][term][col]
+    __shared__ float s_x[FIT_WAVES][8][5][8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int g = lane >> 3, j = lane & 7;
+    const bool rowok = j < B;
+    constexpr int H = B / 2;
+    const float jf = (float)j;
+    int64_t n = p.N;
+    if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+
+    for (;;) {
+        unsigned long long base = 0;
+        if (lane == 0) base = atomicAdd(p.queue, 8ull);
+        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
+               (unsigned)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffu));
+        if ((int64_t)base >= n) break;
+        const int64_t sidx = (int64_t)base + g;
+        const bool spot_ok = sidx < n;
+
+        // ---- load row j of the spot (photons) -------------------------------
+        float d[B];
+#pragma unroll
+        for (int i = 0; i < B; i++) d[i] = 0.f;
+        if (spot_ok && rowok) {
+            if (FROM_MOVIE) {
+                const int64_t fr = p.frame[sidx], yy = p.y[sidx], xx = p.x[sidx];
+                const int64_t o = (fr * p.Y + (yy - H + j)) * p.X + (xx - H);
+#pragma unroll
+                for (int i = 0; i < B; i++)      // localize.py:1112: float32 sub, mul, div in this order
+                    d[i] = ((load_movie_px(p.movie, p.dtype, o + i) - p.baseline) * p.sensitivity) / p.gain;
+            } else {
+                const float *sp = p.spots + sidx * (B * B) + j * B;
+#pragma unroll
+                for (int i = 0; i < B; i++) d[i] = sp[i];
+            }
+        }
+
+        // ---- initial parameters (gaussmle.py:28-139) -----------------------
+        double ps = 0.0, px = 0.0;
+#pragma unroll
+        for (int i = 0; i < B; i++) { ps += (double)d[i]; px += (double)d[i] * (double)i; }
+        double sum = sum8_d(ps), sx_ = sum8_d(px), sy_ = sum8_d(ps * (double)j);
+        // 3x3 edge-clipped mean filter: row-local 3-column sums, then the rows above / below
+        float fmin_l = INFINITY;
+        {
+            double t3[B];
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                double a = (double)d[i];
+                if (i > 0) a = (double)d[i - 1] + a;
+                if (i + 1 < B) a += (double)d[i + 1];
+                t3[i] = a;
+            }
+            const bool up = j > 0, dn = j + 1 < B;
+            const int nrow = 1 + (up ? 1 : 0) + (dn ? 1 : 0);
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                const double a = from_prev_d(t3[i]), c = from_next_d(t3[i]);
+                double tot = t3[i];
+                if (up) tot = a + tot;
+                if (dn) tot += c;
+                const int ncol = 1 + (i > 0 ? 1 : 0) + (i + 1 < B ? 1 : 0);
+                const float filt = (float)(tot / (double)(nrow * ncol));
+                if (rowok) fmin_l = fminf(fmin_l, filt);
+            }
+        }
+        const float bg0 = min8(fmin_l);
+        double com_y, com_x;
+        if (sum <= 0.0) { sum = 0.01; com_y = (B - 1) / 2.0; com_x = (B - 1) / 2.0; }
+        else { com_y = sy_ / sum; com_x = sx_ / sum; }
+        double photons = sum - (double)(B * B) * (double)bg0;
+        photons = (photons != photons) ? photons : (photons > 1.0 ? photons : 1.0);
+        // second moments of (spot - bg) along the centre column (over rows) and centre row (over columns)
+        double a_sdy = 0.0, a_sy = 0.0, a_sdx = 0.0, a_sx = 0.0;
+        if (rowok) {
+            const float vm = d[H] - bg0;
+            a_sdy = (double)vm * (double)((j - H) * (j - H));
+            a_sy = (double)vm;
+            if (j == H) {
+#pragma unroll
+                for (int i = 0; i < B; i++) {
+                    const float v2 = d[i] - bg0;
+                    a_sdx += (double)v2 * (double)((i - H) * (i - H));
+                    a_sx += (double)v2;
+                }
+            }
+        }
+        a_sdy = sum8_d(a_sdy); a_sy = sum8_d(a_sy); a_sdx = sum8_d(a_sdx); a_sx = sum8_d(a_sx);
+        double isy = sqrt(a_sdy / a_sy), isx = sqrt(a_sdx / a_sx);
+        if (!isfinite(isy)) isy = 0.01;
+        if (!isfinite(isx)) isx = 0.01;
+        if (isx == 0) isx = 0.01;
+        if (isy == 0) isy = 0.01;
+
+        float th[6];
+        th[0] = (float)com_x; th[1] = (float)com_y; th[2] = (float)photons; th[3] = bg0;
+        if (NP == 6) { th[4] = (float)isx; th[5] = (float)isy; }
+        else { th[4] = (float)((isx + isy) / 2); th[5] = 0.f; }
+        float ms[6];
+        ms[0] = th[4]; ms[1] = th[4];
+        ms[2] = (float)(0.1 * (double)th[2]); ms[3] = (float)(0.1 * (double)th[3]);
+        ms[4] = (float)(0.2 * (double)th[4]); ms[5] = (float)(0.2 * (double)th[5]);
+
+        float old_x = th[0], old_y = th[1], old_sx = th[4], old_sy = th[5];
+        int kk = 0;
+        bool active = spot_ok && p.max_it > 0;
+        float *xs = &s_x[wid][g][0][0];
+
+        while (__any(active)) {
+            const float sgy = NP == 6 ? th[5] : th[4];
+            const BTerms tx = boundary_terms(jf, th[0], th[4]);     // column j
+            const BTerms ty = boundary_terms(jf, th[1], sgy);       // row j
+            __builtin_amdgcn_wave_barrier();
+            xs[0 * 8 + j] = tx.E; xs[1 * 8 + j] = tx.A; xs[2 * 8 + j] = tx.A2; xs[3 * 8 + j] = tx.S; xs[4 * 8 + j] = tx.S2;
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+
+            const float N_ = th[2], bg = th[3];
+            const float NEy = N_ * ty.E;
+            float a_cA = 0.f, a_cE = 0.f, a_c = 0.f, a_cS = 0.f, a_cA2 = 0.f, a_cS2 = 0.f;
+            float a_dA = 0.f, a_dE = 0.f, a_d = 0.f, a_dS = 0.f, a_dSE = 0.f;
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                const float Ex = xs[0 * 8 + i], Ax = xs[1 * 8 + i], A2x = xs[2 * 8 + i], Sx = xs[3 * 8 + i], S2x = xs[4 * 8 + i];
+                const float model = NEy * Ex + bg;
+                float cf = 0.f, df = 0.f;
+                if (model > 10e-3f) {
+                    const float r = 1.0f / model;
+                    cf = d[i] * r - 1.f;
+                    df = d[i] * r * r;
+                }
+                cf = np_minf(cf, 10e4f);
+                df = np_minf(df, 10e4f);
+                a_cA += cf * Ax; a_cE += cf * Ex; a_c += cf; a_cS += cf * Sx; a_cA2 += cf * A2x; a_cS2 += cf * S2x;
+                a_dA += df * Ax * Ax; a_dE += df * Ex * Ex; a_d += df; a_dS += df * Sx * Sx;
+                if (NP == 5) a_dSE += df * Sx * Ex;
+            }
+            float num[6], den[6];
+            const float NAy = N_ * ty.A, NA2y = N_ * ty.A2, NSy = N_ * ty.S, NS2y = N_ * ty.S2;
+            num[0] = NEy * a_cA;              den[0] = NEy * a_cA2 - NEy * NEy * a_dA;
+            num[1] = NAy * a_cE;              den[1] = NA2y * a_cE - NAy * NAy * a_dE;
+            num[2] = ty.E * a_cE;             den[2] = -ty.E * ty.E * a_dE;
+            num[3] = a_c;                     den[3] = -a_d;
+            if (NP == 6) {
+                num[4] = NEy * a_cS;          den[4] = NEy * a_cS2 - NEy * NEy * a_dS;
+                num[5] = NSy * a_cE;          den[5] = NS2y * a_cE - NSy * NSy * a_dE;
+            } else {
+                // isotropic sigma: du = N (Ey Sx + Ex Sy); d2u keeps the reference's precedence quirk
+                num[4] = NEy * a_cS + NSy * a_cE;
+                den[4] = (NEy * a_cS2 + 2.f * ty.S * a_cS + ty.S2 * a_cE)
+                         - (NEy * NEy * a_dS + 2.f * NEy * NSy * a_dSE + NSy * NSy * a_dE);
+                num[5] = 0.f; den[5] = 0.f;
+            }
+            if (!rowok) {
+#pragma unroll
+                for (int l = 0; l < 6; l++) { num[l] = 0.f; den[l] = 0.f; }
+            }
+#pragma unroll
+            for (int l = 0; l < NP; l++) { num[l] = sum8(num[l]); den[l] = sum8(den[l]); }
+
+            float nt[6];
+#pragma unroll
+            for (int l = 0; l < 6; l++) nt[l] = th[l];
+            bool conv;
+            if (NP == 6) {                                  // gaussmle.py:860-884
+#pragma unroll
+                for (int l = 0; l < 6; l++) {
+                    if (den[l] == 0.0f) nt[l] = th[l] - np_signf(num[l]) * ms[l];
+                    else nt[l] = th[l] - np_minf(np_maxf(num[l] / den[l], -ms[l]), ms[l]);
+                }
+                nt[2] = np_maxf(nt[2], 1.0f); nt[3] = np_maxf(nt[3], 0.01f);
+                nt[4] = np_maxf(nt[4], 0.01f); nt[5] = np_maxf(nt[5], 0.01f);
+                conv = ((double)fabsf(old_x - nt[0]) < p.eps) && ((double)fabsf(old_y - nt[1]) < p.eps) &&
+                       ((double)fabsf(old_sx - nt[4]) < p.eps) && ((double)fabsf(old_sy - nt[5]) < p.eps);
+            } else {                                        // gaussmle.py:647-670
+#pragma unroll
+                for (int l = 0; l < 5; l++) {
+                    float upd;
+                    if (den[l] == 0.0f) upd = np_signf(num[l] * ms[l]);
+                    else upd = np_minf(np_maxf(num[l] / den[l], -ms[l]), ms[l]);
+                    nt[l] = th[l] - upd;
+                }
+                nt[2] = np_maxf(nt[2], 1.0f); nt[3] = np_maxf(nt[3], 0.01f);
+                nt[4] = np_maxf(nt[4], 0.01f); nt[4] = np_minf(nt[4], (float)B);
+                conv = ((double)fabsf(old_x - nt[0]) < p.eps) && ((double)fabsf(old_y - nt[1]) < p.eps);
+            }
+            if (active) {                                   // finished groups keep their state
+#pragma unroll
+                for (int l = 0; l < 6; l++) th[l] = nt[l];
+                kk++;
+                old_x = th[0]; old_y = th[1]; old_sx = th[4]; old_sy = th[5];
+                if (conv || kk >= p.max_it) active = false;
+            }
+        }
+
+        // ---- CRLB and log-likelihood (gaussmle.py:673-742, 887-954) --------
+        double M[36];
+        float ll;
+        {
+            const float sgy = NP == 6 ? th[5] : th[4];
+            const BTerms tx = boundary_terms(jf, th[0], th[4]);
+            const BTerms ty = boundary_terms(jf, th[1], sgy);
+            __builtin_amdgcn_wave_barrier();
+            xs[0 * 8 + j] = tx.E; xs[1 * 8 + j] = tx.A; xs[3 * 8 + j] = tx.S;
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            double Mloc[21];
+#pragma unroll
+            for (int e = 0; e < 21; e++) Mloc[e] = 0.0;
+            float ll_loc = 0.f;
+            const float N_ = th[2];
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                const float Ex = xs[0 * 8 + i], Ax = xs[1 * 8 + i], Sx = xs[3 * 8 + i];
+                float du[6];
+                du[0] = N_ * ty.E * Ax;
+                du[1] = N_ * Ex * ty.A;
+                du[2] = Ex * ty.E;
+                du[3] = 1.f;
+                if (NP == 6) { du[4] = N_ * ty.E * Sx; du[5] = N_ * Ex * ty.S; }
+                else { du[4] = N_ * (ty.E * Sx + Ex * ty.S); du[5] = 0.f; }
+                const float model = N_ * Ex * ty.E + th[3];
+                if (rowok) {
+                    const double inv = 1.0 / (double)model;
+                    int e = 0;
+#pragma unroll
+                    for (int k = 0; k < NP; k++)
+#pragma unroll
+                        for (int l = k; l < NP; l++) { Mloc[e] += (double)(du[l] * du[k]) * inv; e++; }
+                    if (model > 0.f) {
+                        if (d[i] > 0.f) ll_loc += d[i] * __logf(model / d[i]) - (model - d[i]);
+                        else ll_loc += -model;
+                    }
+                }
+            }
+            int e = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++)
+#pragma unroll
+                for (int l = k; l < NP; l++) { const double v = sum8_d(Mloc[e]); M[k * NP + l] = v; M[l * NP + k] = v; e++; }
+            ll = sum8(ll_loc);
+        }
+
+        // LDL^T inverse diagonal (uniform inside the group); ill-conditioned -> pinv kernel
+        double L[36], D[6], diag[6];
+        bool bad = false;
+        double trM = 0.0;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            trM += M[i * NP + i];
+#pragma unroll
+            for (int c = 0; c <= i; c++) {
+                double a = M[i * NP + c];
+#pragma unroll
+                for (int k = 0; k < c; k++) a -= L[i * NP + k] * L[c * NP + k] * D[k];
+                if (c == i) { D[i] = a; if (!(a > 0.0)) bad = true; }
+                else L[i * NP + c] = a / D[c];
+            }
+        }
+        double Li[36];
+#pragma unroll
+        for (int i = 0; i < NP; i++)
+#pragma unroll
+            for (int c = 0; c < NP; c++) Li[i * NP + c] = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+        for (int c = 0; c < NP; c++)
+#pragma unroll
+            for (int i = c + 1; i < NP; i++) {
+                double a = 0.0;
+#pragma unroll
+                for (int k = c; k < i; k++) a -= L[i * NP + k] * Li[k * NP + c];
+                Li[i * NP + c] = a;
+            }
+        double trInv = 0.0;
+#pragma unroll
+        for (int i = 0; i < NP; i++) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = i; k < NP; k++) a += Li[k * NP + i] * Li[k * NP + i] / D[k];
+            diag[i] = a;
+            trInv += a;
+        }
+        if (!(trM * trInv < 1e12)) bad = true;
+
+        if (spot_ok && j == 0) {
+            float *to = p.thetas + sidx * 6, *co = p.crlbs + sidx * 6;
+#pragma unroll
+            for (int l = 0; l < 5; l++) to[l] = th[l];
+            to[5] = NP == 6 ? th[5] : th[4];
+#pragma unroll
+            for (int l = 0; l < NP; l++) co[l] = (float)diag[l];
+            if (NP == 5) co[5] = (float)diag[4];
+            p.loglik[sidx] = ll;
+            p.iterations[sidx] = kk;
+            if (bad) {
+                int slot = atomicAdd(p.fallback_count, 1);
+                if (slot < p.fallback_cap) {
+                    p.fallback_idx[slot] = (int)sidx;
+                    double *Mo = p.fallback_M + (size_t)slot * 36;
+                    for (int e = 0; e < NP * NP; e++) Mo[e] = M[e];
+                }
+            }
+        }
+    }
+}
+
+template <int NP, bool FROM_MOVIE>
+static void launch_g8_box(int box, dim3 grid, hipStream_t s, const FitParams &p)
+{
+    switch (box) {
+    case 3: hipLaunchKernelGGL((mle_fit_g8_kernel<NP, 3, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
+    case 5: hipLaunchKernelGGL((mle_fit_g8_kernel<NP, 5, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
+    default: hipLaunchKernelGGL((mle_fit_g8_kernel<NP, 7, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
+    }
+}
+
+// boxes 3, 5, 7: eight spots per wavefront.  Returns false when the box is not handled.
+bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, hipStream_t s)
+{
+    if (p.box > 7) return false;
+    const int64_t waves = (p.N + 7) / 8;
+    const int64_t blocks = std::min<int64_t>((waves + FIT_WAVES - 1) / FIT_WAVES, (int64_t)cu_count * 8);
+    dim3 grid((unsigned)std::max<int64_t>(blocks, 1));
+    if (method == PMI_MLE_SIGMAXY) {
+        if (from_movie) launch_g8_box<6, true>(p.box, grid, s, p); else launch_g8_box<6, false>(p.box, grid, s, p);
+    } else {
+        if (from_movie) launch_g8_box<5, true>(p.box, grid, s, p); else launch_g8_box<5, false>(p.box, grid, s, p);
+    }
+    return true;
+}
+
+}  // namespace pmi

@@ -16,7 +16,10 @@ out = [torch.empty(cap, dtype=torch.int32, device="cuda") for _ in range(3)] + [
 dn = torch.zeros(1, dtype=torch.int64, device="cuda")
 L.pmi_set_kernel_timing(1)
 a, b = ctypes.c_float(0), ctypes.c_float(0)
-for label, ng in (("scan only (min_ng 1e12)", 1e12), ("normal (5000)", 5000.0), ("low (400)", 400.0), ("all candidates (-1e9)", -1e9)):
+modes = (("scan only (min_ng 1e12)", 1e12), ("normal (5000)", 5000.0), ("low (400)", 400.0), ("all candidates (-1e9)", -1e9))
+if len(sys.argv) > 3:
+    modes = (modes[int(sys.argv[3])],)
+for label, ng in modes:
     ts = []
     for _ in range(4):
         rc = L.pmi_identify_dev(ctypes.c_void_p(mov.data_ptr()), 0, F, 512, 512, box, ng, None, 0, F - 1,

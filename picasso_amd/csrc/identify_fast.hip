@@ -79,6 +79,9 @@ struct FastParams {
 };
 
 constexpr int FAST_WAVES = 4;
+#ifndef FAST_MIN_WAVES
+#define FAST_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for
+#endif
 
 // pair `s` = pixels (s, s+1) relative to the lane's first pixel; A[k] holds (2k-4, 2k-3),
 // Bp[k] = (2k-5, 2k-4)
@@ -121,18 +124,19 @@ __device__ __forceinline__ float exact_ng_noWrap(const uint16_t *__restrict__ sr
 #pragma unroll
     for (int b = 0; b < W; b++) { rowA[b] = (float)base[b]; rowB[b] = (float)base[X + b]; }
     float ng = 0.0f;
-#pragma unroll
+#pragma unroll 1                               // rolled: a fully unrolled body keeps ~160 VGPRs live and costs a wave of occupancy
     for (int k = 0; k < BOX; k++) {
+        const uint16_t *rc = base + (int64_t)(k + 2) * X;
 #pragma unroll
-        for (int b = 0; b < W; b++) rowC[b] = (float)base[(int64_t)(k + 2) * X + b];
+        for (int b = 0; b < W; b++) rowC[b] = (float)rc[b];
+        const float *cy_ = suy + k * BOX, *cx_ = sux + k * BOX;
 #pragma unroll
         for (int l = 0; l < BOX; l++) {
-            if (k == H && l == H) continue;
             // window pixel (k, l) sits at neighbourhood (k+1, l+1): rowB[l+1]
             float gy = sub_rn(rowC[l + 1], rowA[l + 1]);
             float gx = sub_rn(rowB[l + 2], rowB[l]);
-            float sacc = add_rn(mul_rn(gy, suy[k * BOX + l]), mul_rn(gx, sux[k * BOX + l]));
-            ng = add_rn(ng, sacc);
+            float sacc = add_rn(mul_rn(gy, cy_[l]), mul_rn(gx, cx_[l]));
+            ng = (k == H && l == H) ? ng : add_rn(ng, sacc);      // the centre is skipped (its unit vector is 0/0)
         }
 #pragma unroll
         for (int b = 0; b < W; b++) { rowA[b] = rowB[b]; rowB[b] = rowC[b]; }
@@ -140,22 +144,26 @@ __device__ __forceinline__ float exact_ng_noWrap(const uint16_t *__restrict__ sr
     return ng;
 }
 
-template <int H, int RB>
-__global__ __launch_bounds__(FAST_WAVES * 64) void identify_scan_u16_fast_kernel(
+template <int H, int RB, int D>
+__global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan_u16_fast_kernel(
     FastParams p, const float *__restrict__ uxy, Record *__restrict__ recs, long long cap,
     unsigned long long *__restrict__ shard_cnt, int *__restrict__ frame_count)
 {
     constexpr int BOX = 2 * H + 1;
     constexpr int HR = H > 1 ? H - 1 : 1;                 // Hrow ring length (unused when H == 1)
     constexpr int U_ = (H == 1) ? 2 : H * (H - 1);         // unroll period of both rings
-    constexpr int D = (U_ % 3 == 0) ? 3 : 2;               // rows of loads in flight
+    static_assert(U_ % D == 0, "prefetch depth must divide the unroll period");
     constexpr int GS = U_ >= 6 ? U_ : 8;                   // rows per min/max statistics group
     constexpr int NR = RB + 2 * H + 2;                     // pipeline rows: band + H halo + 1 stats row each side
     constexpr int NRP = ((NR + GS - 1) / GS) * GS;
     constexpr int NG = NRP / GS;
-    constexpr int LIST = RB * 512 / ((H + 1) * (H + 1)) + 64;   // local maxima are > H apart
+    // Local maxima are > H apart, so a band holds at most RB*512/(H+1)^2 of them; shot noise gives ~1/(2H+1)^2
+    // per pixel.  The list is sized at 3/4 of the geometric bound (4 workgroups per CU fit in LDS);
+    // a denser band takes the exact rescan path below.
+    constexpr int LIST = (RB * 512 / ((H + 1) * (H + 1))) * 3 / 4;
+    static_assert(RB <= 128, "list entries keep the row in 7 bits");
 
-    __shared__ unsigned s_list[FAST_WAVES][LIST];
+    __shared__ unsigned short s_list[FAST_WAVES][LIST];   // (row - band_lo) << 9 | (col - 512 * seg)
     __shared__ int s_cnt[FAST_WAVES];
     __shared__ unsigned s_stat[FAST_WAVES][NG][64];       // (max << 16) | min of each lane's 8-column strip per row group
     __shared__ float s_u[2 * BOX * BOX];
@@ -197,13 +205,20 @@ __global__ __launch_bounds__(FAST_WAVES * 64) void identify_scan_u16_fast_kernel
         colmask *= 0x1111u;
     }
 
+    // per-lane byte offsets inside a row (32-bit) + a wave-uniform row base: the loads use
+    // SGPR-base + VGPR-offset addressing, no 64-bit vector address arithmetic per row
+    const unsigned off_m = (unsigned)col_m * 2u, off_l = (unsigned)col_l * 2u, off_r = (unsigned)col_r * 2u;
+    const char *frame_base = reinterpret_cast<const char *>(src);
+    const int64_t pitch = p.X * 2;
+    // interior bands never touch a row outside the crop: no clamping in their row loop
+    const bool interior = rs0 >= 0 && rs0 + NRP + D <= p.cy;
     auto load_row = [&](int r) -> RowRegs {
-        int rc = min(max(r, 0), p.cy - 1);
-        const uint16_t *row = src + (int64_t)rc * p.X;
+        const int rc = interior ? r : min(max(r, 0), p.cy - 1);
+        const char *row = frame_base + (int64_t)rc * pitch;
         RowRegs o;
-        o.m = *reinterpret_cast<const uint4 *>(row + col_m);
-        o.l = *reinterpret_cast<const uint2 *>(row + col_l);
-        o.r = *reinterpret_cast<const uint2 *>(row + col_r);
+        o.m = *reinterpret_cast<const uint4 *>(row + off_m);
+        o.l = *reinterpret_cast<const uint2 *>(row + off_l);
+        o.r = *reinterpret_cast<const uint2 *>(row + off_r);
         return o;
     };
 
@@ -235,7 +250,6 @@ __global__ __launch_bounds__(FAST_WAVES * 64) void identify_scan_u16_fast_kernel
 #pragma unroll
             for (int k = 1; k < 8; k++) Bp[k] = __builtin_amdgcn_alignbit(A[k], A[k - 1], 16);
             mn = pk_min(pk_min(mn, pk_min(A[2], A[3])), pk_min(A[4], A[5]));
-            mx = pk_max(pk_max(mx, pk_max(A[2], A[3])), pk_max(A[4], A[5]));
 
             u32 L[4], R[4];
             L[0] = LR<H, 2, 0>::left(A, Bp); R[0] = LR<H, 2, 0>::right(A, Bp);
@@ -247,6 +261,7 @@ __global__ __launch_bounds__(FAST_WAVES * 64) void identify_scan_u16_fast_kernel
             for (int q = 0; q < 4; q++) {
                 const u32 v = A[q + 2];
                 const u32 hrow = pk_max(pk_max(L[q], v), R[q]);
+                if (q == 0 || q == 3) mx = pk_max(mx, hrow);   // row-window maxima of pixels 0,1 and 6,7 cover all 8 columns
                 u32 Ucur = hrow;
                 if (H > 1) {
 #pragma unroll
@@ -280,7 +295,7 @@ __global__ __launch_bounds__(FAST_WAVES * 64) void identify_scan_u16_fast_kernel
                         const int within = b & 15;
                         const int rd = rd0 + (within >> 2);
                         const int j = c8 * 8 + ((within & 3) << 1) + (b >> 4);
-                        if (slot < LIST) s_list[w][slot] = ((unsigned)rd << 16) | (unsigned)j;
+                        if (slot < LIST) s_list[w][slot] = (unsigned short)(((rd - band_lo) << 9) | (j - seg * 512));
                         slot++;
                     }
                 }
@@ -381,10 +396,10 @@ __global__ __launch_bounds__(FAST_WAVES * 64) void identify_scan_u16_fast_kernel
         for (int q0 = 0; q0 < found; q0 += 64) {
             const int q = q0 + lane;
             bool keep = false;
-            unsigned e = 0;
+            unsigned short e = 0;
             if (q < found) {
                 e = s_list[w][q];
-                const int i = (int)(e >> 16), j = (int)(e & 0xffffu);
+                const int i = band_lo + (int)(e >> 9), j = seg * 512 + (int)(e & 511u);
                 keep = true;
                 if (i != H && j != H) {       // |ng| <= C_box * (max - min) over the statistics cells covering the stencil
                     const int ol = (j >> 3) & 63;
@@ -416,7 +431,7 @@ __global__ __launch_bounds__(FAST_WAVES * 64) void identify_scan_u16_fast_kernel
             const int q = q0 + lane;
             if (q < kept) {
                 const unsigned e = s_list[w][q];
-                const int i = (int)(e >> 16), j = (int)(e & 0xffffu);
+                const int i = band_lo + (int)(e >> 9), j = seg * 512 + (int)(e & 511u);
                 const bool wraps = (i == H) || (j == H);
                 // the packed test cannot see ties at 65535 (saturating +1): those are rechecked exactly
                 const bool saturated = src[(int64_t)i * p.X + j] == 0xffffu;
@@ -439,13 +454,13 @@ __global__ __launch_bounds__(FAST_WAVES * 64) void identify_scan_u16_fast_kernel
     }
 }
 
-template <int H, int RB>
+template <int H, int RB, int D>
 static int launch_fast(const FastParams &p, const float *d_tab, Record *recs, long long cap,
                        unsigned long long *shard_cnt, int *frame_count, hipStream_t s)
 {
     long long blocks = 8LL * p.bpf * ((p.nframes + 7) / 8);
     if (blocks > 0x7fffffffLL) { set_error("identify: too many blocks (%lld)", blocks); return PMI_ERR_ARG; }
-    hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, RB>), dim3((unsigned)blocks), dim3(FAST_WAVES * 64), 0, s,
+    hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, RB, D>), dim3((unsigned)blocks), dim3(FAST_WAVES * 64), 0, s,
                        p, d_tab, recs, cap, shard_cnt, frame_count);
     PMI_HIP(hipGetLastError());
     return PMI_OK;
@@ -477,11 +492,13 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
             if (k || l) c += (std::abs((double)k) + std::abs((double)l)) / std::sqrt((double)(k * k + l * l));
     p.bound_c = c * 1.001;
     int rc;
+    static const int deep = getenv("PMI_IDENTIFY_D6") ? 0 : 1;     // A/B switch for the prefetch depth (default 3 rows)
     switch (h) {
-    case 1: rc = launch_fast<1, 16>(p, d_tab, recs, cap, n_total, frame_count, s); break;
-    case 2: rc = launch_fast<2, 32>(p, d_tab, recs, cap, n_total, frame_count, s); break;
-    case 3: rc = launch_fast<3, 64>(p, d_tab, recs, cap, n_total, frame_count, s); break;
-    default: rc = launch_fast<4, 64>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 1: rc = launch_fast<1, 16, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 2: rc = launch_fast<2, 32, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 3: rc = deep ? launch_fast<3, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s)
+                      : launch_fast<3, 64, 6>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    default: rc = launch_fast<4, 64, 4>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     }
     if (rc == PMI_OK) *handled = true;
     return rc;

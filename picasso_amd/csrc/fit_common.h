@@ -25,12 +25,11 @@ struct FitParams {
     int max_it;
     float *thetas, *crlbs, *loglik;
     int32_t *iterations;
-    unsigned long long *queue;   // dynamic spot queue
-    int *fallback_count;         // spots whose Fisher matrix needs the pinv path
-    int fallback_cap;
-    int *fallback_idx;
-    double *fallback_M;          // 36 doubles per flagged spot
+    unsigned long long *queue;   // dynamic spot queue of this batch (counts from 0)
+    int64_t first;               // first spot of this batch; the kernel handles [first, min(N, *d_n))
+    double *fisher;              // upper triangle of the Fisher matrix, 21 doubles per spot of the batch
 };
+constexpr int FISHER_STRIDE = 21;
 
 // ---- DPP wave reductions -------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xf>

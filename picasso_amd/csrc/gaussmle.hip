@@ -51,6 +51,7 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p)
         if (lane == 0) sidx = atomicAdd(p.queue, 1ull);
         sidx = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(sidx >> 32)) << 32) |
                (unsigned)__builtin_amdgcn_readfirstlane((int)(sidx & 0xffffffffu));
+        sidx += (unsigned long long)p.first;
         if ((int64_t)sidx >= n) break;
 
         // ---- load the spot (photons) -----------------------------------
@@ -229,95 +230,42 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p)
                 }
             }
         }
-        double M[36];
+        // Fisher matrix (upper triangle) -> crlb_kernel; theta, log-likelihood, iterations out
+        double Msum[21];
         {
             int e = 0;
 #pragma unroll
             for (int k = 0; k < NP; k++)
 #pragma unroll
-                for (int l = k; l < NP; l++) { double v = wave_sum_d(Mloc[e]); M[k * NP + l] = v; M[l * NP + k] = v; e++; }
+                for (int l = k; l < NP; l++) { Msum[e] = wave_sum_d(Mloc[e]); e++; }
         }
         const float ll = wave_sum(ll_loc);
-
-        // LDL^T inverse diagonal; flagged for the pinv kernel when the matrix is not
-        // safely invertible in the sense of np.linalg.pinv's 1e-15 cutoff.
-        double L[36], D[6], diag[6];
-        bool bad = false;
-        double trM = 0.0;
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            trM += M[i * NP + i];
-#pragma unroll
-            for (int j = 0; j <= i; j++) {
-                double a = M[i * NP + j];
-#pragma unroll
-                for (int k = 0; k < j; k++) a -= L[i * NP + k] * L[j * NP + k] * D[k];
-                if (j == i) { D[i] = a; if (!(a > 0.0)) bad = true; }
-                else L[i * NP + j] = a / D[j];
-            }
-        }
-        // Linv = inverse of unit lower-triangular L; diag(M^-1)_i = sum_k Linv[k][i]^2 / D[k]
-        double Li[36];
-#pragma unroll
-        for (int i = 0; i < NP; i++)
-#pragma unroll
-            for (int j = 0; j < NP; j++) Li[i * NP + j] = (i == j) ? 1.0 : 0.0;
-#pragma unroll
-        for (int j = 0; j < NP; j++)
-#pragma unroll
-            for (int i = j + 1; i < NP; i++) {
-                double a = 0.0;
-#pragma unroll
-                for (int k = j; k < i; k++) a -= L[i * NP + k] * Li[k * NP + j];
-                Li[i * NP + j] = a;
-            }
-        double trInv = 0.0;
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            double a = 0.0;
-#pragma unroll
-            for (int k = i; k < NP; k++) a += Li[k * NP + i] * Li[k * NP + i] / D[k];
-            diag[i] = a;
-            trInv += a;
-        }
-        if (!(trM * trInv < 1e12)) bad = true;     // eigenvalue ratio could reach pinv's cutoff (or NaN)
-
         if (lane == 0) {
-            float *to = p.thetas + sidx * 6, *co = p.crlbs + sidx * 6;
+            float *to = p.thetas + sidx * 6;
 #pragma unroll
             for (int l = 0; l < 5; l++) to[l] = th[l];
             to[5] = NP == 6 ? th[5] : th[4];
-#pragma unroll
-            for (int l = 0; l < NP; l++) co[l] = (float)diag[l];
-            if (NP == 5) co[5] = (float)diag[4];
             p.loglik[sidx] = ll;
             p.iterations[sidx] = kk;
-            if (bad) {
-                int slot = atomicAdd(p.fallback_count, 1);
-                if (slot < p.fallback_cap) {
-                    p.fallback_idx[slot] = (int)sidx;
-                    double *Mo = p.fallback_M + (size_t)slot * 36;
-                    for (int e = 0; e < NP * NP; e++) Mo[e] = M[e];
-                }
-            }
+            double *fo = p.fisher + (sidx - (unsigned long long)p.first) * FISHER_STRIDE;
+#pragma unroll
+            for (int e = 0; e < NP * (NP + 1) / 2; e++) fo[e] = Msum[e];
         }
         __builtin_amdgcn_wave_barrier();
     }
 }
 
-// np.linalg.pinv diagonal for the flagged Fisher matrices (cyclic Jacobi,
-// singular values <= 1e-15 * max dropped).  One thread per flagged spot.
+// CRLB = diag(np.linalg.pinv(M)) (gaussmle.py:737, :950), one thread per spot.  Fast path:
+// LDL^T inverse when trace(M) * trace(M^-1) < 1e12, which keeps every eigenvalue far above
+// pinv's 1e-15 cutoff (pinv == inverse).  Otherwise a cyclic-Jacobi restatement of pinv's
+// semantics: eigenvalues <= 1e-15 * max are dropped, so singular directions give 0, not inf.
 template <int NP>
-__global__ void crlb_pinv_kernel(const int *__restrict__ count, int cap, const int *__restrict__ idx,
-                                 const double *__restrict__ Ms, float *__restrict__ crlbs)
+__device__ void pinv_diag_jacobi(const double *Min, double *diag)
 {
-    int t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= *count || t >= cap) return;
     double A[36], V[36];
     bool nonfinite = false;
-    for (int i = 0; i < NP * NP; i++) { A[i] = Ms[(size_t)t * 36 + i]; if (!isfinite(A[i])) nonfinite = true; }
-    float *co = crlbs + (size_t)idx[t] * 6;
-    if (nonfinite) { for (int i = 0; i < 6; i++) co[i] = NAN; return; }
+    for (int i = 0; i < NP * NP; i++) { A[i] = Min[i]; if (!isfinite(A[i])) nonfinite = true; }
+    if (nonfinite) { for (int i = 0; i < NP; i++) diag[i] = NAN; return; }
     for (int i = 0; i < NP; i++) for (int j = 0; j < NP; j++) V[i * NP + j] = (i == j) ? 1.0 : 0.0;
     for (int sweep = 0; sweep < 60; sweep++) {
         double off = 0.0;
@@ -338,13 +286,75 @@ __global__ void crlb_pinv_kernel(const int *__restrict__ count, int cap, const i
     double smax = 0.0;
     for (int i = 0; i < NP; i++) smax = fmax(smax, fabs(A[i * NP + i]));
     const double cutoff = 1e-15 * smax;
-    double diag[6];
     for (int i = 0; i < NP; i++) {
         double acc = 0.0;
         for (int k = 0; k < NP; k++) { double lam = A[k * NP + k]; if (fabs(lam) > cutoff) acc += V[i * NP + k] * V[i * NP + k] / lam; }
         diag[i] = acc;
     }
-    for (int i = 0; i < NP; i++) co[i] = (float)diag[i];
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void crlb_kernel(const double *__restrict__ fisher, int64_t first, int64_t N,
+                                                   const int64_t *__restrict__ d_n, float *__restrict__ crlbs)
+{
+    int64_t n = N;
+    if (d_n) { int64_t dn = *d_n; n = dn < n ? dn : n; }
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t sidx = first + t;
+    if (sidx >= n) return;
+    const double *f = fisher + t * FISHER_STRIDE;
+    double M[36];
+    {
+        int e = 0;
+#pragma unroll
+        for (int k = 0; k < NP; k++)
+#pragma unroll
+            for (int l = k; l < NP; l++) { const double v = f[e++]; M[k * NP + l] = v; M[l * NP + k] = v; }
+    }
+    double L[36], D[6], diag[6];
+    bool bad = false;
+    double trM = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        trM += M[i * NP + i];
+#pragma unroll
+        for (int c = 0; c <= i; c++) {
+            double a = M[i * NP + c];
+#pragma unroll
+            for (int k = 0; k < c; k++) a -= L[i * NP + k] * L[c * NP + k] * D[k];
+            if (c == i) { D[i] = a; if (!(a > 0.0)) bad = true; }
+            else L[i * NP + c] = a / D[c];
+        }
+    }
+    // Linv = inverse of the unit lower-triangular L; diag(M^-1)_i = sum_k Linv[k][i]^2 / D[k]
+    double Li[36];
+#pragma unroll
+    for (int i = 0; i < NP; i++)
+#pragma unroll
+        for (int c = 0; c < NP; c++) Li[i * NP + c] = (i == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int c = 0; c < NP; c++)
+#pragma unroll
+        for (int i = c + 1; i < NP; i++) {
+            double a = 0.0;
+#pragma unroll
+            for (int k = c; k < i; k++) a -= L[i * NP + k] * Li[k * NP + c];
+            Li[i * NP + c] = a;
+        }
+    double trInv = 0.0;
+#pragma unroll
+    for (int i = 0; i < NP; i++) {
+        double a = 0.0;
+#pragma unroll
+        for (int k = i; k < NP; k++) a += Li[k * NP + i] * Li[k * NP + i] / D[k];
+        diag[i] = a;
+        trInv += a;
+    }
+    if (!(trM * trInv < 1e12)) bad = true;       // eigenvalue ratio could reach pinv's cutoff (or NaN)
+    if (bad) pinv_diag_jacobi<NP>(M, diag);
+    float *co = crlbs + sidx * 6;
+#pragma unroll
+    for (int l = 0; l < NP; l++) co[l] = (float)diag[l];
     if (NP == 5) co[5] = (float)diag[4];
 }
 
@@ -378,45 +388,46 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         PMI_HIP(hipGetDevice(&dev));
         PMI_HIP(hipDeviceGetAttribute(&g_cu_count, hipDeviceAttributeMultiprocessorCount, dev));
     }
-    void *ptr = nullptr;
+    // Spots are processed in batches so that the Fisher scratch (168 B per spot) stays bounded;
+    // every batch has its own queue word.  With a device-side row count (d_n) the batches past
+    // the count exit immediately.
+    const int64_t BATCH = 1 << 22;
+    const int64_t nb = (p.N + BATCH - 1) / BATCH;
+    void *ptr = nullptr, *fptr = nullptr;
     int rc;
-    // queue counter + fallback counter, then fallback index list and matrices
-    // The pinv fallback store is sized for the worst case only for small batches; large
-    // batches cap it (ill-conditioned Fisher matrices are rare) and flags beyond the cap
-    // keep their LDL^T result.
-    size_t fb_cap = (size_t)std::min<int64_t>(p.N, 1 << 18);
-    p.fallback_cap = (int)fb_cap;
-    if ((rc = scratch(SCR_FIT, 64 + fb_cap * sizeof(int) + 64, &ptr)) != PMI_OK) return rc;
-    p.queue = (unsigned long long *)ptr;
-    p.fallback_count = (int *)((char *)ptr + 16);
-    p.fallback_idx = (int *)((char *)ptr + 64);
-    void *mptr = nullptr;
-    if ((rc = scratch(SCR_STAGE_D, fb_cap * 36 * sizeof(double), &mptr)) != PMI_OK) return rc;
-    p.fallback_M = (double *)mptr;
-    PMI_HIP(hipMemsetAsync(ptr, 0, 64, s));
-
+    if ((rc = scratch(SCR_FIT, (size_t)nb * 8 + 64, &ptr)) != PMI_OK) return rc;
+    if ((rc = scratch(SCR_STAGE_D, (size_t)std::min<int64_t>(p.N, BATCH) * FISHER_STRIDE * sizeof(double), &fptr)) != PMI_OK) return rc;
+    PMI_HIP(hipMemsetAsync(ptr, 0, (size_t)nb * 8, s));
+    p.fisher = (double *)fptr;
     const int ppl = (p.box * p.box + 63) / 64;
-    int64_t blocks = std::min<int64_t>((p.N + FIT_WAVES - 1) / FIT_WAVES, (int64_t)g_cu_count * 8);
-    dim3 grid((unsigned)std::max<int64_t>(blocks, 1));
-    {
-        ScopedKernelTimer tm(s, &g_last_times.fit_ms);
-        static const bool force_wave_per_spot = getenv("PMI_FIT_WAVE_PER_SPOT") != nullptr;
+    const int64_t Ntotal = p.N;
+    ScopedKernelTimer tm(s, &g_last_times.fit_ms);
+    static const bool force_wave_per_spot = getenv("PMI_FIT_WAVE_PER_SPOT") != nullptr;
+    for (int64_t bi = 0; bi < nb; bi++) {
+        p.first = bi * BATCH;
+        p.N = std::min<int64_t>(Ntotal, p.first + BATCH);
+        p.queue = (unsigned long long *)ptr + bi;
+        const int64_t count = p.N - p.first;
         // boxes <= 7: eight spots per wavefront (gaussmle_g8.hip); larger boxes: one wavefront per spot
         if (!force_wave_per_spot && launch_fit_g8(p, method, from_movie, g_cu_count, s)) {
-        } else if (method == PMI_MLE_SIGMAXY) {
-            if (from_movie) launch_fit_ppl<6, true>(ppl, grid, s, p); else launch_fit_ppl<6, false>(ppl, grid, s, p);
         } else {
-            if (from_movie) launch_fit_ppl<5, true>(ppl, grid, s, p); else launch_fit_ppl<5, false>(ppl, grid, s, p);
+            int64_t blocks = std::min<int64_t>((count + FIT_WAVES - 1) / FIT_WAVES, (int64_t)g_cu_count * 8);
+            dim3 grid((unsigned)std::max<int64_t>(blocks, 1));
+            if (method == PMI_MLE_SIGMAXY) {
+                if (from_movie) launch_fit_ppl<6, true>(ppl, grid, s, p); else launch_fit_ppl<6, false>(ppl, grid, s, p);
+            } else {
+                if (from_movie) launch_fit_ppl<5, true>(ppl, grid, s, p); else launch_fit_ppl<5, false>(ppl, grid, s, p);
+            }
         }
-        tm.stop();
+        PMI_HIP(hipGetLastError());
+        const unsigned cb = (unsigned)((count + 255) / 256);
+        if (method == PMI_MLE_SIGMAXY)
+            hipLaunchKernelGGL((crlb_kernel<6>), dim3(cb), dim3(256), 0, s, p.fisher, p.first, p.N, p.d_n, p.crlbs);
+        else
+            hipLaunchKernelGGL((crlb_kernel<5>), dim3(cb), dim3(256), 0, s, p.fisher, p.first, p.N, p.d_n, p.crlbs);
+        PMI_HIP(hipGetLastError());
     }
-    PMI_HIP(hipGetLastError());
-    unsigned fb_blocks = (unsigned)((fb_cap + 63) / 64);
-    if (method == PMI_MLE_SIGMAXY)
-        hipLaunchKernelGGL((crlb_pinv_kernel<6>), dim3(fb_blocks), dim3(64), 0, s, p.fallback_count, p.fallback_cap, p.fallback_idx, p.fallback_M, p.crlbs);
-    else
-        hipLaunchKernelGGL((crlb_pinv_kernel<5>), dim3(fb_blocks), dim3(64), 0, s, p.fallback_count, p.fallback_cap, p.fallback_idx, p.fallback_M, p.crlbs);
-    PMI_HIP(hipGetLastError());
+    tm.stop();
     return PMI_OK;
 }
 

@@ -74,11 +74,19 @@ __device__ __forceinline__ float erf_f32(float a)
     return t > 0.921875f ? big : small;
 }
 
+__device__ __forceinline__ float rcp_f32(float x) { return __builtin_amdgcn_rcpf(x); }       // v_rcp_f32, 1 ulp
+// numpy clip / maximum / minimum semantics (NaN propagates) at 3 instructions instead of 8
+// np.minimum(np.maximum(q, -lim), lim): NOT a median — max_step can be negative (background below zero
+// after baseline subtraction), and then the reference's nested min/max always returns lim
+__device__ __forceinline__ float clip_np(float q, float lim) { const float c = fminf(fmaxf(q, -lim), lim); return (q != q) ? q : c; }
+__device__ __forceinline__ float max_np(float a, float b) { const float c = fmaxf(a, b); return (a != a) ? a : c; }   // b is a finite constant
+__device__ __forceinline__ float min_np(float a, float b) { const float c = fminf(a, b); return (a != a) ? a : c; }
+
 struct BTerms { float E, A, A2, S, S2; };
 // per-pixel terms of index j from the boundary values of lane j (k = j) and lane j+1
 __device__ __forceinline__ BTerms boundary_terms(float jf, float mu, float sigma)
 {
-    const float is = 1.0f / sigma;
+    const float is = rcp_f32(sigma);
     const float sn = 0.70710678118654757f * is, c1 = 0.3989422804014327f * is, is2 = is * is;
     const float u0 = jf - 0.5f - mu;
     const float e0 = erf_f32(u0 * sn);
@@ -114,6 +122,7 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_g8_kernel(FitParams p)
         if (lane == 0) base = atomicAdd(p.queue, 8ull);
         base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
                (unsigned)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffu));
+        base += (unsigned long long)p.first;
         if ((int64_t)base >= n) break;
         const int64_t sidx = (int64_t)base + g;
         const bool spot_ok = sidx < n;
@@ -224,14 +233,11 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_g8_kernel(FitParams p)
             for (int i = 0; i < B; i++) {
                 const float Ex = xs[0 * 8 + i], Ax = xs[1 * 8 + i], A2x = xs[2 * 8 + i], Sx = xs[3 * 8 + i], S2x = xs[4 * 8 + i];
                 const float model = NEy * Ex + bg;
-                float cf = 0.f, df = 0.f;
-                if (model > 10e-3f) {
-                    const float r = 1.0f / model;
-                    cf = d[i] * r - 1.f;
-                    df = d[i] * r * r;
-                }
-                cf = np_minf(cf, 10e4f);
-                df = np_minf(df, 10e4f);
+                const float r = rcp_f32(model);
+                const float dr = d[i] * r;
+                const bool ok = model > 10e-3f;             // gaussmle.py:831: otherwise cf = df = 0
+                const float cf = ok ? min_np(dr - 1.f, 10e4f) : 0.f;
+                const float df = ok ? min_np(dr * r, 10e4f) : 0.f;
                 a_cA += cf * Ax; a_cE += cf * Ex; a_c += cf; a_cS += cf * Sx; a_cA2 += cf * A2x; a_cS2 += cf * S2x;
                 a_dA += df * Ax * Ax; a_dE += df * Ex * Ex; a_d += df; a_dS += df * Sx * Sx;
                 if (NP == 5) a_dSE += df * Sx * Ex;
@@ -266,37 +272,34 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_g8_kernel(FitParams p)
             if (NP == 6) {                                  // gaussmle.py:860-884
 #pragma unroll
                 for (int l = 0; l < 6; l++) {
-                    if (den[l] == 0.0f) nt[l] = th[l] - np_signf(num[l]) * ms[l];
-                    else nt[l] = th[l] - np_minf(np_maxf(num[l] / den[l], -ms[l]), ms[l]);
+                    const float stepz = np_signf(num[l]) * ms[l];                 // zero denominator (gaussmle.py:873)
+                    const float stepn = clip_np(num[l] * rcp_f32(den[l]), ms[l]);
+                    nt[l] = th[l] - (den[l] == 0.0f ? stepz : stepn);
                 }
-                nt[2] = np_maxf(nt[2], 1.0f); nt[3] = np_maxf(nt[3], 0.01f);
-                nt[4] = np_maxf(nt[4], 0.01f); nt[5] = np_maxf(nt[5], 0.01f);
+                nt[2] = max_np(nt[2], 1.0f); nt[3] = max_np(nt[3], 0.01f);
+                nt[4] = max_np(nt[4], 0.01f); nt[5] = max_np(nt[5], 0.01f);
                 conv = ((double)fabsf(old_x - nt[0]) < p.eps) && ((double)fabsf(old_y - nt[1]) < p.eps) &&
                        ((double)fabsf(old_sx - nt[4]) < p.eps) && ((double)fabsf(old_sy - nt[5]) < p.eps);
             } else {                                        // gaussmle.py:647-670
 #pragma unroll
                 for (int l = 0; l < 5; l++) {
-                    float upd;
-                    if (den[l] == 0.0f) upd = np_signf(num[l] * ms[l]);
-                    else upd = np_minf(np_maxf(num[l] / den[l], -ms[l]), ms[l]);
-                    nt[l] = th[l] - upd;
+                    const float stepz = np_signf(num[l] * ms[l]);                 // +-1, not +-max_step (gaussmle.py:658)
+                    const float stepn = clip_np(num[l] * rcp_f32(den[l]), ms[l]);
+                    nt[l] = th[l] - (den[l] == 0.0f ? stepz : stepn);
                 }
-                nt[2] = np_maxf(nt[2], 1.0f); nt[3] = np_maxf(nt[3], 0.01f);
-                nt[4] = np_maxf(nt[4], 0.01f); nt[4] = np_minf(nt[4], (float)B);
+                nt[2] = max_np(nt[2], 1.0f); nt[3] = max_np(nt[3], 0.01f);
+                nt[4] = max_np(nt[4], 0.01f); nt[4] = min_np(nt[4], (float)B);
                 conv = ((double)fabsf(old_x - nt[0]) < p.eps) && ((double)fabsf(old_y - nt[1]) < p.eps);
             }
-            if (active) {                                   // finished groups keep their state
+            // finished groups keep their state (selects, no branch)
 #pragma unroll
-                for (int l = 0; l < 6; l++) th[l] = nt[l];
-                kk++;
-                old_x = th[0]; old_y = th[1]; old_sx = th[4]; old_sy = th[5];
-                if (conv || kk >= p.max_it) active = false;
-            }
+            for (int l = 0; l < 6; l++) th[l] = active ? nt[l] : th[l];
+            kk += active ? 1 : 0;
+            old_x = th[0]; old_y = th[1]; old_sx = th[4]; old_sy = th[5];
+            active = active && !(conv || kk >= p.max_it);
         }
 
-        // ---- CRLB and log-likelihood (gaussmle.py:673-742, 887-954) --------
-        double M[36];
-        float ll;
+        // ---- Fisher matrix and log-likelihood (gaussmle.py:673-742, 887-954) ----
         {
             const float sgy = NP == 6 ? th[5] : th[4];
             const BTerms tx = boundary_terms(jf, th[0], th[4]);
@@ -334,72 +337,22 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_g8_kernel(FitParams p)
                     }
                 }
             }
-            int e = 0;
+            // group sums; lane j stores entries j, j+8, j+16 of its spot's Fisher triangle
+            // (the 6x6 inverse runs in crlb_kernel, one thread per spot, not 8-fold redundantly here)
+            double *fo = p.fisher + (sidx - p.first) * FISHER_STRIDE;
 #pragma unroll
-            for (int k = 0; k < NP; k++)
-#pragma unroll
-                for (int l = k; l < NP; l++) { const double v = sum8_d(Mloc[e]); M[k * NP + l] = v; M[l * NP + k] = v; e++; }
-            ll = sum8(ll_loc);
-        }
-
-        // LDL^T inverse diagonal (uniform inside the group); ill-conditioned -> pinv kernel
-        double L[36], D[6], diag[6];
-        bool bad = false;
-        double trM = 0.0;
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            trM += M[i * NP + i];
-#pragma unroll
-            for (int c = 0; c <= i; c++) {
-                double a = M[i * NP + c];
-#pragma unroll
-                for (int k = 0; k < c; k++) a -= L[i * NP + k] * L[c * NP + k] * D[k];
-                if (c == i) { D[i] = a; if (!(a > 0.0)) bad = true; }
-                else L[i * NP + c] = a / D[c];
+            for (int e = 0; e < NP * (NP + 1) / 2; e++) {
+                const double v = sum8_d(Mloc[e]);
+                if (spot_ok && j == (e & 7)) fo[e] = v;
             }
-        }
-        double Li[36];
+            const float ll = sum8(ll_loc);
+            if (spot_ok && j == 0) {
+                float *to = p.thetas + sidx * 6;
 #pragma unroll
-        for (int i = 0; i < NP; i++)
-#pragma unroll
-            for (int c = 0; c < NP; c++) Li[i * NP + c] = (i == c) ? 1.0 : 0.0;
-#pragma unroll
-        for (int c = 0; c < NP; c++)
-#pragma unroll
-            for (int i = c + 1; i < NP; i++) {
-                double a = 0.0;
-#pragma unroll
-                for (int k = c; k < i; k++) a -= L[i * NP + k] * Li[k * NP + c];
-                Li[i * NP + c] = a;
-            }
-        double trInv = 0.0;
-#pragma unroll
-        for (int i = 0; i < NP; i++) {
-            double a = 0.0;
-#pragma unroll
-            for (int k = i; k < NP; k++) a += Li[k * NP + i] * Li[k * NP + i] / D[k];
-            diag[i] = a;
-            trInv += a;
-        }
-        if (!(trM * trInv < 1e12)) bad = true;
-
-        if (spot_ok && j == 0) {
-            float *to = p.thetas + sidx * 6, *co = p.crlbs + sidx * 6;
-#pragma unroll
-            for (int l = 0; l < 5; l++) to[l] = th[l];
-            to[5] = NP == 6 ? th[5] : th[4];
-#pragma unroll
-            for (int l = 0; l < NP; l++) co[l] = (float)diag[l];
-            if (NP == 5) co[5] = (float)diag[4];
-            p.loglik[sidx] = ll;
-            p.iterations[sidx] = kk;
-            if (bad) {
-                int slot = atomicAdd(p.fallback_count, 1);
-                if (slot < p.fallback_cap) {
-                    p.fallback_idx[slot] = (int)sidx;
-                    double *Mo = p.fallback_M + (size_t)slot * 36;
-                    for (int e = 0; e < NP * NP; e++) Mo[e] = M[e];
-                }
+                for (int l = 0; l < 5; l++) to[l] = th[l];
+                to[5] = NP == 6 ? th[5] : th[4];
+                p.loglik[sidx] = ll;
+                p.iterations[sidx] = kk;
             }
         }
     }
@@ -419,7 +372,7 @@ static void launch_g8_box(int box, dim3 grid, hipStream_t s, const FitParams &p)
 bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, hipStream_t s)
 {
     if (p.box > 7) return false;
-    const int64_t waves = (p.N + 7) / 8;
+    const int64_t waves = (p.N - p.first + 7) / 8;
     const int64_t blocks = std::min<int64_t>((waves + FIT_WAVES - 1) / FIT_WAVES, (int64_t)cu_count * 8);
     dim3 grid((unsigned)std::max<int64_t>(blocks, 1));
     if (method == PMI_MLE_SIGMAXY) {

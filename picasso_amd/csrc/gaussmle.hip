@@ -374,7 +374,7 @@ static void launch_fit_ppl(int ppl, dim3 grid, hipStream_t s, const FitParams &p
 
 static int g_cu_count = 0;
 
-bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, hipStream_t s);   // gaussmle_g8.hip
+bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, float *state, hipStream_t s);   // gaussmle_g8.hip
 
 int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
 {
@@ -396,7 +396,10 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     void *ptr = nullptr, *fptr = nullptr;
     int rc;
     if ((rc = scratch(SCR_FIT, (size_t)nb * 8 + 64, &ptr)) != PMI_OK) return rc;
-    if ((rc = scratch(SCR_STAGE_D, (size_t)std::min<int64_t>(p.N, BATCH) * FISHER_STRIDE * sizeof(double), &fptr)) != PMI_OK) return rc;
+    // per spot of a batch: 21 doubles of Fisher triangle + 12 floats of Newton start state
+    const size_t per_batch = (size_t)std::min<int64_t>(p.N, BATCH);
+    if ((rc = scratch(SCR_STAGE_D, per_batch * (FISHER_STRIDE * sizeof(double) + 12 * sizeof(float)), &fptr)) != PMI_OK) return rc;
+    float *state = reinterpret_cast<float *>((char *)fptr + per_batch * FISHER_STRIDE * sizeof(double));
     PMI_HIP(hipMemsetAsync(ptr, 0, (size_t)nb * 8, s));
     p.fisher = (double *)fptr;
     const int ppl = (p.box * p.box + 63) / 64;
@@ -409,7 +412,7 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         p.queue = (unsigned long long *)ptr + bi;
         const int64_t count = p.N - p.first;
         // boxes <= 7: eight spots per wavefront (gaussmle_g8.hip); larger boxes: one wavefront per spot
-        if (!force_wave_per_spot && launch_fit_g8(p, method, from_movie, g_cu_count, s)) {
+        if (!force_wave_per_spot && launch_fit_g8(p, method, from_movie, g_cu_count, state, s)) {
         } else {
             int64_t blocks = std::min<int64_t>((count + FIT_WAVES - 1) / FIT_WAVES, (int64_t)g_cu_count * 8);
             dim3 grid((unsigned)std::max<int64_t>(blocks, 1));

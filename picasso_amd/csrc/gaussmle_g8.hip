@@ -14,11 +14,13 @@
 //   * the model is separable, so each lane accumulates ten row-local sums over its B
 //     pixels and multiplies by its row constants once; 12 group reductions of three
 //     DPP steps (quad_perm, quad_perm, row_half_mirror) serve 8 spots at once;
-//   * Newton state is uniform inside a group; converged groups idle until the slowest
-//     of the eight finishes.
+//   * three kernels: g8_init (initial theta and max_step per spot), g8_iterate (persistent
+//     waves; a group that converges stores its theta and immediately REFILLS with the next
+//     spot of its wave's chunk, so the eight groups never wait for the slowest spot — the
+//     iteration count per spot ranges 3..100), g8_final (Fisher matrix, log-likelihood);
+//     the 6x6 inverse runs one thread per spot in crlb_kernel (gaussmle.hip).
 //
-// Float32 Newton loop, float64 initial sums / Fisher matrix / LDL^T, like the
-// wave-per-spot kernel.
+// Float32 Newton loop, float64 initial sums and Fisher matrix, like the wave-per-spot kernel.
 #include <algorithm>
 
 #include "fit_common.h"
@@ -104,281 +106,382 @@ __device__ __forceinline__ BTerms boundary_terms(float jf, float mu, float sigma
     return t;
 }
 
-template <int NP, int B, bool FROM_MOVIE>
-__global__ __launch_bounds__(FIT_NT) void mle_fit_g8_kernel(FitParams p)
+
+// ---- pieces shared by the three kernels ------------------------------------
+template <int B, bool FROM_MOVIE>
+__device__ __forceinline__ void load_row(const FitParams &p, int64_t sidx, int j, bool valid, float (&d)[B])
 {
-    // x terms of every column, per group: [wave][group][term][col]
-    __shared__ float s_x[FIT_WAVES][8][5][8];
+    constexpr int H = B / 2;
+#pragma unroll
+    for (int i = 0; i < B; i++) d[i] = 0.f;
+    if (valid) {
+        if (FROM_MOVIE) {
+            const int64_t fr = p.frame[sidx], yy = p.y[sidx], xx = p.x[sidx];
+            const int64_t o = (fr * p.Y + (yy - H + j)) * p.X + (xx - H);
+#pragma unroll
+            for (int i = 0; i < B; i++)      // localize.py:1112: float32 sub, mul, div in this order
+                d[i] = ((load_movie_px(p.movie, p.dtype, o + i) - p.baseline) * p.sensitivity) / p.gain;
+        } else {
+            const float *sp = p.spots + sidx * (B * B) + j * B;
+#pragma unroll
+            for (int i = 0; i < B; i++) d[i] = sp[i];
+        }
+    }
+}
+
+// One Newton iteration for the eight groups of a wave (gaussmle.py:745-884 / :533-670).
+// th is updated in place when `active`; returns whether the group is still iterating.
+template <int NP, int B>
+__device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6], const float (&ms)[6], float *xs,
+                                            int j, bool rowok, bool active, int &kk, double eps, int max_it)
+{
+    const float jf = (float)j;
+    const float sgy = NP == 6 ? th[5] : th[4];
+    const BTerms tx = boundary_terms(jf, th[0], th[4]);     // column j
+    const BTerms ty = boundary_terms(jf, th[1], sgy);       // row j
+    __builtin_amdgcn_wave_barrier();
+    xs[0 * 8 + j] = tx.E; xs[1 * 8 + j] = tx.A; xs[2 * 8 + j] = tx.A2; xs[3 * 8 + j] = tx.S; xs[4 * 8 + j] = tx.S2;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+
+    const float N_ = th[2], bg = th[3];
+    const float NEy = N_ * ty.E;
+    float a_cA = 0.f, a_cE = 0.f, a_c = 0.f, a_cS = 0.f, a_cA2 = 0.f, a_cS2 = 0.f;
+    float a_dA = 0.f, a_dE = 0.f, a_d = 0.f, a_dS = 0.f, a_dSE = 0.f;
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        const float Ex = xs[0 * 8 + i], Ax = xs[1 * 8 + i], A2x = xs[2 * 8 + i], Sx = xs[3 * 8 + i], S2x = xs[4 * 8 + i];
+        const float model = NEy * Ex + bg;
+        const float r = rcp_f32(model);
+        const float dr = d[i] * r;
+        const bool ok = model > 10e-3f;             // gaussmle.py:831: otherwise cf = df = 0
+        // plain fminf: a NaN can only enter through a NaN pixel, and then theta is NaN from g8_init on
+        const float cf = ok ? fminf(dr - 1.f, 10e4f) : 0.f;
+        const float df = ok ? fminf(dr * r, 10e4f) : 0.f;
+        a_cA += cf * Ax; a_cE += cf * Ex; a_c += cf; a_cS += cf * Sx; a_cA2 += cf * A2x; a_cS2 += cf * S2x;
+        a_dA += df * Ax * Ax; a_dE += df * Ex * Ex; a_d += df; a_dS += df * Sx * Sx;
+        if (NP == 5) a_dSE += df * Sx * Ex;
+    }
+    float num[6], den[6];
+    const float NAy = N_ * ty.A, NA2y = N_ * ty.A2, NSy = N_ * ty.S, NS2y = N_ * ty.S2;
+    num[0] = NEy * a_cA;              den[0] = NEy * a_cA2 - NEy * NEy * a_dA;
+    num[1] = NAy * a_cE;              den[1] = NA2y * a_cE - NAy * NAy * a_dE;
+    num[2] = ty.E * a_cE;             den[2] = -ty.E * ty.E * a_dE;
+    num[3] = a_c;                     den[3] = -a_d;
+    if (NP == 6) {
+        num[4] = NEy * a_cS;          den[4] = NEy * a_cS2 - NEy * NEy * a_dS;
+        num[5] = NSy * a_cE;          den[5] = NS2y * a_cE - NSy * NSy * a_dE;
+    } else {
+        // isotropic sigma: du = N (Ey Sx + Ex Sy); d2u keeps the reference's precedence quirk
+        num[4] = NEy * a_cS + NSy * a_cE;
+        den[4] = (NEy * a_cS2 + 2.f * ty.S * a_cS + ty.S2 * a_cE)
+                 - (NEy * NEy * a_dS + 2.f * NEy * NSy * a_dSE + NSy * NSy * a_dE);
+        num[5] = 0.f; den[5] = 0.f;
+    }
+    if (!rowok) {
+#pragma unroll
+        for (int l = 0; l < 6; l++) { num[l] = 0.f; den[l] = 0.f; }
+    }
+#pragma unroll
+    for (int l = 0; l < NP; l++) { num[l] = sum8(num[l]); den[l] = sum8(den[l]); }
+
+    float nt[6];
+#pragma unroll
+    for (int l = 0; l < 6; l++) nt[l] = th[l];
+    bool conv;
+    if (NP == 6) {                                  // gaussmle.py:860-884
+#pragma unroll
+        for (int l = 0; l < 6; l++) {
+            const float stepz = np_signf(num[l]) * ms[l];                 // zero denominator (gaussmle.py:873)
+            const float stepn = clip_np(num[l] * rcp_f32(den[l]), ms[l]);
+            nt[l] = th[l] - (den[l] == 0.0f ? stepz : stepn);
+        }
+        nt[2] = max_np(nt[2], 1.0f); nt[3] = max_np(nt[3], 0.01f);
+        nt[4] = max_np(nt[4], 0.01f); nt[5] = max_np(nt[5], 0.01f);
+        conv = ((double)fabsf(th[0] - nt[0]) < eps) && ((double)fabsf(th[1] - nt[1]) < eps) &&
+               ((double)fabsf(th[4] - nt[4]) < eps) && ((double)fabsf(th[5] - nt[5]) < eps);
+    } else {                                        // gaussmle.py:647-670
+#pragma unroll
+        for (int l = 0; l < 5; l++) {
+            const float stepz = np_signf(num[l] * ms[l]);                 // +-1, not +-max_step (gaussmle.py:658)
+            const float stepn = clip_np(num[l] * rcp_f32(den[l]), ms[l]);
+            nt[l] = th[l] - (den[l] == 0.0f ? stepz : stepn);
+        }
+        nt[2] = max_np(nt[2], 1.0f); nt[3] = max_np(nt[3], 0.01f);
+        nt[4] = max_np(nt[4], 0.01f); nt[4] = min_np(nt[4], (float)B);
+        conv = ((double)fabsf(th[0] - nt[0]) < eps) && ((double)fabsf(th[1] - nt[1]) < eps);
+    }
+    // the previous-iteration values the reference compares with ARE th (old_x = theta after every pass);
+    // finished groups keep their state (selects, no branch)
+#pragma unroll
+    for (int l = 0; l < 6; l++) th[l] = active ? nt[l] : th[l];
+    kk += active ? 1 : 0;
+    return active && !(conv || kk >= max_it);
+}
+
+// ---- kernel 1: initial parameters (gaussmle.py:28-168) ----------------------
+template <int NP, int B, bool FROM_MOVIE>
+__global__ __launch_bounds__(FIT_NT) void g8_init_kernel(FitParams p, float *__restrict__ state)
+{
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = lane >> 3, j = lane & 7;
     const bool rowok = j < B;
     constexpr int H = B / 2;
-    const float jf = (float)j;
     int64_t n = p.N;
     if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+    const int64_t sidx = p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * 8 + g;
+    const bool spot_ok = sidx < n;
+    if (__builtin_amdgcn_readfirstlane((int)(p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * 8 >= n))) return;
+
+    float d[B];
+    load_row<B, FROM_MOVIE>(p, sidx, j, spot_ok && rowok, d);
+
+    double ps = 0.0, px = 0.0;
+#pragma unroll
+    for (int i = 0; i < B; i++) { ps += (double)d[i]; px += (double)d[i] * (double)i; }
+    double sum = sum8_d(ps), sx_ = sum8_d(px), sy_ = sum8_d(ps * (double)j);
+    // 3x3 edge-clipped mean filter: row-local 3-column sums, then the rows above / below
+    float fmin_l = INFINITY;
+    {
+        double t3[B];
+#pragma unroll
+        for (int i = 0; i < B; i++) {
+            double a = (double)d[i];
+            if (i > 0) a = (double)d[i - 1] + a;
+            if (i + 1 < B) a += (double)d[i + 1];
+            t3[i] = a;
+        }
+        const bool up = j > 0, dn = j + 1 < B;
+        const int nrow = 1 + (up ? 1 : 0) + (dn ? 1 : 0);
+#pragma unroll
+        for (int i = 0; i < B; i++) {
+            const double a = from_prev_d(t3[i]), c = from_next_d(t3[i]);
+            double tot = t3[i];
+            if (up) tot = a + tot;
+            if (dn) tot += c;
+            const int ncol = 1 + (i > 0 ? 1 : 0) + (i + 1 < B ? 1 : 0);
+            const float filt = (float)(tot / (double)(nrow * ncol));
+            if (rowok) fmin_l = fminf(fmin_l, filt);
+        }
+    }
+    // np.min propagates NaN: a NaN pixel poisons the background (and through the sums everything else),
+    // so the iteration kernel needs no per-pixel NaN guards
+    const float bg0 = (sum != sum) ? (float)sum : min8(fmin_l);
+    double com_y, com_x;
+    if (sum <= 0.0) { sum = 0.01; com_y = (B - 1) / 2.0; com_x = (B - 1) / 2.0; }
+    else { com_y = sy_ / sum; com_x = sx_ / sum; }
+    double photons = sum - (double)(B * B) * (double)bg0;
+    photons = (photons != photons) ? photons : (photons > 1.0 ? photons : 1.0);
+    // second moments of (spot - bg) along the centre column (over rows) and centre row (over columns)
+    double a_sdy = 0.0, a_sy = 0.0, a_sdx = 0.0, a_sx = 0.0;
+    if (rowok) {
+        const float vm = d[H] - bg0;
+        a_sdy = (double)vm * (double)((j - H) * (j - H));
+        a_sy = (double)vm;
+        if (j == H) {
+#pragma unroll
+            for (int i = 0; i < B; i++) {
+                const float v2 = d[i] - bg0;
+                a_sdx += (double)v2 * (double)((i - H) * (i - H));
+                a_sx += (double)v2;
+            }
+        }
+    }
+    a_sdy = sum8_d(a_sdy); a_sy = sum8_d(a_sy); a_sdx = sum8_d(a_sdx); a_sx = sum8_d(a_sx);
+    double isy = sqrt(a_sdy / a_sy), isx = sqrt(a_sdx / a_sx);
+    if (!isfinite(isy)) isy = 0.01;
+    if (!isfinite(isx)) isx = 0.01;
+    if (isx == 0) isx = 0.01;
+    if (isy == 0) isy = 0.01;
+
+    float th[6], ms[6];
+    th[0] = (float)com_x; th[1] = (float)com_y; th[2] = (float)photons; th[3] = bg0;
+    if (NP == 6) { th[4] = (float)isx; th[5] = (float)isy; }
+    else { th[4] = (float)((isx + isy) / 2); th[5] = 0.f; }
+    ms[0] = th[4]; ms[1] = th[4];
+    ms[2] = (float)(0.1 * (double)th[2]); ms[3] = (float)(0.1 * (double)th[3]);
+    ms[4] = (float)(0.2 * (double)th[4]); ms[5] = (float)(0.2 * (double)th[5]);
+    if (spot_ok && j == 0) {
+        float4 *so = reinterpret_cast<float4 *>(state + (sidx - p.first) * 12);
+        so[0] = make_float4(th[0], th[1], th[2], th[3]);
+        so[1] = make_float4(th[4], th[5], ms[0], ms[1]);
+        so[2] = make_float4(ms[2], ms[3], ms[4], ms[5]);
+    }
+}
+
+// ---- kernel 2: Newton iterations, persistent waves with per-group refill ----
+template <int NP, int B, bool FROM_MOVIE>
+__global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const float *__restrict__ state)
+{
+    __shared__ float s_x[FIT_WAVES][8][5][8];       // x terms of every column: [wave][group][term][col]
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int g = lane >> 3, j = lane & 7;
+    const bool rowok = j < B;
+    int64_t n = p.N;
+    if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+    // static partition: every wave owns a contiguous chunk of the batch (no queue atomics in the loop)
+    const int64_t count = n - p.first;
+    if (count <= 0) return;
+    const int64_t total_waves = (int64_t)gridDim.x * FIT_WAVES;
+    const int64_t chunk = (count + total_waves - 1) / total_waves;
+    const int64_t wv = (int64_t)blockIdx.x * FIT_WAVES + __builtin_amdgcn_readfirstlane(wid);
+    int64_t next = p.first + wv * chunk;
+    const int64_t end = next + chunk < n ? next + chunk : n;
+    if (next >= end) return;
+
+    float *xs = &s_x[wid][g][0][0];
+    float d[B], th[6], ms[6];
+#pragma unroll
+    for (int i = 0; i < B; i++) d[i] = 1.f;
+#pragma unroll
+    for (int l = 0; l < 6; l++) { th[l] = 1.f; ms[l] = 1.f; }
+    int kk = 0;
+    int64_t sidx = -1;
+    bool active = false;
+    const unsigned long long below = (1ull << (lane & ~7)) - 1ull;     // lanes of lower groups
 
     for (;;) {
-        unsigned long long base = 0;
-        if (lane == 0) base = atomicAdd(p.queue, 8ull);
-        base = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(base >> 32)) << 32) |
-               (unsigned)__builtin_amdgcn_readfirstlane((int)(base & 0xffffffffu));
-        base += (unsigned long long)p.first;
-        if ((int64_t)base >= n) break;
-        const int64_t sidx = (int64_t)base + g;
-        const bool spot_ok = sidx < n;
-
-        // ---- load row j of the spot (photons) -------------------------------
-        float d[B];
-#pragma unroll
-        for (int i = 0; i < B; i++) d[i] = 0.f;
-        if (spot_ok && rowok) {
-            if (FROM_MOVIE) {
-                const int64_t fr = p.frame[sidx], yy = p.y[sidx], xx = p.x[sidx];
-                const int64_t o = (fr * p.Y + (yy - H + j)) * p.X + (xx - H);
-#pragma unroll
-                for (int i = 0; i < B; i++)      // localize.py:1112: float32 sub, mul, div in this order
-                    d[i] = ((load_movie_px(p.movie, p.dtype, o + i) - p.baseline) * p.sensitivity) / p.gain;
-            } else {
-                const float *sp = p.spots + sidx * (B * B) + j * B;
-#pragma unroll
-                for (int i = 0; i < B; i++) d[i] = sp[i];
-            }
-        }
-
-        // ---- initial parameters (gaussmle.py:28-139) -----------------------
-        double ps = 0.0, px = 0.0;
-#pragma unroll
-        for (int i = 0; i < B; i++) { ps += (double)d[i]; px += (double)d[i] * (double)i; }
-        double sum = sum8_d(ps), sx_ = sum8_d(px), sy_ = sum8_d(ps * (double)j);
-        // 3x3 edge-clipped mean filter: row-local 3-column sums, then the rows above / below
-        float fmin_l = INFINITY;
-        {
-            double t3[B];
-#pragma unroll
-            for (int i = 0; i < B; i++) {
-                double a = (double)d[i];
-                if (i > 0) a = (double)d[i - 1] + a;
-                if (i + 1 < B) a += (double)d[i + 1];
-                t3[i] = a;
-            }
-            const bool up = j > 0, dn = j + 1 < B;
-            const int nrow = 1 + (up ? 1 : 0) + (dn ? 1 : 0);
-#pragma unroll
-            for (int i = 0; i < B; i++) {
-                const double a = from_prev_d(t3[i]), c = from_next_d(t3[i]);
-                double tot = t3[i];
-                if (up) tot = a + tot;
-                if (dn) tot += c;
-                const int ncol = 1 + (i > 0 ? 1 : 0) + (i + 1 < B ? 1 : 0);
-                const float filt = (float)(tot / (double)(nrow * ncol));
-                if (rowok) fmin_l = fminf(fmin_l, filt);
-            }
-        }
-        const float bg0 = min8(fmin_l);
-        double com_y, com_x;
-        if (sum <= 0.0) { sum = 0.01; com_y = (B - 1) / 2.0; com_x = (B - 1) / 2.0; }
-        else { com_y = sy_ / sum; com_x = sx_ / sum; }
-        double photons = sum - (double)(B * B) * (double)bg0;
-        photons = (photons != photons) ? photons : (photons > 1.0 ? photons : 1.0);
-        // second moments of (spot - bg) along the centre column (over rows) and centre row (over columns)
-        double a_sdy = 0.0, a_sy = 0.0, a_sdx = 0.0, a_sx = 0.0;
-        if (rowok) {
-            const float vm = d[H] - bg0;
-            a_sdy = (double)vm * (double)((j - H) * (j - H));
-            a_sy = (double)vm;
-            if (j == H) {
-#pragma unroll
-                for (int i = 0; i < B; i++) {
-                    const float v2 = d[i] - bg0;
-                    a_sdx += (double)v2 * (double)((i - H) * (i - H));
-                    a_sx += (double)v2;
-                }
-            }
-        }
-        a_sdy = sum8_d(a_sdy); a_sy = sum8_d(a_sy); a_sdx = sum8_d(a_sdx); a_sx = sum8_d(a_sx);
-        double isy = sqrt(a_sdy / a_sy), isx = sqrt(a_sdx / a_sx);
-        if (!isfinite(isy)) isy = 0.01;
-        if (!isfinite(isx)) isx = 0.01;
-        if (isx == 0) isx = 0.01;
-        if (isy == 0) isy = 0.01;
-
-        float th[6];
-        th[0] = (float)com_x; th[1] = (float)com_y; th[2] = (float)photons; th[3] = bg0;
-        if (NP == 6) { th[4] = (float)isx; th[5] = (float)isy; }
-        else { th[4] = (float)((isx + isy) / 2); th[5] = 0.f; }
-        float ms[6];
-        ms[0] = th[4]; ms[1] = th[4];
-        ms[2] = (float)(0.1 * (double)th[2]); ms[3] = (float)(0.1 * (double)th[3]);
-        ms[4] = (float)(0.2 * (double)th[4]); ms[5] = (float)(0.2 * (double)th[5]);
-
-        float old_x = th[0], old_y = th[1], old_sx = th[4], old_sy = th[5];
-        int kk = 0;
-        bool active = spot_ok && p.max_it > 0;
-        float *xs = &s_x[wid][g][0][0];
-
-        while (__any(active)) {
-            const float sgy = NP == 6 ? th[5] : th[4];
-            const BTerms tx = boundary_terms(jf, th[0], th[4]);     // column j
-            const BTerms ty = boundary_terms(jf, th[1], sgy);       // row j
-            __builtin_amdgcn_wave_barrier();
-            xs[0 * 8 + j] = tx.E; xs[1 * 8 + j] = tx.A; xs[2 * 8 + j] = tx.A2; xs[3 * 8 + j] = tx.S; xs[4 * 8 + j] = tx.S2;
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-
-            const float N_ = th[2], bg = th[3];
-            const float NEy = N_ * ty.E;
-            float a_cA = 0.f, a_cE = 0.f, a_c = 0.f, a_cS = 0.f, a_cA2 = 0.f, a_cS2 = 0.f;
-            float a_dA = 0.f, a_dE = 0.f, a_d = 0.f, a_dS = 0.f, a_dSE = 0.f;
-#pragma unroll
-            for (int i = 0; i < B; i++) {
-                const float Ex = xs[0 * 8 + i], Ax = xs[1 * 8 + i], A2x = xs[2 * 8 + i], Sx = xs[3 * 8 + i], S2x = xs[4 * 8 + i];
-                const float model = NEy * Ex + bg;
-                const float r = rcp_f32(model);
-                const float dr = d[i] * r;
-                const bool ok = model > 10e-3f;             // gaussmle.py:831: otherwise cf = df = 0
-                const float cf = ok ? min_np(dr - 1.f, 10e4f) : 0.f;
-                const float df = ok ? min_np(dr * r, 10e4f) : 0.f;
-                a_cA += cf * Ax; a_cE += cf * Ex; a_c += cf; a_cS += cf * Sx; a_cA2 += cf * A2x; a_cS2 += cf * S2x;
-                a_dA += df * Ax * Ax; a_dE += df * Ex * Ex; a_d += df; a_dS += df * Sx * Sx;
-                if (NP == 5) a_dSE += df * Sx * Ex;
-            }
-            float num[6], den[6];
-            const float NAy = N_ * ty.A, NA2y = N_ * ty.A2, NSy = N_ * ty.S, NS2y = N_ * ty.S2;
-            num[0] = NEy * a_cA;              den[0] = NEy * a_cA2 - NEy * NEy * a_dA;
-            num[1] = NAy * a_cE;              den[1] = NA2y * a_cE - NAy * NAy * a_dE;
-            num[2] = ty.E * a_cE;             den[2] = -ty.E * ty.E * a_dE;
-            num[3] = a_c;                     den[3] = -a_d;
-            if (NP == 6) {
-                num[4] = NEy * a_cS;          den[4] = NEy * a_cS2 - NEy * NEy * a_dS;
-                num[5] = NSy * a_cE;          den[5] = NS2y * a_cE - NSy * NSy * a_dE;
-            } else {
-                // isotropic sigma: du = N (Ey Sx + Ex Sy); d2u keeps the reference's precedence quirk
-                num[4] = NEy * a_cS + NSy * a_cE;
-                den[4] = (NEy * a_cS2 + 2.f * ty.S * a_cS + ty.S2 * a_cE)
-                         - (NEy * NEy * a_dS + 2.f * NEy * NSy * a_dSE + NSy * NSy * a_dE);
-                num[5] = 0.f; den[5] = 0.f;
-            }
-            if (!rowok) {
-#pragma unroll
-                for (int l = 0; l < 6; l++) { num[l] = 0.f; den[l] = 0.f; }
-            }
-#pragma unroll
-            for (int l = 0; l < NP; l++) { num[l] = sum8(num[l]); den[l] = sum8(den[l]); }
-
-            float nt[6];
-#pragma unroll
-            for (int l = 0; l < 6; l++) nt[l] = th[l];
-            bool conv;
-            if (NP == 6) {                                  // gaussmle.py:860-884
-#pragma unroll
-                for (int l = 0; l < 6; l++) {
-                    const float stepz = np_signf(num[l]) * ms[l];                 // zero denominator (gaussmle.py:873)
-                    const float stepn = clip_np(num[l] * rcp_f32(den[l]), ms[l]);
-                    nt[l] = th[l] - (den[l] == 0.0f ? stepz : stepn);
-                }
-                nt[2] = max_np(nt[2], 1.0f); nt[3] = max_np(nt[3], 0.01f);
-                nt[4] = max_np(nt[4], 0.01f); nt[5] = max_np(nt[5], 0.01f);
-                conv = ((double)fabsf(old_x - nt[0]) < p.eps) && ((double)fabsf(old_y - nt[1]) < p.eps) &&
-                       ((double)fabsf(old_sx - nt[4]) < p.eps) && ((double)fabsf(old_sy - nt[5]) < p.eps);
-            } else {                                        // gaussmle.py:647-670
-#pragma unroll
-                for (int l = 0; l < 5; l++) {
-                    const float stepz = np_signf(num[l] * ms[l]);                 // +-1, not +-max_step (gaussmle.py:658)
-                    const float stepn = clip_np(num[l] * rcp_f32(den[l]), ms[l]);
-                    nt[l] = th[l] - (den[l] == 0.0f ? stepz : stepn);
-                }
-                nt[2] = max_np(nt[2], 1.0f); nt[3] = max_np(nt[3], 0.01f);
-                nt[4] = max_np(nt[4], 0.01f); nt[4] = min_np(nt[4], (float)B);
-                conv = ((double)fabsf(old_x - nt[0]) < p.eps) && ((double)fabsf(old_y - nt[1]) < p.eps);
-            }
-            // finished groups keep their state (selects, no branch)
-#pragma unroll
-            for (int l = 0; l < 6; l++) th[l] = active ? nt[l] : th[l];
-            kk += active ? 1 : 0;
-            old_x = th[0]; old_y = th[1]; old_sx = th[4]; old_sy = th[5];
-            active = active && !(conv || kk >= p.max_it);
-        }
-
-        // ---- Fisher matrix and log-likelihood (gaussmle.py:673-742, 887-954) ----
-        {
-            const float sgy = NP == 6 ? th[5] : th[4];
-            const BTerms tx = boundary_terms(jf, th[0], th[4]);
-            const BTerms ty = boundary_terms(jf, th[1], sgy);
-            __builtin_amdgcn_wave_barrier();
-            xs[0 * 8 + j] = tx.E; xs[1 * 8 + j] = tx.A; xs[3 * 8 + j] = tx.S;
-            __builtin_amdgcn_wave_barrier();
-            __threadfence_block();
-            double Mloc[21];
-#pragma unroll
-            for (int e = 0; e < 21; e++) Mloc[e] = 0.0;
-            float ll_loc = 0.f;
-            const float N_ = th[2];
-#pragma unroll
-            for (int i = 0; i < B; i++) {
-                const float Ex = xs[0 * 8 + i], Ax = xs[1 * 8 + i], Sx = xs[3 * 8 + i];
-                float du[6];
-                du[0] = N_ * ty.E * Ax;
-                du[1] = N_ * Ex * ty.A;
-                du[2] = Ex * ty.E;
-                du[3] = 1.f;
-                if (NP == 6) { du[4] = N_ * ty.E * Sx; du[5] = N_ * Ex * ty.S; }
-                else { du[4] = N_ * (ty.E * Sx + Ex * ty.S); du[5] = 0.f; }
-                const float model = N_ * Ex * ty.E + th[3];
-                if (rowok) {
-                    const double inv = 1.0 / (double)model;
-                    int e = 0;
-#pragma unroll
-                    for (int k = 0; k < NP; k++)
-#pragma unroll
-                        for (int l = k; l < NP; l++) { Mloc[e] += (double)(du[l] * du[k]) * inv; e++; }
-                    if (model > 0.f) {
-                        if (d[i] > 0.f) ll_loc += d[i] * __logf(model / d[i]) - (model - d[i]);
-                        else ll_loc += -model;
-                    }
-                }
-            }
-            // group sums; lane j stores entries j, j+8, j+16 of its spot's Fisher triangle
-            // (the 6x6 inverse runs in crlb_kernel, one thread per spot, not 8-fold redundantly here)
-            double *fo = p.fisher + (sidx - p.first) * FISHER_STRIDE;
-#pragma unroll
-            for (int e = 0; e < NP * (NP + 1) / 2; e++) {
-                const double v = sum8_d(Mloc[e]);
-                if (spot_ok && j == (e & 7)) fo[e] = v;
-            }
-            const float ll = sum8(ll_loc);
-            if (spot_ok && j == 0) {
+        if (__any(!active)) {
+            // finished groups publish theta / iteration count, then take the next spots of the chunk
+            if (!active && sidx >= 0 && j == 0) {
                 float *to = p.thetas + sidx * 6;
 #pragma unroll
                 for (int l = 0; l < 5; l++) to[l] = th[l];
                 to[5] = NP == 6 ? th[5] : th[4];
-                p.loglik[sidx] = ll;
                 p.iterations[sidx] = kk;
+            }
+            const unsigned long long want = __ballot(!active && j == 0);
+            const int64_t cand = next + __popcll(want & below);
+            if (!active) {
+                sidx = -1;
+                if (cand < end) {
+                    sidx = cand;
+                    const float4 *si = reinterpret_cast<const float4 *>(state + (sidx - p.first) * 12);
+                    const float4 s0 = si[0], s1 = si[1], s2 = si[2];
+                    th[0] = s0.x; th[1] = s0.y; th[2] = s0.z; th[3] = s0.w; th[4] = s1.x; th[5] = s1.y;
+                    ms[0] = s1.z; ms[1] = s1.w; ms[2] = s2.x; ms[3] = s2.y; ms[4] = s2.z; ms[5] = s2.w;
+                    load_row<B, FROM_MOVIE>(p, sidx, j, rowok, d);
+                    kk = 0;
+                    active = p.max_it > 0;
+                    if (!active && j == 0) {          // max_it == 0: the initial theta is the result
+                        float *to = p.thetas + sidx * 6;
+#pragma unroll
+                        for (int l = 0; l < 5; l++) to[l] = th[l];
+                        to[5] = NP == 6 ? th[5] : th[4];
+                        p.iterations[sidx] = 0;
+                        sidx = -1;
+                    }
+                }
+            }
+            next += __popcll(want);
+            if (!__any(active)) {
+                if (next >= end) break;
+                continue;
+            }
+        }
+        active = newton_step<NP, B>(d, th, ms, xs, j, rowok, active, kk, p.eps, p.max_it);
+    }
+}
+
+// ---- kernel 3: Fisher matrix and log-likelihood (gaussmle.py:673-742, 887-954)
+template <int NP, int B, bool FROM_MOVIE>
+__global__ __launch_bounds__(FIT_NT) void g8_final_kernel(FitParams p)
+{
+    __shared__ float s_x[FIT_WAVES][8][3][8];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int g = lane >> 3, j = lane & 7;
+    const bool rowok = j < B;
+    const float jf = (float)j;
+    int64_t n = p.N;
+    if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+    const int64_t sidx = p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * 8 + g;
+    const bool spot_ok = sidx < n;
+    if (__builtin_amdgcn_readfirstlane((int)(p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * 8 >= n))) return;
+
+    float d[B], th[6];
+    load_row<B, FROM_MOVIE>(p, sidx, j, spot_ok && rowok, d);
+#pragma unroll
+    for (int l = 0; l < 6; l++) th[l] = spot_ok ? p.thetas[sidx * 6 + l] : 1.f;
+    float *xs = &s_x[wid][g][0][0];
+    const float sgy = NP == 6 ? th[5] : th[4];
+    const BTerms tx = boundary_terms(jf, th[0], th[4]);
+    const BTerms ty = boundary_terms(jf, th[1], sgy);
+    xs[0 * 8 + j] = tx.E; xs[1 * 8 + j] = tx.A; xs[2 * 8 + j] = tx.S;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    double Mloc[21];
+#pragma unroll
+    for (int e = 0; e < 21; e++) Mloc[e] = 0.0;
+    float ll_loc = 0.f;
+    const float N_ = th[2];
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        const float Ex = xs[0 * 8 + i], Ax = xs[1 * 8 + i], Sx = xs[2 * 8 + i];
+        float du[6];
+        du[0] = N_ * ty.E * Ax;
+        du[1] = N_ * Ex * ty.A;
+        du[2] = Ex * ty.E;
+        du[3] = 1.f;
+        if (NP == 6) { du[4] = N_ * ty.E * Sx; du[5] = N_ * Ex * ty.S; }
+        else { du[4] = N_ * (ty.E * Sx + Ex * ty.S); du[5] = 0.f; }
+        const float model = N_ * Ex * ty.E + th[3];
+        if (rowok) {
+            const double inv = 1.0 / (double)model;
+            int e = 0;
+#pragma unroll
+            for (int k = 0; k < NP; k++)
+#pragma unroll
+                for (int l = k; l < NP; l++) { Mloc[e] += (double)(du[l] * du[k]) * inv; e++; }
+            if (model > 0.f) {
+                if (d[i] > 0.f) ll_loc += d[i] * __logf(model / d[i]) - (model - d[i]);
+                else ll_loc += -model;
             }
         }
     }
+    // group sums; lane j stores entries j, j+8, j+16 of its spot's Fisher triangle
+    double *fo = p.fisher + (sidx - p.first) * FISHER_STRIDE;
+#pragma unroll
+    for (int e = 0; e < NP * (NP + 1) / 2; e++) {
+        const double v = sum8_d(Mloc[e]);
+        if (spot_ok && j == (e & 7)) fo[e] = v;
+    }
+    const float ll = sum8(ll_loc);
+    if (spot_ok && j == 0) p.loglik[sidx] = ll;
+}
+
+template <int NP, int B, bool FROM_MOVIE>
+static void launch_g8(const FitParams &p, float *state, int cu_count, hipStream_t s)
+{
+    const int64_t count = p.N - p.first;
+    const int64_t waves = (count + 7) / 8;
+    const dim3 flat((unsigned)((waves + FIT_WAVES - 1) / FIT_WAVES));
+    // persistent iterate grid: 6 workgroups (24 waves, 73 VGPRs each) per CU, each wave owning >= 64 spots when possible
+    const int64_t pw = std::max<int64_t>(1, std::min<int64_t>((int64_t)cu_count * 24, (count + 63) / 64));
+    const dim3 pers((unsigned)((pw + FIT_WAVES - 1) / FIT_WAVES));
+    hipLaunchKernelGGL((g8_init_kernel<NP, B, FROM_MOVIE>), flat, dim3(FIT_NT), 0, s, p, state);
+    hipLaunchKernelGGL((g8_iterate_kernel<NP, B, FROM_MOVIE>), pers, dim3(FIT_NT), 0, s, p, (const float *)state);
+    hipLaunchKernelGGL((g8_final_kernel<NP, B, FROM_MOVIE>), flat, dim3(FIT_NT), 0, s, p);
 }
 
 template <int NP, bool FROM_MOVIE>
-static void launch_g8_box(int box, dim3 grid, hipStream_t s, const FitParams &p)
+static void launch_g8_box(const FitParams &p, float *state, int cu_count, hipStream_t s)
 {
-    switch (box) {
-    case 3: hipLaunchKernelGGL((mle_fit_g8_kernel<NP, 3, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
-    case 5: hipLaunchKernelGGL((mle_fit_g8_kernel<NP, 5, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
-    default: hipLaunchKernelGGL((mle_fit_g8_kernel<NP, 7, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
+    switch (p.box) {
+    case 3: launch_g8<NP, 3, FROM_MOVIE>(p, state, cu_count, s); break;
+    case 5: launch_g8<NP, 5, FROM_MOVIE>(p, state, cu_count, s); break;
+    default: launch_g8<NP, 7, FROM_MOVIE>(p, state, cu_count, s); break;
     }
 }
 
-// boxes 3, 5, 7: eight spots per wavefront.  Returns false when the box is not handled.
-bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, hipStream_t s)
+// boxes 3, 5, 7: eight spots per wavefront.  `state` = 12 floats per spot of the batch.
+// Returns false when the box is not handled.
+bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, float *state, hipStream_t s)
 {
     if (p.box > 7) return false;
-    const int64_t waves = (p.N - p.first + 7) / 8;
-    const int64_t blocks = std::min<int64_t>((waves + FIT_WAVES - 1) / FIT_WAVES, (int64_t)cu_count * 8);
-    dim3 grid((unsigned)std::max<int64_t>(blocks, 1));
     if (method == PMI_MLE_SIGMAXY) {
-        if (from_movie) launch_g8_box<6, true>(p.box, grid, s, p); else launch_g8_box<6, false>(p.box, grid, s, p);
+        if (from_movie) launch_g8_box<6, true>(p, state, cu_count, s); else launch_g8_box<6, false>(p, state, cu_count, s);
     } else {
-        if (from_movie) launch_g8_box<5, true>(p.box, grid, s, p); else launch_g8_box<5, false>(p.box, grid, s, p);
+        if (from_movie) launch_g8_box<5, true>(p, state, cu_count, s); else launch_g8_box<5, false>(p, state, cu_count, s);
     }
     return true;
 }

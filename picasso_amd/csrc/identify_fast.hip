@@ -5,9 +5,10 @@
 // _local_maxima, :202-244 _net_gradient, :288 threshold); only the schedule differs:
 //
 //   * one wavefront owns a band of RB rows x 512 columns of one frame; lane l holds
-//     8 consecutive pixels of the current row as four packed u16x2 registers plus
-//     4 pixels of each neighbour chunk (one 16-byte and two 8-byte global loads per
-//     row, the neighbour loads are L1/L2 hits);
+//     8 consecutive pixels of the current row as four packed u16x2 registers (one
+//     16-byte global load per row) plus the 4 pixels on either side, taken from the
+//     neighbouring lanes' registers by DPP wave_shr/wave_shl (lanes 0 and 63 load
+//     theirs with one masked 8-byte load);
 //   * horizontal: L = max of the h pixels left of each pixel, R = max of the h to
 //     the right, Hrow = max(L, v, R), all as v_pk_max_u16 on aligned/odd pixel pairs
 //     (odd pairs by v_alignbit);
@@ -110,7 +111,11 @@ struct LR {
     }
 };
 
-struct RowRegs { uint4 m; uint2 l, r; };
+struct RowRegs { uint4 m; uint2 e; };   // 8 own pixels + (lanes 0 / 63 only) the 4 pixels beyond the wave's edge
+
+// value of lane-1 / lane+1 across the whole wavefront; `edge` is returned where no such lane exists
+__device__ __forceinline__ u32 from_lane_below(u32 v, u32 edge) { return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
+__device__ __forceinline__ u32 from_lane_above(u32 v, u32 edge) { return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
 
 // Exact float32 net gradient of one candidate whose stencil does not wrap, in the reference's
 // (k, l) order, from a sliding three-row register window (each pixel is loaded once).
@@ -207,7 +212,12 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
 
     // per-lane byte offsets inside a row (32-bit) + a wave-uniform row base: the loads use
     // SGPR-base + VGPR-offset addressing, no 64-bit vector address arithmetic per row
-    const unsigned off_m = (unsigned)col_m * 2u, off_l = (unsigned)col_l * 2u, off_r = (unsigned)col_r * 2u;
+    // Neighbour pixels come from the adjacent lanes' registers (DPP), not from memory: overlapping
+    // 8-byte loads next to the 16-byte ones doubled the HBM-side traffic (requests to a line whose
+    // fill is still in flight are not merged).  Only lanes 0 and 63 load the 4 pixels beyond the wave.
+    const unsigned off_m = (unsigned)col_m * 2u;
+    const unsigned off_e = (unsigned)(lane == 0 ? col_l : col_r) * 2u;
+    const bool edge_lane = lane == 0 || lane == 63;
     const char *frame_base = reinterpret_cast<const char *>(src);
     const int64_t pitch = p.X * 2;
     // interior bands never touch a row outside the crop: no clamping in their row loop
@@ -217,8 +227,8 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
         const char *row = frame_base + (int64_t)rc * pitch;
         RowRegs o;
         o.m = *reinterpret_cast<const uint4 *>(row + off_m);
-        o.l = *reinterpret_cast<const uint2 *>(row + off_l);
-        o.r = *reinterpret_cast<const uint2 *>(row + off_r);
+        o.e = make_uint2(0u, 0u);
+        if (edge_lane) o.e = *reinterpret_cast<const uint2 *>(row + off_e);
         return o;
     };
 
@@ -244,7 +254,8 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
             const int st = sb + u;                    // pipeline step; row r = rs0 + st
             const RowRegs cur = pf[u % D];
             pf[u % D] = load_row(rs0 + st + D);
-            u32 A[8] = {cur.l.x, cur.l.y, cur.m.x, cur.m.y, cur.m.z, cur.m.w, cur.r.x, cur.r.y};
+            u32 A[8] = {from_lane_below(cur.m.z, cur.e.x), from_lane_below(cur.m.w, cur.e.y), cur.m.x, cur.m.y, cur.m.z, cur.m.w,
+                        from_lane_above(cur.m.x, cur.e.x), from_lane_above(cur.m.y, cur.e.y)};
             u32 Bp[8];
             Bp[0] = 0;
 #pragma unroll

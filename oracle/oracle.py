@@ -91,7 +91,7 @@ def identify(movie, min_ng, box, roi=None, frame_bounds=None, threads=1):
     code = DTYPE_CODES[movie.dtype]
     r = normalise_roi(roi, Y, X)
     lo, hi = frame_range(frame_bounds, F)
-    cap = max(1024, F * 64)
+    cap = max(1024, F * 512)
     while True:
         fr = np.empty(cap, np.int64); yy = np.empty(cap, np.int64)
         xx = np.empty(cap, np.int64); ng = np.empty(cap, np.float32)

@@ -118,9 +118,19 @@ __device__ __forceinline__ void load_row(const FitParams &p, int64_t sidx, int j
         if (FROM_MOVIE) {
             const int64_t fr = p.frame[sidx], yy = p.y[sidx], xx = p.x[sidx];
             const int64_t o = (fr * p.Y + (yy - H + j)) * p.X + (xx - H);
+            float raw[B];
+            // one switch per row, not per pixel: the B loads of a row issue back to back
+            switch (p.dtype) {
+            case PMI_U16: { const uint16_t *q = (const uint16_t *)p.movie + o; _Pragma("unroll") for (int i = 0; i < B; i++) raw[i] = (float)q[i]; } break;
+            case PMI_U8:  { const uint8_t *q = (const uint8_t *)p.movie + o;   _Pragma("unroll") for (int i = 0; i < B; i++) raw[i] = (float)q[i]; } break;
+            case PMI_I16: { const int16_t *q = (const int16_t *)p.movie + o;   _Pragma("unroll") for (int i = 0; i < B; i++) raw[i] = (float)q[i]; } break;
+            case PMI_U32: { const uint32_t *q = (const uint32_t *)p.movie + o; _Pragma("unroll") for (int i = 0; i < B; i++) raw[i] = (float)q[i]; } break;
+            case PMI_I32: { const int32_t *q = (const int32_t *)p.movie + o;   _Pragma("unroll") for (int i = 0; i < B; i++) raw[i] = (float)q[i]; } break;
+            default:      { const float *q = (const float *)p.movie + o;       _Pragma("unroll") for (int i = 0; i < B; i++) raw[i] = q[i]; } break;
+            }
 #pragma unroll
             for (int i = 0; i < B; i++)      // localize.py:1112: float32 sub, mul, div in this order
-                d[i] = ((load_movie_px(p.movie, p.dtype, o + i) - p.baseline) * p.sensitivity) / p.gain;
+                d[i] = ((raw[i] - p.baseline) * p.sensitivity) / p.gain;
         } else {
             const float *sp = p.spots + sidx * (B * B) + j * B;
 #pragma unroll
@@ -253,14 +263,22 @@ __global__ __launch_bounds__(FIT_NT) void g8_init_kernel(FitParams p, float *__r
         }
         const bool up = j > 0, dn = j + 1 < B;
         const int nrow = 1 + (up ? 1 : 0) + (dn ? 1 : 0);
+        // window sizes are nrow*2 (first / last column) or nrow*3: two reciprocals per lane, and
+        // q = t*r corrected by one FMA residual step (= the correctly rounded quotient up to the
+        // rare double-rounding case; the value is rounded to float32 right after)
+        const double n2 = (double)(nrow * 2), n3 = (double)(nrow * 3);
+        const double r2 = 1.0 / n2, r3 = 1.0 / n3;
 #pragma unroll
         for (int i = 0; i < B; i++) {
             const double a = from_prev_d(t3[i]), c = from_next_d(t3[i]);
             double tot = t3[i];
             if (up) tot = a + tot;
             if (dn) tot += c;
-            const int ncol = 1 + (i > 0 ? 1 : 0) + (i + 1 < B ? 1 : 0);
-            const float filt = (float)(tot / (double)(nrow * ncol));
+            const bool edge = (i == 0) || (i + 1 == B);
+            const double nn = edge ? n2 : n3, rr = edge ? r2 : r3;
+            double q = tot * rr;
+            q = fma(fma(-q, nn, tot), rr, q);
+            const float filt = (float)q;
             if (rowok) fmin_l = fminf(fmin_l, filt);
         }
     }
@@ -426,7 +444,10 @@ __global__ __launch_bounds__(FIT_NT) void g8_final_kernel(FitParams p)
         else { du[4] = N_ * (ty.E * Sx + Ex * ty.S); du[5] = 0.f; }
         const float model = N_ * Ex * ty.E + th[3];
         if (rowok) {
-            const double inv = 1.0 / (double)model;
+            const double md = (double)model;
+            double inv = (double)rcp_f32(model);
+            inv = inv * (2.0 - md * inv);                       // ~1e-14 relative: one Newton step on a 1-ulp float seed
+            inv = inv * (2.0 - md * inv);
             int e = 0;
 #pragma unroll
             for (int k = 0; k < NP; k++)

@@ -25,6 +25,8 @@
  *   pmi_gaussmle*      picasso/gaussmle.py:409-475 gaussmle / :478-530
  *                      gaussmle_async (-> :533-742 sigma, :745-954 sigmaxy)
  *   pmi_locs_from_fits_dev  picasso/gaussmle.py:957-1037 locs_from_fits
+ *   pmi_zfit*          picasso/zfit.py:327-382 _fit_z (per-localization loop)
+ *   pmi_avgroi*        picasso/avgroi.py:45-65 fit_spots
  *   pmi_localize_mle_dev    picasso/localize.py:1682-1815 localize with
  *                      fitting_method="gaussmle" (identify -> get_spots -> fit
  *                      -> table) as one asynchronous device pipeline
@@ -141,6 +143,22 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
                          double baseline, double sensitivity, double gain,
                          double eps, int max_it, int method,
                          void *d_table, int64_t cap, int64_t *d_out_n, void *stream);
+
+/* ---- zfit (picasso/zfit.py:254-291, 327-382) ---------------------------- *
+ * Per localization: argmin over z in [-1000, 1000] of
+ * (sqrt(sx) - sqrt(wx(z)))^2 + (sqrt(sy) - sqrt(wy(z)))^2, wx/wy degree-6
+ * polynomials (cx7/cy7, highest power first), by the bounded Brent minimiser of
+ * scipy.optimize.minimize_scalar (xatol 1e-5, maxiter 500).  Outputs are float64:
+ * z before the magnification factor and the squared residual (d_zcalib^2).   */
+int pmi_zfit(const float *sx, const float *sy, int64_t N, const double *cx7, const double *cy7,
+             double *z, double *sq_residual);
+int pmi_zfit_dev(const float *d_sx, const float *d_sy, int64_t N, const int64_t *d_n, const double *cx7,
+                 const double *cy7, double *d_z, double *d_sq_residual, void *stream);
+
+/* ---- avg (picasso/avgroi.py:24-65) -------------------------------------- *
+ * theta (N,6) = [0, 0, sum, sum, 1, 1] with a float64 ROI sum.               */
+int pmi_avgroi(const float *spots, int64_t N, int box, float *theta);
+int pmi_avgroi_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box, float *d_theta, void *stream);
 
 /* ---- timing hooks for bench.py (HIP events on the given stream) ------- */
 int pmi_event_create(void **event);

@@ -50,6 +50,8 @@ def lib():
         L.orc_initial_parameters.argtypes = [p, i64, i32, p]
         L.orc_initial_parameters.restype = i32
         L.orc_unit_vectors.argtypes = [i32, p, p]
+        L.orc_avgroi.argtypes = [p, i64, i32, p]
+        L.orc_zfit.argtypes = [p, p, i64, p, p, p, p, i32]
         L.orc_max_threads.restype = i32
         _lib = L
     return _lib
@@ -150,3 +152,21 @@ def unit_vectors(box):
     ux = np.zeros((box, box), np.float32); uy = np.zeros((box, box), np.float32)
     lib().orc_unit_vectors(int(box), _ptr(ux), _ptr(uy))
     return ux, uy
+
+
+def avgroi(spots):
+    spots = np.ascontiguousarray(spots, np.float32)
+    N, box, _ = spots.shape
+    th = np.zeros((N, 6), np.float32)
+    lib().orc_avgroi(_ptr(spots), N, box, _ptr(th))
+    return th
+
+
+def zfit(sx, sy, cx, cy, threads=1):
+    """Bounded Brent per localization -> z (un-magnified) and squared residual, float64."""
+    sx = np.ascontiguousarray(sx, np.float32); sy = np.ascontiguousarray(sy, np.float32)
+    cx = np.ascontiguousarray(cx, np.float64); cy = np.ascontiguousarray(cy, np.float64)
+    N = len(sx)
+    z = np.zeros(N, np.float64); sq = np.zeros(N, np.float64)
+    lib().orc_zfit(_ptr(sx), _ptr(sy), N, _ptr(cx), _ptr(cy), _ptr(z), _ptr(sq), int(threads))
+    return z, sq

@@ -593,6 +593,118 @@ int orc_initial_parameters(const float *spots, int64_t N, int box, float *theta6
     return 0;
 }
 
+/* ------------------------------------------------------------------------
+ * avgroi  (picasso/avgroi.py:24-41): theta = [0, 0, sum, sum, 1, 1], float64 sum
+ * ---------------------------------------------------------------------- */
+int orc_avgroi(const float *spots, int64_t N, int box, float *theta6)
+{
+    for (int64_t i = 0; i < N; i++) {
+        double s = 0.0;
+        for (int k = 0; k < box * box; k++) s += (double)spots[i * box * box + k];
+        float *t = theta6 + i * 6;
+        t[0] = 0.f; t[1] = 0.f; t[2] = (float)s; t[3] = (float)s; t[4] = 1.f; t[5] = 1.f;
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------
+ * zfit  (picasso/zfit.py:254-291 _fit_z_target, :327-382 _fit_z)
+ * The minimiser is third-party: scipy.optimize.minimize_scalar(bounds=...),
+ * i.e. scipy/optimize/_optimize.py:_minimize_scalar_bounded (scipy 1.15.3,
+ * xatol 1e-5, maxiter 500) — Brent's golden-section / parabolic fminbound,
+ * restated here from its published algorithm; call site picasso/zfit.py:359-363.
+ * ---------------------------------------------------------------------- */
+static inline double zfit_target(double z, float sx, float sy, const double *cx, const double *cy)
+{
+    double z2 = z * z, z3 = z * z2, z4 = z * z3, z5 = z * z4, z6 = z * z5;
+    double wx = cx[0] * z6 + cx[1] * z5 + cx[2] * z4 + cx[3] * z3 + cx[4] * z2 + cx[5] * z + cx[6];
+    double wy = cy[0] * z6 + cy[1] * z5 + cy[2] * z4 + cy[3] * z3 + cy[4] * z2 + cy[5] * z + cy[6];
+    double ax = pow((double)sx, 0.5) - pow(wx, 0.5), ay = pow((double)sy, 0.5) - pow(wy, 0.5);
+    return ax * ax + ay * ay;
+}
+
+static inline double dsign(double v) { return (v > 0) - (v < 0); }
+
+static void fminbound(float sx, float sy, const double *cx, const double *cy, double x1, double x2,
+                      double xatol, int maxfun, double *xout, double *fout)
+{
+    const double sqrt_eps = sqrt(2.2e-16), golden_mean = 0.5 * (3.0 - sqrt(5.0));
+    double a = x1, b = x2;
+    double fulc = a + golden_mean * (b - a), nfc = fulc, xf = fulc;
+    double rat = 0.0, e = 0.0;
+    double x = xf, fx = zfit_target(x, sx, sy, cx, cy);
+    int num = 1;
+    double fu = INFINITY, ffulc = fx, fnfc = fx;
+    double xm = 0.5 * (a + b);
+    double tol1 = sqrt_eps * fabs(xf) + xatol / 3.0, tol2 = 2.0 * tol1;
+    while (fabs(xf - xm) > (tol2 - 0.5 * (b - a))) {
+        int golden = 1;
+        if (fabs(e) > tol1) {
+            golden = 0;
+            double r = (xf - nfc) * (fx - ffulc);
+            double q = (xf - fulc) * (fx - fnfc);
+            double p = (xf - fulc) * q - (xf - nfc) * r;
+            q = 2.0 * (q - r);
+            if (q > 0.0) p = -p;
+            q = fabs(q);
+            r = e;
+            e = rat;
+            if ((fabs(p) < fabs(0.5 * q * r)) && (p > q * (a - xf)) && (p < q * (b - xf))) {
+                rat = (p + 0.0) / q;
+                x = xf + rat;
+                if (((x - a) < tol2) || ((b - x) < tol2)) {
+                    double si = dsign(xm - xf) + ((xm - xf) == 0);
+                    rat = tol1 * si;
+                }
+            } else {
+                golden = 1;
+            }
+        }
+        if (golden) {
+            e = (xf >= xm) ? a - xf : b - xf;
+            rat = golden_mean * e;
+        }
+        double si = dsign(rat) + (rat == 0);
+        double ar = fabs(rat);
+        x = xf + si * ((ar != ar) ? ar : ((tol1 != tol1) ? tol1 : (ar > tol1 ? ar : tol1)));   /* np.maximum */
+        fu = zfit_target(x, sx, sy, cx, cy);
+        num++;
+        if (fu <= fx) {
+            if (x >= xf) a = xf; else b = xf;
+            fulc = nfc; ffulc = fnfc;
+            nfc = xf; fnfc = fx;
+            xf = x; fx = fu;
+        } else {
+            if (x < xf) a = x; else b = x;
+            if ((fu <= fnfc) || (nfc == xf)) {
+                fulc = nfc; ffulc = fnfc;
+                nfc = x; fnfc = fu;
+            } else if ((fu <= ffulc) || (fulc == xf) || (fulc == nfc)) {
+                fulc = x; ffulc = fu;
+            }
+        }
+        xm = 0.5 * (a + b);
+        tol1 = sqrt_eps * fabs(xf) + xatol / 3.0;
+        tol2 = 2.0 * tol1;
+        if (num >= maxfun) break;
+    }
+    *xout = xf;
+    *fout = fx;
+}
+
+/* z (before the magnification factor) and the squared calibration residual, float64 */
+int orc_zfit(const float *sx, const float *sy, int64_t N, const double *cx7, const double *cy7,
+             double *z, double *sqd, int nthreads)
+{
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(static) num_threads(nthreads)
+#endif
+    for (int64_t i = 0; i < N; i++)
+        fminbound(sx[i], sy[i], cx7, cy7, -1000.0, 1000.0, 1e-5, 500, z + i, sqd + i);
+    return 0;
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP

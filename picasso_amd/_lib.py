@@ -53,6 +53,10 @@ SYMBOLS = {
     "pmi_locs_from_fits_dev": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i32, _p, _p]),
     "pmi_localize_mle_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _f64, _f64, _f64,
                                     _f64, _i32, _i32, _p, _i64, _p, _p]),
+    "pmi_zfit": (_i32, [_p, _p, _i64, _p, _p, _p, _p]),
+    "pmi_zfit_dev": (_i32, [_p, _p, _i64, _p, _p, _p, _p, _p, _p]),
+    "pmi_avgroi": (_i32, [_p, _i64, _i32, _p]),
+    "pmi_avgroi_dev": (_i32, [_p, _i64, _p, _i32, _p, _p]),
     "pmi_event_create": (_i32, [_p]),
     "pmi_event_record": (_i32, [_p, _p]),
     "pmi_event_elapsed_ms": (_i32, [_p, _p, _p]),

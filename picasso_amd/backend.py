@@ -129,6 +129,36 @@ def gaussmle_arrays(spots: np.ndarray, eps: float, max_it: int, method: str = "s
     return thetas, crlbs, loglik, iterations
 
 
+def avgroi_array(spots: np.ndarray) -> np.ndarray:
+    _lib.require_gpu()
+    spots = np.ascontiguousarray(spots, np.float32)
+    N, box, _ = spots.shape
+    theta = np.empty((N, 6), np.float32)
+    theta.fill(np.nan)
+    with _lib.lock():
+        rc = _lib.load().pmi_avgroi(_lib.ptr(spots), N, int(box), _lib.ptr(theta))
+    _lib.check(rc, "pmi_avgroi")
+    return theta
+
+
+def zfit_arrays(sx, sy, cx, cy):
+    """-> z (before magnification) and squared calibration residual, float64."""
+    _lib.require_gpu()
+    sx = np.ascontiguousarray(sx, np.float32)
+    sy = np.ascontiguousarray(sy, np.float32)
+    cx = np.ascontiguousarray(cx, np.float64)
+    cy = np.ascontiguousarray(cy, np.float64)
+    if cx.shape != (7,) or cy.shape != (7,):
+        raise ValueError("calibration needs 7 coefficients per axis")
+    N = len(sx)
+    z = np.zeros(N, np.float64)
+    sq = np.zeros(N, np.float64)
+    with _lib.lock():
+        rc = _lib.load().pmi_zfit(_lib.ptr(sx), _lib.ptr(sy), N, _lib.ptr(cx), _lib.ptr(cy), _lib.ptr(z), _lib.ptr(sq))
+    _lib.check(rc, "pmi_zfit")
+    return z, sq
+
+
 class DeviceMovie:
     """A movie resident in HBM (pmi_malloc), for repeated calls without H2D."""
 

@@ -17,7 +17,7 @@ from typing import Callable, Literal
 import numpy as np
 import pandas as pd
 
-from . import __version__, backend, gaussmle
+from . import __version__, avgroi, backend, gaussmle
 
 _CHUNK_BYTES = 1 << 30      # movie bytes per device call = progress / abort granularity
 FITTING_METHODS = ["gausslq", "gausslq-gpu", "gaussmle", "avg"]
@@ -243,13 +243,20 @@ def fit2D(movie, movie_info, camera_info: dict, identifications: pd.DataFrame, b
                       "camera pixel size in nm. Assuming 130.")
         camera_info["Pixelsize"] = 130
 
-    if fitting_method != "gaussmle":
+    if fitting_method not in ("gaussmle", "avg"):
         raise NotImplementedError(
-            f"fitting_method={fitting_method!r} has no HIP kernel yet in picasso_amd (only 'gaussmle'); "
+            f"fitting_method={fitting_method!r} has no HIP kernel yet in picasso_amd (only 'gaussmle' and 'avg'); "
             "there is no CPU fallback — use the reference for this method")
     spots = get_spots(movie, identifications, box, camera_info)
-    locs = _fit2d_gaussmle(spots, identifications, box, eps, max_it, mle_method, multiprocess,
-                           progress_callback, abort_callback)
+    em = camera_info["Gain"] > 1
+    if fitting_method == "gaussmle":
+        locs = _fit2d_gaussmle(spots, identifications, box, eps, max_it, mle_method, multiprocess,
+                               progress_callback, abort_callback)
+    else:
+        if callable(abort_callback) and abort_callback():
+            locs = None
+        else:
+            locs = avgroi.locs_from_fits(identifications, avgroi.fit_spots(spots, progress_callback), box, em)
     localize_info = {"Generated by": f"Picasso: v{__version__} Fit 2D (picasso_amd HIP backend)",
                      "Fit method": fitting_method}
     if fitting_method == "gaussmle":

@@ -277,6 +277,52 @@ def main():
         out["columns"] = np.array(list(locs.columns))
         out["dtypes"] = np.array([str(locs[c].dtype) for c in locs.columns])
         save("locs_from_fits_lq_em%d" % int(em), **out)
+    # ----------------------------------------------------------------- zfit
+    print("zfit goldens (scipy bounded Brent through the reference)")
+    zfit, avgroi = ref["zfit"], ref["avgroi"]
+    CALIB = {   # reference tests/conftest.py:207-229 (CALIB_3D)
+        "X Coefficients": [-1.6680708772714857e-18, 2.4038209829154137e-15, 2.1771067332017187e-12,
+                           -3.0324788231238476e-09, 3.5433326085494675e-06, 0.0023039289366630425, 1.2026032603707493],
+        "Y Coefficients": [-1.7708672355491796e-18, 9.808249540501714e-16, 2.10653248543535e-12,
+                           2.228026137415219e-11, 3.628007433361433e-06, -0.001646865504353452, 1.2257249554338714],
+        "Step size in nm": 5.0, "Number of frames": 201, "Magnification factor": 0.79,
+    }
+    rng = np.random.default_rng(2026)
+    n = 400
+    ztrue = rng.uniform(-450, 450, n)
+    cxv, cyv = np.array(CALIB["X Coefficients"]), np.array(CALIB["Y Coefficients"])
+    wx = np.polyval(cxv, ztrue) * rng.normal(1.0, 0.03, n)
+    wy = np.polyval(cyv, ztrue) * rng.normal(1.0, 0.03, n)
+    wx[:6] = [0.3, 3.5, 1.0, 1e-3, 2.9, 0.0]      # off-curve / degenerate widths
+    wy[:6] = [3.5, 0.3, 1.0, 1e-3, 2.9, 1.2]
+    zl = pd.DataFrame({
+        "frame": np.sort(rng.integers(0, 50, n)).astype(np.uint32),
+        "x": rng.uniform(5, 27, n).astype(np.float32), "y": rng.uniform(5, 27, n).astype(np.float32),
+        "photons": rng.uniform(800, 9000, n).astype(np.float32),
+        "sx": wx.astype(np.float32), "sy": wy.astype(np.float32),
+        "bg": rng.uniform(2, 40, n).astype(np.float32),
+        "lpx": rng.uniform(0.005, 0.05, n).astype(np.float32), "lpy": rng.uniform(0.005, 0.05, n).astype(np.float32),
+        "sx_unc": rng.uniform(0.005, 0.05, n).astype(np.float32), "sy_unc": rng.uniform(0.005, 0.05, n).astype(np.float32),
+    })
+    zinfo = [{"Width": 32, "Height": 32, "Frames": 50, "Pixelsize": 130}]
+    out = {c: zl[c].to_numpy() for c in zl.columns}
+    out["cx"], out["cy"], out["magnification"], out["pixelsize"] = cxv, cyv, np.float64(0.79), np.float64(130.0)
+    for method in ("gausslq", "gaussmle"):
+        r = zfit._fit_z(zl, zinfo, CALIB, 0.79, 130, fitting_method=method, filter=0)
+        out[method + "_index"] = r.index.to_numpy()      # rows surviving ensure_sanity
+        for c in ("z", "d_zcalib", "lpz"):
+            out[f"{method}_{c}"] = r[c].to_numpy()
+        r2 = zfit._fit_z(zl, zinfo, CALIB, 0.79, 130, fitting_method=method, filter=2)
+        out[method + "_index_filter2"] = r2.index.to_numpy()
+    save("zfit_calib3d", **out)
+
+    # ------------------------------------------------------------------ avg
+    theta = avgroi.fit_spots(real_spots)
+    locs = avgroi.locs_from_fits(ids_a, theta, 7, False)
+    o2 = {c: locs[c].to_numpy() for c in locs.columns}
+    o2["theta"] = theta
+    o2["columns"] = np.array(list(locs.columns))
+    save("avg_testdata", **o2)
     print("done")
 
 

@@ -110,7 +110,7 @@ def test_fit2d_missing_pixelsize_warns_then_fails_loudly_without_gpu(testdata_mo
 
 def test_methods_without_a_kernel_raise_not_implemented(testdata_movie):
     a = _fit2d_args(_Movie(testdata_movie))
-    for m in ("gausslq", "gausslq-gpu", "avg"):
+    for m in ("gausslq", "gausslq-gpu"):
         with pytest.raises(NotImplementedError, match="no HIP kernel yet"):
             localize.fit2D(**a, fitting_method=m)
 
@@ -132,3 +132,56 @@ def test_sigma_uncertainty_formula():
     tau = 2 * np.pi * sa2 * bg / n
     want = np.sqrt((s**2 / (4 * n)) * (1 + 8 * tau + np.sqrt(8 * tau / (1 + 2 * tau))))
     assert np.isclose(gaussmle.sigma_uncertainty(s, so, n, bg), want, rtol=1e-12)
+
+
+def test_gausslq_table_and_precision_match_reference():
+    """locs_from_fits / localization_precision of picasso/gausslq.py:404-484, 547-589 against
+    the table the reference produced (em False and True)."""
+    from picasso_amd import gausslq
+    ids = golden("get_spots_testdata")
+    idf = pd.DataFrame({"frame": ids["frame"], "x": ids["x"], "y": ids["y"], "net_gradient": ids["ng"]})
+    theta = golden("gausslq_testdata_real")["theta"]
+    for em in (False, True):
+        g = golden("locs_from_fits_lq_em%d" % int(em))
+        locs = gausslq.locs_from_fits(idf, theta, 7, em)
+        assert list(locs.columns) == list(g["columns"])
+        for c in locs.columns:
+            assert str(locs[c].dtype) == str(g[c].dtype), c
+            assert np.array_equal(locs[c].to_numpy(), g[c], equal_nan=True), c
+
+
+def test_avg_table_matches_reference():
+    from picasso_amd import avgroi
+    ids = golden("get_spots_testdata")
+    idf = pd.DataFrame({"frame": ids["frame"], "x": ids["x"], "y": ids["y"], "net_gradient": ids["ng"]})
+    g = golden("avg_testdata")
+    locs = avgroi.locs_from_fits(idf, g["theta"], 7, False)
+    assert list(locs.columns) == list(g["columns"])
+    for c in locs.columns:
+        assert np.array_equal(locs[c].to_numpy(), g[c], equal_nan=True), c
+
+
+def test_ensure_sanity_and_filter():
+    from picasso_amd import lib, zfit
+    locs = pd.DataFrame({"x": np.float32([1, 40, 3, 4, -1]), "y": np.float32([1, 2, 3, np.inf, 2]),
+                         "lpx": np.float32([.1, .1, np.nan, .1, .1]), "photons": np.float32([5, 5, 5, 5, 5]),
+                         "d_zcalib": np.float32([.1, .1, .1, .1, 5])})
+    info = [{"Width": 32, "Height": 32, "Frames": 10}]
+    out = lib.ensure_sanity(locs, info)
+    assert list(out.index) == [0]
+    with pytest.raises(KeyError, match="Width"):
+        lib.ensure_sanity(locs, [{"Height": 3, "Frames": 2}])
+    assert lib.get_from_metadata([{"a": 1}, {"a": 2}], "a") == 2
+    assert lib.get_from_metadata({"a": 1}, "b", 7) == 7
+    assert len(zfit.filter_z_fits(locs, 0)) == 5 and len(zfit.filter_z_fits(locs, 1)) == 4
+
+
+def test_zfit_argument_checks():
+    from picasso_amd import zfit
+    locs = pd.DataFrame({"x": np.float32([1.0]), "sx": np.float32([1.0]), "sy": np.float32([1.0])})
+    with pytest.raises(AssertionError, match="Invalid fitting method"):
+        zfit.zfit(locs, [{}], calibration={}, fitting_method="x")
+    with pytest.raises(AssertionError, match="Magnification factor is missing"):
+        zfit.zfit(locs, [{"Pixelsize": 130}], calibration={"X Coefficients": [0] * 7})
+    with pytest.raises(AssertionError, match="pixel size"):
+        zfit.zfit(locs, [{}], calibration={"Magnification factor": 0.8})

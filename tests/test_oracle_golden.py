@@ -142,3 +142,22 @@ def test_gaussmle_bad_method_and_max_it_zero():
     th, cr, ll, it = orc.gaussmle(d["spots"][:4], 1e-3, 0, "sigmaxy")
     assert np.all(it == 0)
     assert np.allclose(th, orc.initial_parameters(d["spots"][:4]))
+
+
+def test_zfit_against_goldens():
+    """Bounded Brent restatement vs the reference running scipy's minimize_scalar."""
+    g = golden("zfit_calib3d")
+    z, sq = orc.zfit(g["sx"], g["sy"], g["cx"], g["cy"], threads=2)
+    zz = z.astype(np.float32) * np.float32(g["magnification"])
+    dz = np.sqrt(sq.astype(np.float32))
+    for m in ("gausslq", "gaussmle"):
+        idx = g[m + "_index"]
+        # the NumPy-executed reference takes sqrt(sx) in float32 (numba: float64): <= 1 float32 ulp in z
+        assert np.max(np.abs(zz[idx] - g[m + "_z"])) <= 1.3e-4
+        assert np.max(np.abs(dz[idx] - g[m + "_d_zcalib"])) < 1e-6
+
+
+def test_avgroi_bit_exact():
+    a = golden("avg_testdata")
+    s = golden("get_spots_testdata")
+    assert np.array_equal(orc.avgroi(s["spots_unit"]), a["theta"])

@@ -51,6 +51,9 @@ def lib():
         L.orc_initial_parameters.restype = i32
         L.orc_unit_vectors.argtypes = [i32, p, p]
         L.orc_avgroi.argtypes = [p, i64, i32, p]
+        L.orc_gausslq.argtypes = [p, i64, i32, p, p, p, i32]
+        L.orc_gausslq_initial.argtypes = [p, i64, i32, p]
+        L.orc_gausslq_from.argtypes = [p, i64, i32, p, p, i32]
         L.orc_zfit.argtypes = [p, p, i64, p, p, p, p, i32]
         L.orc_max_threads.restype = i32
         _lib = L
@@ -170,3 +173,30 @@ def zfit(sx, sy, cx, cy, threads=1):
     z = np.zeros(N, np.float64); sq = np.zeros(N, np.float64)
     lib().orc_zfit(_ptr(sx), _ptr(sy), N, _ptr(cx), _ptr(cy), _ptr(z), _ptr(sq), int(threads))
     return z, sq
+
+
+def gausslq(spots, threads=1, full=False):
+    """gausslq.fit_spots restated (MINPACK lmdif): theta (N,6) float32 [x, y, photons, bg, sx, sy]."""
+    spots = np.ascontiguousarray(spots, np.float32)
+    N, box, _ = spots.shape
+    th = np.full((N, 6), np.nan, np.float32)
+    info = np.zeros(N, np.int32); nfev = np.zeros(N, np.int32)
+    lib().orc_gausslq(_ptr(spots), N, box, _ptr(th), _ptr(info), _ptr(nfev), int(threads))
+    return (th, info, nfev) if full else th
+
+
+def gausslq_initial(spots):
+    spots = np.ascontiguousarray(spots, np.float32)
+    N, box, _ = spots.shape
+    th = np.zeros((N, 6), np.float32)
+    lib().orc_gausslq_initial(_ptr(spots), N, box, _ptr(th))
+    return th
+
+
+def gausslq_from(spots, theta0, threads=1):
+    spots = np.ascontiguousarray(spots, np.float32)
+    theta0 = np.ascontiguousarray(theta0, np.float32)
+    N, box, _ = spots.shape
+    th = np.zeros((N, 6), np.float32)
+    lib().orc_gausslq_from(_ptr(spots), N, box, _ptr(theta0), _ptr(th), int(threads))
+    return th

@@ -705,6 +705,422 @@ int orc_zfit(const float *sx, const float *sy, int64_t N, const double *cx7, con
     return 0;
 }
 
+/* ------------------------------------------------------------------------
+ * gausslq  (picasso/gausslq.py:33-112 model + initial parameters, :206-244 fit_spot)
+ *
+ * The solver is third-party: scipy.optimize.leastsq(ftol=1e-2, xtol=1e-2) ->
+ * MINPACK lmdif (scipy 1.15.3; call site picasso/gausslq.py:240-242).  lmdif,
+ * lmpar, qrfac, qrsolv, fdjac2 and enorm are restated below from the published
+ * MINPACK algorithm (More', Garbow, Hillstrom, ANL-80-74); tests validate this
+ * restatement against scipy's own lmdif on the same residual function.
+ * leastsq defaults that matter: gtol = 0, maxfev = 200*(n+1), factor = 100,
+ * mode 1 (internal scaling), epsfcn = eps of the RESIDUAL dtype (float32).
+ * ---------------------------------------------------------------------- */
+#define LQ_N 6
+#define LQ_MAXM ORC_MAX_PIX
+static const double LQ_EPSMCH = 2.220446049250313e-16;
+static const double LQ_DWARF = 2.2250738585072014e-308;
+
+static double enorm(int n, const double *x)
+{
+    const double rdwarf = 3.834e-20, rgiant = 1.304e19;
+    double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0;
+    const double agiant = rgiant / (double)n;
+    for (int i = 0; i < n; i++) {
+        double xabs = fabs(x[i]);
+        if (xabs > rdwarf && xabs < agiant) { s2 += xabs * xabs; }
+        else if (xabs <= rdwarf) {
+            if (xabs > x3max) { double r = x3max / xabs; s3 = 1 + s3 * r * r; x3max = xabs; }
+            else if (xabs != 0) { double r = xabs / x3max; s3 += r * r; }
+        } else {
+            if (xabs > x1max) { double r = x1max / xabs; s1 = 1 + s1 * r * r; x1max = xabs; }
+            else { double r = xabs / x1max; s1 += r * r; }
+        }
+    }
+    if (s1 != 0) return x1max * sqrt(s1 + (s2 / x1max) / x1max);
+    if (s2 != 0) {
+        if (s2 >= x3max) return sqrt(s2 * (1 + (x3max / s2) * (x3max * s3)));
+        return sqrt(x3max * ((s2 / x3max) + (x3max * s3)));
+    }
+    return x3max * sqrt(s3);
+}
+
+/* residuals of the point-sampled Gaussian model, float32 stores as in gausslq.py:151-203 */
+static void lq_residuals(const double *theta, const float *spot, int size, double *fvec)
+{
+    float mx[ORC_MAX_BOX], my[ORC_MAX_BOX];
+    const int h = size / 2;
+    const double nx = 0.3989422804014327 / theta[4], ny = 0.3989422804014327 / theta[5];
+    for (int i = 0; i < size; i++) {
+        double g = (double)(float)(i - h);                    /* grid is a float32 array */
+        double tx = (g - theta[0]) / theta[4], ty = (g - theta[1]) / theta[5];
+        mx[i] = (float)(nx * exp(-0.5 * (tx * tx)));          /* f32 store */
+        my[i] = (float)(ny * exp(-0.5 * (ty * ty)));
+    }
+    for (int i = 0; i < size; i++)
+        for (int j = 0; j < size; j++) {
+            float model = (float)(theta[2] * (double)my[i] * (double)mx[j] + theta[3]);   /* f32 store */
+            float res = spot[i * size + j] - model;           /* float32 array arithmetic */
+            fvec[i * size + j] = (double)res;
+        }
+}
+
+/* gausslq.py:95-112 */
+static void lq_initial_parameters(const float *spot, int size, float *theta)
+{
+    const int h = size / 2;
+    float mn = spot[0];
+    for (int k = 1; k < size * size; k++) { float v = spot[k]; if (mn == mn && (v < mn || v != v)) mn = v; }
+    theta[3] = mn;
+    double y = 0.0, x = 0.0, sum = 0.0;
+    for (int i = 0; i < size; i++)
+        for (int j = 0; j < size; j++) {
+            double v = (double)(float)(spot[i * size + j] - mn);
+            y += v * (double)i; x += v * (double)j; sum += v;
+        }
+    if (sum <= 0.0) { sum = 0.01; y = (size - 1) / 2.0; x = (size - 1) / 2.0; }
+    else { y /= sum; x /= sum; }
+    theta[1] = (float)y; theta[0] = (float)x;
+    theta[2] = (float)(1.0 > sum ? 1.0 : sum);
+    double sdy = 0.0, sdx = 0.0;
+    for (int i = 0; i < size; i++)
+        for (int j = 0; j < size; j++) {
+            double v = (double)(float)(spot[i * size + j] - mn);
+            double dy = (double)i - (double)theta[1], dx = (double)j - (double)theta[0];
+            sdy += v * (dy * dy);
+            sdx += v * (dx * dx);
+        }
+    theta[5] = (float)sqrt(sdy / sum);
+    theta[4] = (float)sqrt(sdx / sum);
+    theta[0] = theta[0] - (float)h;
+    theta[1] = theta[1] - (float)h;
+}
+
+static void qrsolv(int n, double *r, int ldr, const int *ipvt, const double *diag, const double *qtb,
+                   double *x, double *sdiag, double *wa)
+{
+    for (int j = 0; j < n; j++) {
+        for (int i = j; i < n; i++) r[i + j * ldr] = r[j + i * ldr];
+        x[j] = r[j + j * ldr];
+        wa[j] = qtb[j];
+    }
+    for (int j = 0; j < n; j++) {
+        int l = ipvt[j];
+        if (diag[l] != 0) {
+            for (int k = j; k < n; k++) sdiag[k] = 0;
+            sdiag[j] = diag[l];
+            double qtbpj = 0;
+            for (int k = j; k < n; k++) {
+                if (sdiag[k] == 0) continue;
+                double c, sn;
+                if (fabs(r[k + k * ldr]) < fabs(sdiag[k])) {
+                    double cotan = r[k + k * ldr] / sdiag[k];
+                    sn = 0.5 / sqrt(0.25 + 0.25 * (cotan * cotan));
+                    c = sn * cotan;
+                } else {
+                    double tn = sdiag[k] / r[k + k * ldr];
+                    c = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
+                    sn = c * tn;
+                }
+                r[k + k * ldr] = c * r[k + k * ldr] + sn * sdiag[k];
+                double temp = c * wa[k] + sn * qtbpj;
+                qtbpj = -sn * wa[k] + c * qtbpj;
+                wa[k] = temp;
+                for (int i = k + 1; i < n; i++) {
+                    temp = c * r[i + k * ldr] + sn * sdiag[i];
+                    sdiag[i] = -sn * r[i + k * ldr] + c * sdiag[i];
+                    r[i + k * ldr] = temp;
+                }
+            }
+        }
+        sdiag[j] = r[j + j * ldr];
+        r[j + j * ldr] = x[j];
+    }
+    int nsing = n;
+    for (int j = 0; j < n; j++) {
+        if (sdiag[j] == 0 && nsing == n) nsing = j;
+        if (nsing < n) wa[j] = 0;
+    }
+    for (int k = 1; k <= nsing; k++) {
+        int j = nsing - k;
+        double sum = 0;
+        for (int i = j + 1; i < nsing; i++) sum += r[i + j * ldr] * wa[i];
+        wa[j] = (wa[j] - sum) / sdiag[j];
+    }
+    for (int j = 0; j < n; j++) x[ipvt[j]] = wa[j];
+}
+
+static void lmpar(int n, double *r, int ldr, const int *ipvt, const double *diag, const double *qtb, double delta,
+                  double *par, double *x, double *sdiag, double *wa1, double *wa2)
+{
+    int nsing = n;
+    for (int j = 0; j < n; j++) {
+        wa1[j] = qtb[j];
+        if (r[j + j * ldr] == 0 && nsing == n) nsing = j;
+        if (nsing < n) wa1[j] = 0;
+    }
+    for (int k = 1; k <= nsing; k++) {
+        int j = nsing - k;
+        wa1[j] /= r[j + j * ldr];
+        double temp = wa1[j];
+        for (int i = 0; i < j; i++) wa1[i] -= r[i + j * ldr] * temp;
+    }
+    for (int j = 0; j < n; j++) x[ipvt[j]] = wa1[j];
+    int iter = 0;
+    for (int j = 0; j < n; j++) wa2[j] = diag[j] * x[j];
+    double dxnorm = enorm(n, wa2);
+    double fp = dxnorm - delta;
+    if (fp <= 0.1 * delta) { *par = 0; return; }
+    double parl = 0;
+    if (nsing >= n) {
+        for (int j = 0; j < n; j++) { int l = ipvt[j]; wa1[j] = diag[l] * (wa2[l] / dxnorm); }
+        for (int j = 0; j < n; j++) {
+            double sum = 0;
+            for (int i = 0; i < j; i++) sum += r[i + j * ldr] * wa1[i];
+            wa1[j] = (wa1[j] - sum) / r[j + j * ldr];
+        }
+        double temp = enorm(n, wa1);
+        parl = ((fp / delta) / temp) / temp;
+    }
+    for (int j = 0; j < n; j++) {
+        double sum = 0;
+        for (int i = 0; i <= j; i++) sum += r[i + j * ldr] * qtb[i];
+        wa1[j] = sum / diag[ipvt[j]];
+    }
+    double gnorm = enorm(n, wa1);
+    double paru = gnorm / delta;
+    if (paru == 0) paru = LQ_DWARF / (delta < 0.1 ? delta : 0.1);
+    if (*par < parl) *par = parl;
+    if (*par > paru) *par = paru;
+    if (*par == 0) *par = gnorm / dxnorm;
+    for (;;) {
+        iter++;
+        if (*par == 0) { double t = 0.001 * paru; *par = LQ_DWARF > t ? LQ_DWARF : t; }
+        double temp = sqrt(*par);
+        for (int j = 0; j < n; j++) wa1[j] = temp * diag[j];
+        qrsolv(n, r, ldr, ipvt, wa1, qtb, x, sdiag, wa2);
+        for (int j = 0; j < n; j++) wa2[j] = diag[j] * x[j];
+        dxnorm = enorm(n, wa2);
+        temp = fp;
+        fp = dxnorm - delta;
+        if (fabs(fp) <= 0.1 * delta || (parl == 0 && fp <= temp && temp < 0) || iter == 10) break;
+        for (int j = 0; j < n; j++) { int l = ipvt[j]; wa1[j] = diag[l] * (wa2[l] / dxnorm); }
+        for (int j = 0; j < n; j++) {
+            wa1[j] /= sdiag[j];
+            temp = wa1[j];
+            for (int i = j + 1; i < n; i++) wa1[i] -= r[i + j * ldr] * temp;
+        }
+        temp = enorm(n, wa1);
+        double parc = ((fp / delta) / temp) / temp;
+        if (fp > 0 && parl < *par) parl = *par;
+        if (fp < 0 && paru > *par) paru = *par;
+        double np_ = *par + parc;
+        *par = parl > np_ ? parl : np_;
+    }
+    if (iter == 0) *par = 0;
+}
+
+static void qrfac(int m, int n, double *a, int lda, int *ipvt, double *rdiag, double *acnorm, double *wa)
+{
+    for (int j = 0; j < n; j++) {
+        acnorm[j] = enorm(m, a + j * lda);
+        rdiag[j] = acnorm[j];
+        wa[j] = rdiag[j];
+        ipvt[j] = j;
+    }
+    int minmn = m < n ? m : n;
+    for (int j = 0; j < minmn; j++) {
+        int kmax = j;
+        for (int k = j; k < n; k++) if (rdiag[k] > rdiag[kmax]) kmax = k;
+        if (kmax != j) {
+            for (int i = 0; i < m; i++) { double t = a[i + j * lda]; a[i + j * lda] = a[i + kmax * lda]; a[i + kmax * lda] = t; }
+            rdiag[kmax] = rdiag[j];
+            wa[kmax] = wa[j];
+            int k = ipvt[j]; ipvt[j] = ipvt[kmax]; ipvt[kmax] = k;
+        }
+        double ajnorm = enorm(m - j, a + j + j * lda);
+        if (ajnorm != 0) {
+            if (a[j + j * lda] < 0) ajnorm = -ajnorm;
+            for (int i = j; i < m; i++) a[i + j * lda] /= ajnorm;
+            a[j + j * lda] += 1;
+            for (int k = j + 1; k < n; k++) {
+                double sum = 0;
+                for (int i = j; i < m; i++) sum += a[i + j * lda] * a[i + k * lda];
+                double temp = sum / a[j + j * lda];
+                for (int i = j; i < m; i++) a[i + k * lda] -= temp * a[i + j * lda];
+                if (rdiag[k] != 0) {
+                    temp = a[j + k * lda] / rdiag[k];
+                    double t2 = 1 - temp * temp;
+                    rdiag[k] *= sqrt(t2 > 0 ? t2 : 0);
+                    double q = rdiag[k] / wa[k];
+                    if (0.05 * (q * q) <= LQ_EPSMCH) {
+                        rdiag[k] = enorm(m - j - 1, a + (j + 1) + k * lda);
+                        wa[k] = rdiag[k];
+                    }
+                }
+            }
+        }
+        rdiag[j] = -ajnorm;
+    }
+}
+
+/* lmdif for one spot; returns info, theta (float64[6]) in x */
+static int lmdif_spot(const float *spot, int size, double *x, double ftol, double xtol, double gtol, int maxfev,
+                      double epsfcn, double factor, int *nfev_out)
+{
+    const int n = LQ_N, m = size * size, ld = m;
+    static __thread double fjac[LQ_MAXM * LQ_N], fvec[LQ_MAXM], wa4[LQ_MAXM];
+    double diag[LQ_N], qtf[LQ_N], wa1[LQ_N], wa2[LQ_N], wa3[LQ_N];
+    int ipvt[LQ_N];
+    int info = 0, nfev = 0, iter = 1;
+    double par = 0, delta = 0, xnorm = 0, gnorm = 0, fnorm, fnorm1, actred, prered, dirder, ratio, pnorm;
+    lq_residuals(x, spot, size, fvec); nfev = 1;
+    fnorm = enorm(m, fvec);
+    const double eps = sqrt(epsfcn > LQ_EPSMCH ? epsfcn : LQ_EPSMCH);
+    for (;;) {
+        /* forward-difference Jacobian (fdjac2) */
+        for (int j = 0; j < n; j++) {
+            double temp = x[j], h = eps * fabs(temp);
+            if (h == 0) h = eps;
+            x[j] = temp + h;
+            lq_residuals(x, spot, size, wa4);
+            x[j] = temp;
+            for (int i = 0; i < m; i++) fjac[i + j * ld] = (wa4[i] - fvec[i]) / h;
+        }
+        nfev += n;
+        qrfac(m, n, fjac, ld, ipvt, wa1, wa2, wa3);
+        if (iter == 1) {
+            for (int j = 0; j < n; j++) { diag[j] = wa2[j]; if (wa2[j] == 0) diag[j] = 1; }
+            for (int j = 0; j < n; j++) wa3[j] = diag[j] * x[j];
+            xnorm = enorm(n, wa3);
+            delta = factor * xnorm;
+            if (delta == 0) delta = factor;
+        }
+        for (int i = 0; i < m; i++) wa4[i] = fvec[i];
+        for (int j = 0; j < n; j++) {
+            if (fjac[j + j * ld] != 0) {
+                double sum = 0;
+                for (int i = j; i < m; i++) sum += fjac[i + j * ld] * wa4[i];
+                double temp = -sum / fjac[j + j * ld];
+                for (int i = j; i < m; i++) wa4[i] += fjac[i + j * ld] * temp;
+            }
+            fjac[j + j * ld] = wa1[j];
+            qtf[j] = wa4[j];
+        }
+        gnorm = 0;
+        if (fnorm != 0) {
+            for (int j = 0; j < n; j++) {
+                int l = ipvt[j];
+                if (wa2[l] != 0) {
+                    double sum = 0;
+                    for (int i = 0; i <= j; i++) sum += fjac[i + j * ld] * (qtf[i] / fnorm);
+                    double g = fabs(sum / wa2[l]);
+                    if (g > gnorm) gnorm = g;
+                }
+            }
+        }
+        if (gnorm <= gtol) { info = 4; break; }
+        for (int j = 0; j < n; j++) if (wa2[j] > diag[j]) diag[j] = wa2[j];
+        for (;;) {
+            lmpar(n, fjac, ld, ipvt, diag, qtf, delta, &par, wa1, wa2, wa3, wa4);
+            for (int j = 0; j < n; j++) { wa1[j] = -wa1[j]; wa2[j] = x[j] + wa1[j]; wa3[j] = diag[j] * wa1[j]; }
+            pnorm = enorm(n, wa3);
+            if (iter == 1 && pnorm < delta) delta = pnorm;
+            lq_residuals(wa2, spot, size, wa4); nfev++;
+            fnorm1 = enorm(m, wa4);
+            actred = -1;
+            if (0.1 * fnorm1 < fnorm) { double r = fnorm1 / fnorm; actred = 1 - r * r; }
+            for (int j = 0; j < n; j++) {
+                wa3[j] = 0;
+                double temp = wa1[ipvt[j]];
+                for (int i = 0; i <= j; i++) wa3[i] += fjac[i + j * ld] * temp;
+            }
+            double temp1 = enorm(n, wa3) / fnorm, temp2 = (sqrt(par) * pnorm) / fnorm;
+            prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+            dirder = -(temp1 * temp1 + temp2 * temp2);
+            ratio = 0;
+            if (prered != 0) ratio = actred / prered;
+            if (ratio <= 0.25) {
+                double temp = 0.5;
+                if (actred < 0) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+                if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+                double pd = pnorm / 0.1;
+                delta = temp * (delta < pd ? delta : pd);
+                par = par / temp;
+            } else if (par == 0 || ratio >= 0.75) {
+                delta = pnorm / 0.5;
+                par = 0.5 * par;
+            }
+            if (ratio >= 1e-4) {
+                for (int j = 0; j < n; j++) { x[j] = wa2[j]; wa2[j] = diag[j] * x[j]; }
+                for (int i = 0; i < m; i++) fvec[i] = wa4[i];
+                xnorm = enorm(n, wa2);
+                fnorm = fnorm1;
+                iter++;
+            }
+            if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1) info = 1;
+            if (delta <= xtol * xnorm) info = 2;
+            if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1 && info == 2) info = 3;
+            if (info != 0) break;
+            if (nfev >= maxfev) info = 5;
+            if (fabs(actred) <= LQ_EPSMCH && prered <= LQ_EPSMCH && 0.5 * ratio <= 1) info = 6;
+            if (delta <= LQ_EPSMCH * xnorm) info = 7;
+            if (gnorm <= LQ_EPSMCH) info = 8;
+            if (info != 0) break;
+            if (ratio >= 1e-4) break;
+        }
+        if (info != 0) break;
+    }
+    if (nfev_out) *nfev_out = nfev;
+    return info;
+}
+
+/* gausslq.fit_spots: theta (N,6) float32 [x, y, photons, bg, sx, sy], x/y relative to the box centre */
+int orc_gausslq(const float *spots, int64_t N, int box, float *theta, int32_t *info_out, int32_t *nfev_out, int nthreads)
+{
+    if (box < 1 || box > ORC_MAX_BOX) return -1;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
+#endif
+    for (int64_t i = 0; i < N; i++) {
+        float t0[6];
+        double x[6];
+        lq_initial_parameters(spots + i * box * box, box, t0);
+        for (int k = 0; k < 6; k++) x[k] = (double)t0[k];
+        int nfev = 0;
+        int info = lmdif_spot(spots + i * box * box, box, x, 1e-2, 1e-2, 0.0, 200 * (LQ_N + 1),
+                              1.1920928955078125e-07 /* finfo(float32).eps */, 100.0, &nfev);
+        for (int k = 0; k < 6; k++) theta[i * 6 + k] = (float)x[k];
+        if (info_out) info_out[i] = info;
+        if (nfev_out) nfev_out[i] = nfev;
+    }
+    return 0;
+}
+
+/* lmdif from caller-supplied start values (float32, as gausslq.py:238 builds them) */
+int orc_gausslq_from(const float *spots, int64_t N, int box, const float *theta0, float *theta, int nthreads)
+{
+    if (box < 1 || box > ORC_MAX_BOX) return -1;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 16) num_threads(nthreads)
+#endif
+    for (int64_t i = 0; i < N; i++) {
+        double x[6];
+        for (int k = 0; k < 6; k++) x[k] = (double)theta0[i * 6 + k];
+        lmdif_spot(spots + i * box * box, box, x, 1e-2, 1e-2, 0.0, 200 * (LQ_N + 1), 1.1920928955078125e-07, 100.0, NULL);
+        for (int k = 0; k < 6; k++) theta[i * 6 + k] = (float)x[k];
+    }
+    return 0;
+}
+
+int orc_gausslq_initial(const float *spots, int64_t N, int box, float *theta)
+{
+    for (int64_t i = 0; i < N; i++) lq_initial_parameters(spots + i * box * box, box, theta + i * 6);
+    return 0;
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP

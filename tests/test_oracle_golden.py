@@ -161,3 +161,41 @@ def test_avgroi_bit_exact():
     a = golden("avg_testdata")
     s = golden("get_spots_testdata")
     assert np.array_equal(orc.avgroi(s["spots_unit"]), a["theta"])
+
+
+@pytest.mark.parametrize("name", ["conftest_clean", "conftest_noisy", "testdata_real", "poisson7", "poisson13"])
+def test_gausslq_against_goldens(name):
+    """MINPACK lmdif restatement + the point-sampled Gaussian residuals (gausslq.py:33-244).
+    From the reference's own start values the result is bit-identical to what the reference got
+    out of scipy.optimize.leastsq; from the oracle's start values (float64 moment sums, numba
+    promotion) it differs by what ftol = xtol = 1e-2 leaves undetermined."""
+    g = golden("gausslq_" + name)
+    th = orc.gausslq_from(g["spots"], g["theta0"], threads=2)
+    assert np.array_equal(th, g["theta"])
+    t0 = orc.gausslq_initial(g["spots"])
+    assert np.all(np.abs(t0 - g["theta0"]) <= 3e-6 + 1e-6 * np.abs(g["theta0"]))     # float32-vs-float64 moment sums
+    full = orc.gausslq(g["spots"], threads=2)
+    assert np.max(np.abs(full[:, :2] - g["theta"][:, :2])) < 5e-3
+    assert np.max(np.abs(full[:, 4:] - g["theta"][:, 4:])) < 5e-3
+    assert np.max(np.abs(full[:, 2] - g["theta"][:, 2]) / g["theta"][:, 2]) < 5e-3
+
+
+def test_gausslq_matches_scipy_minpack():
+    """The lmdif restatement against scipy's MINPACK on the same residual function."""
+    from scipy import optimize
+
+    def resid(theta, spot, size):
+        h = size // 2
+        grid = np.arange(-h, h + 1, dtype=np.float32).astype(np.float64)
+        mx = (0.3989422804014327 / theta[4] * np.exp(-0.5 * ((grid - theta[0]) / theta[4]) ** 2)).astype(np.float32)
+        my = (0.3989422804014327 / theta[5] * np.exp(-0.5 * ((grid - theta[1]) / theta[5]) ** 2)).astype(np.float32)
+        model = (theta[2] * my.astype(np.float64)[:, None] * mx.astype(np.float64)[None, :] + theta[3]).astype(np.float32)
+        return (spot - model).astype(np.float32).ravel()
+
+    g = golden("gausslq_poisson7")
+    spots = g["spots"][:48]
+    t0 = orc.gausslq_initial(spots)
+    th, info, nfev = orc.gausslq(spots, full=True)
+    for i in range(len(spots)):
+        r = optimize.leastsq(resid, t0[i], args=(spots[i], 7), ftol=1e-2, xtol=1e-2, full_output=True)
+        assert np.array_equal(r[0].astype(np.float32), th[i]) and r[4] == info[i] and r[2]["nfev"] == nfev[i]

@@ -27,6 +27,13 @@
  *   pmi_locs_from_fits_dev  picasso/gaussmle.py:957-1037 locs_from_fits
  *   pmi_zfit*          picasso/zfit.py:327-382 _fit_z (per-localization loop)
  *   pmi_avgroi*        picasso/avgroi.py:45-65 fit_spots
+ *   pmi_gausslq*       picasso/gausslq.py:206-300 fit_spot / fit_spots /
+ *                      fit_spots_parallel (scipy.optimize.leastsq = MINPACK lmdif
+ *                      on the residuals of :151-203, start values of :95-112)
+ *   pmi_locs_from_fits_lq_dev  picasso/gausslq.py:404-484 locs_from_fits
+ *                      (+ :547-589 localization_precision)
+ *   pmi_localize_lq_dev     picasso/localize.py:1682-1815 localize with
+ *                      fitting_method="gausslq"
  *   pmi_localize_mle_dev    picasso/localize.py:1682-1815 localize with
  *                      fitting_method="gaussmle" (identify -> get_spots -> fit
  *                      -> table) as one asynchronous device pipeline
@@ -143,6 +150,34 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
                          double baseline, double sensitivity, double gain,
                          double eps, int max_it, int method,
                          void *d_table, int64_t cap, int64_t *d_out_n, void *stream);
+
+/* ---- gausslq (picasso/gausslq.py:206-300) ------------------------------- *
+ * spots: (N, box, box) float32 photons, box odd in [3, 21].  thetas (N,6) =
+ * x, y, photons, bg, sx, sy with x, y relative to the box CENTRE (the least-
+ * squares model is point-sampled on the grid -r..r, gausslq.py:228).  info /
+ * nfev (N, int32, may be NULL) are MINPACK's termination code and the number of
+ * residual evaluations, what leastsq(full_output=1) would report.            */
+int pmi_gausslq(const float *spots, int64_t N, int box, float *thetas, int32_t *info, int32_t *nfev);
+int pmi_gausslq_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box, float *d_thetas,
+                    int32_t *d_info, int32_t *d_nfev, void *stream);
+int pmi_gausslq_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
+                          const int32_t *d_frame, const int32_t *d_y, const int32_t *d_x,
+                          int64_t N, const int64_t *d_n, int box, double baseline,
+                          double sensitivity, double gain, float *d_thetas, int32_t *d_info,
+                          int32_t *d_nfev, void *stream);
+/* 11-column table of gausslq.locs_from_fits: 0 frame(u32) 1 x 2 y 3 photons
+ * 4 sx 5 sy 6 bg 7 lpx 8 lpy 9 ellipticity 10 net_gradient.  em != 0 doubles
+ * the variance of lpx/lpy (EMCCD excess noise, gausslq.py:584-585).           */
+#define PMI_LQ_COLUMNS 11
+int pmi_locs_from_fits_lq_dev(const int32_t *d_frame, const int32_t *d_y, const int32_t *d_x,
+                              const float *d_ng, const float *d_thetas, int64_t N, const int64_t *d_n,
+                              int em, void *const *d_cols, void *stream);
+/* identify -> fused cut + least-squares fit -> table; d_table holds
+ * PMI_LQ_COLUMNS * cap * 4 bytes, column c at element c*cap.                  */
+int pmi_localize_lq_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
+                        int box, double min_ng, const int64_t *roi4, int64_t f_lo, int64_t f_hi,
+                        double baseline, double sensitivity, double gain, int em,
+                        void *d_table, int64_t cap, int64_t *d_out_n, void *stream);
 
 /* ---- zfit (picasso/zfit.py:254-291, 327-382) ---------------------------- *
  * Per localization: argmin over z in [-1000, 1000] of

@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(_HERE, "libpicasso_hip.so")
 PMI_OK = 0
 PMI_ERR_CAPACITY = 1
 PMI_LOC_COLUMNS = 17
+PMI_LQ_COLUMNS = 11
 PMI_MAX_BOX = 21
 
 DTYPE_CODES = {
@@ -53,6 +54,13 @@ SYMBOLS = {
     "pmi_locs_from_fits_dev": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i32, _p, _p]),
     "pmi_localize_mle_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _f64, _f64, _f64,
                                     _f64, _i32, _i32, _p, _i64, _p, _p]),
+    "pmi_gausslq": (_i32, [_p, _i64, _i32, _p, _p, _p]),
+    "pmi_gausslq_dev": (_i32, [_p, _i64, _p, _i32, _p, _p, _p, _p]),
+    "pmi_gausslq_movie_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _p, _p, _p, _i64, _p, _i32, _f64, _f64, _f64,
+                                     _p, _p, _p, _p]),
+    "pmi_locs_from_fits_lq_dev": (_i32, [_p, _p, _p, _p, _p, _i64, _p, _i32, _p, _p]),
+    "pmi_localize_lq_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _f64, _f64, _f64,
+                                   _i32, _p, _i64, _p, _p]),
     "pmi_zfit": (_i32, [_p, _p, _i64, _p, _p, _p, _p]),
     "pmi_zfit_dev": (_i32, [_p, _p, _i64, _p, _p, _p, _p, _p, _p]),
     "pmi_avgroi": (_i32, [_p, _i64, _i32, _p]),

@@ -12,6 +12,11 @@ import numpy as np
 
 from . import _lib
 
+LQ_COLUMNS = [
+    ("frame", np.uint32), ("x", np.float32), ("y", np.float32), ("photons", np.float32),
+    ("sx", np.float32), ("sy", np.float32), ("bg", np.float32), ("lpx", np.float32),
+    ("lpy", np.float32), ("ellipticity", np.float32), ("net_gradient", np.float32),
+]
 LOC_COLUMNS = [
     ("frame", np.uint32), ("x", np.float32), ("y", np.float32), ("photons", np.float32),
     ("sx", np.float32), ("sy", np.float32), ("bg", np.float32), ("lpx", np.float32),
@@ -129,6 +134,25 @@ def gaussmle_arrays(spots: np.ndarray, eps: float, max_it: int, method: str = "s
     return thetas, crlbs, loglik, iterations
 
 
+def gausslq_arrays(spots: np.ndarray, full_output: bool = False):
+    """theta (N,6) float32 as picasso/gausslq.py:247-268 fit_spots returns it; with
+    full_output also MINPACK's info code and nfev per spot."""
+    _lib.require_gpu()
+    spots = np.ascontiguousarray(spots, np.float32)
+    if spots.ndim != 3 or spots.shape[1] != spots.shape[2]:
+        raise ValueError("spots must have shape (N, box, box)")
+    N, box, _ = spots.shape
+    theta = np.empty((N, 6), np.float32)
+    info = np.zeros(N, np.int32)
+    nfev = np.zeros(N, np.int32)
+    with _lib.lock():
+        rc = _lib.load().pmi_gausslq(_lib.ptr(spots), N, int(box), _lib.ptr(theta), _lib.ptr(info), _lib.ptr(nfev))
+    _lib.check(rc, "pmi_gausslq")
+    if full_output:
+        return theta, info, nfev
+    return theta
+
+
 def avgroi_array(spots: np.ndarray) -> np.ndarray:
     _lib.require_gpu()
     spots = np.ascontiguousarray(spots, np.float32)
@@ -188,11 +212,9 @@ class DeviceMovie:
             pass
 
 
-def localize_mle_device(d_movie_ptr, dtype, shape, box, min_ng, camera, eps=1e-3, max_it=100,
-                        method="sigmaxy", roi=None, frame_bounds=None, cap=None, stream=None,
-                        f_lo=None, f_hi=None):
-    """identify -> fused cut+fit -> table on a resident movie.  Returns a dict of
-    numpy columns (LOC_COLUMNS).  d_movie_ptr: int / c_void_p device address."""
+def _localize_device(call, columns, d_movie_ptr, dtype, shape, roi, frame_bounds, cap, stream, f_lo, f_hi):
+    """Shared driver of the fused pipelines: allocate the table, submit, grow on
+    overflow, copy the columns back."""
     _lib.require_gpu()
     L = _lib.load()
     F, Y, X = shape
@@ -203,18 +225,15 @@ def localize_mle_device(d_movie_ptr, dtype, shape, box, min_ng, camera, eps=1e-3
     if f_hi is not None:
         hi = min(hi, f_hi)
     cap = int(cap or max(4096, 256 * F))
+    ncol = len(columns)
     while True:
         table = ctypes.c_void_p()
         dn = ctypes.c_void_p()
-        _lib.check(L.pmi_malloc(ctypes.byref(table), _lib.PMI_LOC_COLUMNS * cap * 4), "pmi_malloc")
+        _lib.check(L.pmi_malloc(ctypes.byref(table), ncol * cap * 4), "pmi_malloc")
         _lib.check(L.pmi_malloc(ctypes.byref(dn), 8), "pmi_malloc")
         try:
             with _lib.lock():
-                rc = L.pmi_localize_mle_dev(d_movie_ptr, dtype_code(dtype), F, Y, X, int(box), float(min_ng),
-                                            _lib.ptr(r), lo, hi, float(camera["Baseline"]),
-                                            float(camera["Sensitivity"]), float(camera["Gain"]), float(eps),
-                                            int(max_it), _lib.MLE_METHODS[method], table, cap, dn, stream)
-                _lib.check(rc, "pmi_localize_mle_dev")
+                call(L, d_movie_ptr, dtype_code(dtype), F, Y, X, r, lo, hi, table, cap, dn, stream)
                 _lib.check(L.pmi_stream_synchronize(stream), "sync")
             n = np.zeros(1, np.int64)
             _lib.check(L.pmi_memcpy_d2h(_lib.ptr(n), dn, 8), "d2h")
@@ -223,7 +242,7 @@ def localize_mle_device(d_movie_ptr, dtype, shape, box, min_ng, camera, eps=1e-3
                 cap = n
                 continue
             out = {}
-            for c, (name, dt) in enumerate(LOC_COLUMNS):
+            for c, (name, dt) in enumerate(columns):
                 col = np.empty(n, dt)
                 if n:
                     _lib.check(L.pmi_memcpy_d2h(_lib.ptr(col), ctypes.c_void_p(table.value + c * cap * 4), n * 4), "d2h")
@@ -232,3 +251,29 @@ def localize_mle_device(d_movie_ptr, dtype, shape, box, min_ng, camera, eps=1e-3
         finally:
             L.pmi_free(table)
             L.pmi_free(dn)
+
+
+def localize_mle_device(d_movie_ptr, dtype, shape, box, min_ng, camera, eps=1e-3, max_it=100,
+                        method="sigmaxy", roi=None, frame_bounds=None, cap=None, stream=None,
+                        f_lo=None, f_hi=None):
+    """identify -> fused cut+fit -> table on a resident movie.  Returns a dict of
+    numpy columns (LOC_COLUMNS).  d_movie_ptr: int / c_void_p device address."""
+    def call(L, d_movie, code, F, Y, X, r, lo, hi, table, cap_, dn, stream_):
+        rc = L.pmi_localize_mle_dev(d_movie, code, F, Y, X, int(box), float(min_ng), _lib.ptr(r), lo, hi,
+                                    float(camera["Baseline"]), float(camera["Sensitivity"]), float(camera["Gain"]),
+                                    float(eps), int(max_it), _lib.MLE_METHODS[method], table, cap_, dn, stream_)
+        _lib.check(rc, "pmi_localize_mle_dev")
+    return _localize_device(call, LOC_COLUMNS, d_movie_ptr, dtype, shape, roi, frame_bounds, cap, stream, f_lo, f_hi)
+
+
+def localize_lq_device(d_movie_ptr, dtype, shape, box, min_ng, camera, roi=None, frame_bounds=None, cap=None,
+                       stream=None, f_lo=None, f_hi=None):
+    """identify -> fused cut + least-squares fit -> 11-column table (LQ_COLUMNS)."""
+    em = int(camera["Gain"] > 1)
+
+    def call(L, d_movie, code, F, Y, X, r, lo, hi, table, cap_, dn, stream_):
+        rc = L.pmi_localize_lq_dev(d_movie, code, F, Y, X, int(box), float(min_ng), _lib.ptr(r), lo, hi,
+                                   float(camera["Baseline"]), float(camera["Sensitivity"]), float(camera["Gain"]),
+                                   em, table, cap_, dn, stream_)
+        _lib.check(rc, "pmi_localize_lq_dev")
+    return _localize_device(call, LQ_COLUMNS, d_movie_ptr, dtype, shape, roi, frame_bounds, cap, stream, f_lo, f_hi)

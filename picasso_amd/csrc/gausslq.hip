@@ -1,0 +1,815 @@
+// gausslq.hip — least-squares Gaussian fit (picasso/gausslq.py:206-300 fit_spot / fit_spots).
+//
+// The reference calls scipy.optimize.leastsq(ftol=1e-2, xtol=1e-2) per spot, i.e.
+// MINPACK lmdif with a forward-difference Jacobian (epsfcn = float32 eps because
+// the residual vector is float32), gtol = 0, factor = 100, maxfev = 1400, on the
+// residuals of a point-sampled elliptical Gaussian whose model is stored in
+// float32 (gausslq.py:151-203).  This file restates that algorithm for one
+// wavefront per spot:
+//
+//   - residual row r = i*size + j lives in lane r % 64, element r / 64, so the
+//     m x 6 Jacobian is six register columns per lane; column norms and the
+//     Householder dot products of qrfac are DPP wave reductions in float64;
+//   - the 6 x 6 triangular factor, lmpar and qrsolv are wave-uniform register code
+//     (all indices static; the pivot permutation goes through select chains);
+//   - all float64 arithmetic is unfused (contract off), as compiled MINPACK is.
+//
+// Sums over the m rows are tree reductions here and sequential loops in MINPACK;
+// the difference is in the last bits of float64 and disappears in the float32 theta
+// except when it flips a float32 rounding of the stored model.
+#include <algorithm>
+
+#include "fit_common.h"
+
+#pragma clang fp contract(off)
+
+namespace pmi {
+namespace lq {
+
+constexpr double EPSMCH = 2.220446049250313e-16;
+constexpr double DWARF = 2.2250738585072014e-308;
+constexpr double RDWARF = 3.834e-20, RGIANT = 1.304e19;
+constexpr int LQ_WAVES = 4;
+
+struct Params {
+    const float *spots;
+    const void *movie;
+    const int32_t *frame, *y, *x;
+    int dtype;
+    int64_t Y, X;
+    float baseline, sensitivity, gain;
+    int64_t N;
+    const int64_t *d_n;
+    int box;
+    float *thetas;
+    int32_t *info, *nfev;
+};
+
+__device__ __forceinline__ double readlane_d(double v, int lane)
+{
+    long long b = __builtin_bit_cast(long long, v);
+    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
+    int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
+    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
+}
+__device__ __forceinline__ double wave_max_d(double v)
+{
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+// Indexing a 6-vector by a run-time (wave-uniform) index without leaving registers.
+// The empty asm hides the loads from InstCombine, which otherwise rewrites the select
+// chain into one load through a computed address and pins the array in scratch memory.
+__device__ __forceinline__ double opaque(double v) { asm("" : "+v"(v)); return v; }
+__device__ __forceinline__ double get6(const double (&a)[6], int i)
+{
+    double v = opaque(a[0]);
+#pragma unroll
+    for (int k = 1; k < 6; k++) { const double ak = opaque(a[k]); v = (i == k) ? ak : v; }
+    return v;
+}
+__device__ __forceinline__ void set6(double (&a)[6], int i, double v)
+{
+#pragma unroll
+    for (int k = 0; k < 6; k++) { const double ak = opaque(a[k]); a[k] = (i == k) ? v : ak; }
+}
+
+// MINPACK enorm over six wave-uniform values, sequential as published.
+__device__ __forceinline__ double enorm6(const double (&x)[6])
+{
+    double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0;
+    const double agiant = RGIANT / 6.0;
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        const double xabs = fabs(x[i]);
+        if (xabs > RDWARF && xabs < agiant) { s2 += xabs * xabs; }
+        else if (xabs <= RDWARF) {
+            if (xabs > x3max) { double r = x3max / xabs; s3 = 1 + s3 * r * r; x3max = xabs; }
+            else if (xabs != 0) { double r = xabs / x3max; s3 += r * r; }
+        } else {
+            if (xabs > x1max) { double r = x1max / xabs; s1 = 1 + s1 * r * r; x1max = xabs; }
+            else { double r = xabs / x1max; s1 += r * r; }
+        }
+    }
+    if (s1 != 0) return x1max * sqrt(s1 + (s2 / x1max) / x1max);
+    if (s2 != 0) {
+        if (s2 >= x3max) return sqrt(s2 * (1 + (x3max / s2) * (x3max * s3)));
+        return sqrt(x3max * ((s2 / x3max) + (x3max * s3)));
+    }
+    return x3max * sqrt(s3);
+}
+
+// enorm over rows [row_lo, m) of a register column.  Mid-range components (all of
+// them, for finite photon data) take one reduction; the scaled accumulators of
+// MINPACK are only formed when a component is tiny, huge or NaN.
+template <int E>
+__device__ __forceinline__ double enorm_rows(const double (&v)[E], int lane, int row_lo, int m)
+{
+    const double agiant = RGIANT / (double)(m - row_lo);
+    double s2 = 0;
+    bool odd = false;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int r = lane + 64 * e;
+        if (r >= row_lo && r < m) {
+            const double xabs = fabs(v[e]);
+            if (xabs > RDWARF && xabs < agiant) s2 += xabs * xabs;
+            else if (xabs != 0) odd = true;
+        }
+    }
+    s2 = wave_sum_d(s2);
+    if (__builtin_amdgcn_ballot_w64(odd) == 0) return sqrt(s2);
+    double big = 0, small = 0;
+    bool isnan_ = false;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int r = lane + 64 * e;
+        if (r >= row_lo && r < m) {
+            const double xabs = fabs(v[e]);
+            if (xabs != xabs) isnan_ = true;
+            else if (xabs >= agiant) big = fmax(big, xabs);
+            else if (xabs <= RDWARF) small = fmax(small, xabs);
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(isnan_) != 0) return __builtin_nan("");
+    const double x1max = wave_max_d(big), x3max = wave_max_d(small);
+    double s1 = 0, s3 = 0;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int r = lane + 64 * e;
+        if (r >= row_lo && r < m) {
+            const double xabs = fabs(v[e]);
+            if (xabs >= agiant) { double q = xabs / x1max; s1 += q * q; }
+            else if (xabs <= RDWARF && xabs != 0) { double q = xabs / x3max; s3 += q * q; }
+        }
+    }
+    s1 = wave_sum_d(s1);
+    s3 = wave_sum_d(s3);
+    if (s1 != 0) return x1max * sqrt(s1 + (s2 / x1max) / x1max);
+    if (s2 != 0) {
+        if (s2 >= x3max) return sqrt(s2 * (1 + (x3max / s2) * (x3max * s3)));
+        return sqrt(x3max * ((s2 / x3max) + (x3max * s3)));
+    }
+    return x3max * sqrt(s3);
+}
+
+// Residuals of the float32-stored model (gausslq.py:151-203).  Lanes [0, size)
+// evaluate the x profile, lanes [size, 2 size) the y profile; every row then
+// fetches its two factors.
+template <int E>
+__device__ __forceinline__ void residuals(const double (&th)[6], const float (&sp)[E], const int (&ri)[E],
+                                          const int (&rj)[E], const bool (&act)[E], int size, int lane,
+                                          double (&out)[E])
+{
+    const int hsz = size / 2;
+    const bool isy = lane >= size;
+    const int idx = isy ? lane - size : lane;
+    const double th0 = th[0], th1 = th[1], th4 = th[4], th5 = th[5];   // values, not an lvalue select
+    const double mu = isy ? th1 : th0, sg = isy ? th5 : th4;
+    const double g = (double)(float)(idx - hsz);
+    const double t = (g - mu) / sg;
+    const double nrm = 0.3989422804014327 / sg;
+    const float prof = (float)(nrm * exp(-0.5 * (t * t)));
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const float mxv = __shfl(prof, rj[e]);
+        const float myv = __shfl(prof, size + ri[e]);
+        const float model = (float)(th[2] * (double)myv * (double)mxv + th[3]);
+        const float res = sp[e] - model;
+        out[e] = act[e] ? (double)res : 0.0;
+    }
+}
+
+// MINPACK qrsolv on the wave-uniform 6x6 factor R (R[row][col]).
+__device__ __forceinline__ void qrsolv(double (&R)[6][6], const int (&ipvt)[6], const double (&diag)[6],
+                                       const double (&qtb)[6], double (&x)[6], double (&sdiag)[6])
+{
+    double wa[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+#pragma unroll
+        for (int i = j; i < 6; i++) R[i][j] = R[j][i];
+        x[j] = R[j][j];
+        wa[j] = qtb[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        const double dl = get6(diag, ipvt[j]);
+        if (dl != 0) {
+#pragma unroll
+            for (int k = j; k < 6; k++) sdiag[k] = 0;
+            sdiag[j] = dl;
+            double qtbpj = 0;
+#pragma unroll
+            for (int k = j; k < 6; k++) {
+                if (sdiag[k] != 0) {
+                    double c, sn;
+                    if (fabs(R[k][k]) < fabs(sdiag[k])) {
+                        const double cotan = R[k][k] / sdiag[k];
+                        sn = 0.5 / sqrt(0.25 + 0.25 * (cotan * cotan));
+                        c = sn * cotan;
+                    } else {
+                        const double tn = sdiag[k] / R[k][k];
+                        c = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
+                        sn = c * tn;
+                    }
+                    R[k][k] = c * R[k][k] + sn * sdiag[k];
+                    double temp = c * wa[k] + sn * qtbpj;
+                    qtbpj = -sn * wa[k] + c * qtbpj;
+                    wa[k] = temp;
+#pragma unroll
+                    for (int i = k + 1; i < 6; i++) {
+                        temp = c * R[i][k] + sn * sdiag[i];
+                        sdiag[i] = -sn * R[i][k] + c * sdiag[i];
+                        R[i][k] = temp;
+                    }
+                }
+            }
+        }
+        sdiag[j] = R[j][j];
+        R[j][j] = x[j];
+    }
+    int nsing = 6;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        if (sdiag[j] == 0 && nsing == 6) nsing = j;
+        if (nsing < 6) wa[j] = 0;
+    }
+#pragma unroll
+    for (int j = 5; j >= 0; j--) {
+        if (j < nsing) {
+            double sum = 0;
+#pragma unroll
+            for (int i = j + 1; i < 6; i++)
+                if (i < nsing) sum += R[i][j] * wa[i];
+            wa[j] = (wa[j] - sum) / sdiag[j];
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) set6(x, ipvt[j], wa[j]);
+}
+
+// MINPACK lmpar.
+__device__ __forceinline__ void lmpar(double (&R)[6][6], const int (&ipvt)[6], const double (&diag)[6],
+                                      const double (&qtb)[6], double delta, double &par, double (&x)[6],
+                                      double (&sdiag)[6])
+{
+    double wa1[6], wa2[6];
+    int nsing = 6;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        wa1[j] = qtb[j];
+        if (R[j][j] == 0 && nsing == 6) nsing = j;
+        if (nsing < 6) wa1[j] = 0;
+    }
+#pragma unroll
+    for (int j = 5; j >= 0; j--) {
+        if (j < nsing) {
+            wa1[j] /= R[j][j];
+            const double temp = wa1[j];
+#pragma unroll
+            for (int i = 0; i < j; i++) wa1[i] -= R[i][j] * temp;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) set6(x, ipvt[j], wa1[j]);
+    int iter = 0;
+#pragma unroll
+    for (int j = 0; j < 6; j++) wa2[j] = diag[j] * x[j];
+    double dxnorm = enorm6(wa2);
+    double fp = dxnorm - delta;
+    if (fp <= 0.1 * delta) { par = 0; return; }
+    double parl = 0;
+    if (nsing >= 6) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) { const int l = ipvt[j]; wa1[j] = get6(diag, l) * (get6(wa2, l) / dxnorm); }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            double sum = 0;
+#pragma unroll
+            for (int i = 0; i < j; i++) sum += R[i][j] * wa1[i];
+            wa1[j] = (wa1[j] - sum) / R[j][j];
+        }
+        const double temp = enorm6(wa1);
+        parl = ((fp / delta) / temp) / temp;
+    }
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double sum = 0;
+#pragma unroll
+        for (int i = 0; i <= j; i++) sum += R[i][j] * qtb[i];
+        wa1[j] = sum / get6(diag, ipvt[j]);
+    }
+    const double gnorm = enorm6(wa1);
+    double paru = gnorm / delta;
+    if (paru == 0) paru = DWARF / (delta < 0.1 ? delta : 0.1);
+    if (par < parl) par = parl;
+    if (par > paru) par = paru;
+    if (par == 0) par = gnorm / dxnorm;
+    for (;;) {
+        iter++;
+        if (par == 0) { const double t = 0.001 * paru; par = DWARF > t ? DWARF : t; }
+        double temp = sqrt(par);
+#pragma unroll
+        for (int j = 0; j < 6; j++) wa1[j] = temp * diag[j];
+        qrsolv(R, ipvt, wa1, qtb, x, sdiag);
+#pragma unroll
+        for (int j = 0; j < 6; j++) wa2[j] = diag[j] * x[j];
+        dxnorm = enorm6(wa2);
+        temp = fp;
+        fp = dxnorm - delta;
+        if (fabs(fp) <= 0.1 * delta || (parl == 0 && fp <= temp && temp < 0) || iter == 10) break;
+#pragma unroll
+        for (int j = 0; j < 6; j++) { const int l = ipvt[j]; wa1[j] = get6(diag, l) * (get6(wa2, l) / dxnorm); }
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            wa1[j] /= sdiag[j];
+            temp = wa1[j];
+#pragma unroll
+            for (int i = j + 1; i < 6; i++) wa1[i] -= R[i][j] * temp;
+        }
+        temp = enorm6(wa1);
+        const double parc = ((fp / delta) / temp) / temp;
+        if (fp > 0 && parl < par) parl = par;
+        if (fp < 0 && paru > par) paru = par;
+        const double np_ = par + parc;
+        par = parl > np_ ? parl : np_;
+    }
+}
+
+// One column of MINPACK qrfac (pivot, Householder vector, update of the trailing
+// columns and of their running norms).  rdiag = wa1, wa = wa3.
+template <int E, int j>
+__device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], double (&wa3)[6], int (&ipvt)[6],
+                                           int lane, int m)
+{
+    int kmax = j;
+    double best = wa1[j];
+#pragma unroll
+    for (int k = j + 1; k < 6; k++)
+        if (wa1[k] > best) { best = wa1[k]; kmax = k; }
+#pragma unroll
+    for (int k = j + 1; k < 6; k++) {
+        // selects, not a branch: a conditional swap sinks into stores through pointer phis
+        // and the arrays then stay in scratch memory
+        const bool sw = kmax == k;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const double t = a[j][e], u = a[k][e];
+            a[j][e] = sw ? u : t;
+            a[k][e] = sw ? t : u;
+        }
+        wa1[k] = sw ? wa1[j] : wa1[k];
+        wa3[k] = sw ? wa3[j] : wa3[k];
+        const int t = ipvt[j], u = ipvt[k];
+        ipvt[j] = sw ? u : t;
+        ipvt[k] = sw ? t : u;
+    }
+    double ajnorm = enorm_rows<E>(a[j], lane, j, m);
+    if (ajnorm != 0) {
+        if (readlane_d(a[j][0], j) < 0) ajnorm = -ajnorm;
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            if (e > 0 || lane >= j) a[j][e] /= ajnorm;
+        if (lane == j) a[j][0] += 1;
+        const double ajj = readlane_d(a[j][0], j);
+#pragma unroll
+        for (int k = j + 1; k < 6; k++) {
+            double sum = 0;
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if (e > 0 || lane >= j) sum += a[j][e] * a[k][e];
+            sum = wave_sum_d(sum);
+            double temp = sum / ajj;
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if (e > 0 || lane >= j) a[k][e] -= temp * a[j][e];
+            if (wa1[k] != 0) {
+                temp = readlane_d(a[k][0], j) / wa1[k];
+                const double t2 = 1 - temp * temp;
+                wa1[k] *= sqrt(t2 > 0 ? t2 : 0);
+                const double q = wa1[k] / wa3[k];
+                if (0.05 * (q * q) <= EPSMCH) {
+                    wa1[k] = enorm_rows<E>(a[k], lane, j + 1, m);
+                    wa3[k] = wa1[k];
+                }
+            }
+        }
+    }
+    wa1[j] = -ajnorm;
+}
+
+template <int E, bool FROM_MOVIE>
+__global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
+{
+    const int lane = threadIdx.x & 63;
+    const int64_t wave0 = (int64_t)blockIdx.x * LQ_WAVES + (threadIdx.x >> 6);
+    const int64_t nwaves = (int64_t)gridDim.x * LQ_WAVES;
+    int64_t n = p.N;
+    if (p.d_n) { const int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+    const int size = p.box, m = size * size, hsz = size / 2;
+    int ri[E], rj[E];
+    bool act[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int r = lane + 64 * e;
+        act[e] = r < m;
+        const int rr = act[e] ? r : 0;
+        ri[e] = rr / size;
+        rj[e] = rr - ri[e] * size;
+    }
+    const double ftol = 1e-2, xtol = 1e-2, gtol = 0.0, factor = 100.0;
+    const int maxfev = 200 * (6 + 1);
+    const double eps = sqrt(1.1920928955078125e-07);     // sqrt(max(epsfcn, epsmch)), epsfcn = float32 eps
+
+    for (int64_t s = wave0; s < n; s += nwaves) {
+        // ---- the spot: rows of this lane ----
+        float sp[E];
+        if (FROM_MOVIE) {
+            const int64_t fr = p.frame[s], y0 = p.y[s] - hsz, x0 = p.x[s] - hsz;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                sp[e] = 0.f;
+                if (act[e]) {
+                    const float raw = load_movie_px(p.movie, p.dtype, (fr * p.Y + (y0 + ri[e])) * p.X + (x0 + rj[e]));
+                    sp[e] = ((raw - p.baseline) * p.sensitivity) / p.gain;
+                }
+            }
+        } else {
+#pragma unroll
+            for (int e = 0; e < E; e++) sp[e] = act[e] ? p.spots[s * m + lane + 64 * e] : 0.f;
+        }
+
+        // ---- initial parameters (gausslq.py:95-112) ----
+        double x[6];
+        {
+            float mn = __builtin_inff();
+            bool anynan = false;
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if (act[e]) { mn = fminf(mn, sp[e]); anynan |= sp[e] != sp[e]; }
+            mn = wave_min(mn);
+            if (__builtin_amdgcn_ballot_w64(anynan) != 0) mn = __builtin_nanf("");
+            double sy = 0, sx = 0, sum = 0;
+            double v[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                v[e] = act[e] ? (double)(float)(sp[e] - mn) : 0.0;
+                sy += v[e] * (double)ri[e];
+                sx += v[e] * (double)rj[e];
+                sum += v[e];
+            }
+            sy = wave_sum_d(sy); sx = wave_sum_d(sx); sum = wave_sum_d(sum);
+            if (sum <= 0.0) { sum = 0.01; sy = (size - 1) / 2.0; sx = (size - 1) / 2.0; }
+            else { sy /= sum; sx /= sum; }
+            float t1 = (float)sy, t0 = (float)sx;
+            const float t2 = (float)(1.0 > sum ? 1.0 : sum);
+            double sdy = 0, sdx = 0;
+#pragma unroll
+            for (int e = 0; e < E; e++) {
+                const double dy = (double)ri[e] - (double)t1, dx = (double)rj[e] - (double)t0;
+                sdy += v[e] * (dy * dy);
+                sdx += v[e] * (dx * dx);
+            }
+            sdy = wave_sum_d(sdy); sdx = wave_sum_d(sdx);
+            const float t5 = (float)sqrt(sdy / sum), t4 = (float)sqrt(sdx / sum);
+            t0 = t0 - (float)hsz;
+            t1 = t1 - (float)hsz;
+            x[0] = (double)t0; x[1] = (double)t1; x[2] = (double)t2; x[3] = (double)mn;
+            x[4] = (double)t4; x[5] = (double)t5;
+        }
+
+        // ---- lmdif ----
+        double a[6][E], fv[E], w4[E];
+        double R[6][6];
+        double diag[6], qtf[6], wa1[6], wa2[6], wa3[6];
+        int ipvt[6];
+        int info = 0, nfev = 1, iter = 1;
+        double par = 0, delta = 0, xnorm = 0, gnorm = 0, fnorm, fnorm1, actred, prered, dirder, ratio, pnorm;
+        residuals<E>(x, sp, ri, rj, act, size, lane, fv);
+        fnorm = enorm_rows<E>(fv, lane, 0, m);
+        for (;;) {
+            // fdjac2
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const double temp = x[j];
+                double hstep = eps * fabs(temp);
+                if (hstep == 0) hstep = eps;
+                x[j] = temp + hstep;
+                residuals<E>(x, sp, ri, rj, act, size, lane, w4);
+                x[j] = temp;
+#pragma unroll
+                for (int e = 0; e < E; e++) a[j][e] = (w4[e] - fv[e]) / hstep;
+            }
+            nfev += 6;
+            // qrfac with column pivoting: rdiag = wa1, acnorm = wa2, wa = wa3
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                wa2[j] = enorm_rows<E>(a[j], lane, 0, m);
+                wa1[j] = wa2[j];
+                wa3[j] = wa1[j];
+                ipvt[j] = j;
+            }
+            qrfac_step<E, 0>(a, wa1, wa3, ipvt, lane, m);
+            qrfac_step<E, 1>(a, wa1, wa3, ipvt, lane, m);
+            qrfac_step<E, 2>(a, wa1, wa3, ipvt, lane, m);
+            qrfac_step<E, 3>(a, wa1, wa3, ipvt, lane, m);
+            qrfac_step<E, 4>(a, wa1, wa3, ipvt, lane, m);
+            qrfac_step<E, 5>(a, wa1, wa3, ipvt, lane, m);
+            if (iter == 1) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) { diag[j] = wa2[j]; if (wa2[j] == 0) diag[j] = 1; }
+#pragma unroll
+                for (int j = 0; j < 6; j++) wa3[j] = diag[j] * x[j];
+                xnorm = enorm6(wa3);
+                delta = factor * xnorm;
+                if (delta == 0) delta = factor;
+            }
+            // (Q^T fvec)[0..6) and R
+#pragma unroll
+            for (int e = 0; e < E; e++) w4[e] = fv[e];
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const double ajj = readlane_d(a[j][0], j);
+                if (ajj != 0) {
+                    double sum = 0;
+#pragma unroll
+                    for (int e = 0; e < E; e++)
+                        if (e > 0 || lane >= j) sum += a[j][e] * w4[e];
+                    sum = wave_sum_d(sum);
+                    const double temp = -sum / ajj;
+#pragma unroll
+                    for (int e = 0; e < E; e++)
+                        if (e > 0 || lane >= j) w4[e] += a[j][e] * temp;
+                }
+                if (lane == j) a[j][0] = wa1[j];
+                qtf[j] = readlane_d(w4[0], j);
+            }
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+#pragma unroll
+                for (int i = 0; i < 6; i++) R[i][j] = (i <= j) ? readlane_d(a[j][0], i) : 0.0;
+            gnorm = 0;
+            if (fnorm != 0) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const double w2l = get6(wa2, ipvt[j]);
+                    if (w2l != 0) {
+                        double sum = 0;
+#pragma unroll
+                        for (int i = 0; i <= j; i++) sum += R[i][j] * (qtf[i] / fnorm);
+                        const double g = fabs(sum / w2l);
+                        if (g > gnorm) gnorm = g;
+                    }
+                }
+            }
+            if (gnorm <= gtol) { info = 4; break; }
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+                if (wa2[j] > diag[j]) diag[j] = wa2[j];
+            for (;;) {
+                lmpar(R, ipvt, diag, qtf, delta, par, wa1, wa2);
+#pragma unroll
+                for (int j = 0; j < 6; j++) { wa1[j] = -wa1[j]; wa2[j] = x[j] + wa1[j]; wa3[j] = diag[j] * wa1[j]; }
+                pnorm = enorm6(wa3);
+                if (iter == 1 && pnorm < delta) delta = pnorm;
+                residuals<E>(wa2, sp, ri, rj, act, size, lane, w4);
+                nfev++;
+                fnorm1 = enorm_rows<E>(w4, lane, 0, m);
+                actred = -1;
+                if (0.1 * fnorm1 < fnorm) { const double r = fnorm1 / fnorm; actred = 1 - r * r; }
+#pragma unroll
+                for (int j = 0; j < 6; j++) wa3[j] = 0;
+#pragma unroll
+                for (int j = 0; j < 6; j++) {
+                    const double temp = get6(wa1, ipvt[j]);
+#pragma unroll
+                    for (int i = 0; i <= j; i++) wa3[i] += R[i][j] * temp;
+                }
+                const double temp1 = enorm6(wa3) / fnorm, temp2 = (sqrt(par) * pnorm) / fnorm;
+                prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+                dirder = -(temp1 * temp1 + temp2 * temp2);
+                ratio = 0;
+                if (prered != 0) ratio = actred / prered;
+                if (ratio <= 0.25) {
+                    double temp = 0.5;
+                    if (actred < 0) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+                    if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+                    const double pd = pnorm / 0.1;
+                    delta = temp * (delta < pd ? delta : pd);
+                    par = par / temp;
+                } else if (par == 0 || ratio >= 0.75) {
+                    delta = pnorm / 0.5;
+                    par = 0.5 * par;
+                }
+                if (ratio >= 1e-4) {
+#pragma unroll
+                    for (int j = 0; j < 6; j++) { x[j] = wa2[j]; wa2[j] = diag[j] * x[j]; }
+#pragma unroll
+                    for (int e = 0; e < E; e++) fv[e] = w4[e];
+                    xnorm = enorm6(wa2);
+                    fnorm = fnorm1;
+                    iter++;
+                }
+                if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1) info = 1;
+                if (delta <= xtol * xnorm) info = 2;
+                if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1 && info == 2) info = 3;
+                if (info != 0) break;
+                if (nfev >= maxfev) info = 5;
+                if (fabs(actred) <= EPSMCH && prered <= EPSMCH && 0.5 * ratio <= 1) info = 6;
+                if (delta <= EPSMCH * xnorm) info = 7;
+                if (gnorm <= EPSMCH) info = 8;
+                if (info != 0) break;
+                if (ratio >= 1e-4) break;
+            }
+            if (info != 0) break;
+        }
+        if (lane < 6) p.thetas[s * 6 + lane] = (float)get6(x, lane);
+        if (lane == 0) {
+            if (p.info) p.info[s] = info;
+            if (p.nfev) p.nfev[s] = nfev;
+        }
+    }
+}
+
+template <bool FROM_MOVIE>
+static int launch(const Params &p, hipStream_t s)
+{
+    int dev = 0, cus = 256;
+    (void)hipGetDevice(&dev);
+    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int m = p.box * p.box;
+    const int e = (m + 63) / 64;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((p.N + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16));
+    dim3 grid((unsigned)blocks), block(LQ_WAVES * 64);
+    if (e <= 1) hipLaunchKernelGGL((lq_fit_kernel<1, FROM_MOVIE>), grid, block, 0, s, p);
+    else if (e <= 2) hipLaunchKernelGGL((lq_fit_kernel<2, FROM_MOVIE>), grid, block, 0, s, p);
+    else if (e <= 3) hipLaunchKernelGGL((lq_fit_kernel<3, FROM_MOVIE>), grid, block, 0, s, p);
+    else if (e <= 4) hipLaunchKernelGGL((lq_fit_kernel<4, FROM_MOVIE>), grid, block, 0, s, p);
+    else hipLaunchKernelGGL((lq_fit_kernel<7, FROM_MOVIE>), grid, block, 0, s, p);
+    PMI_HIP(hipGetLastError());
+    return PMI_OK;
+}
+
+static int check_box(int box)
+{
+    // scipy refuses m < n ("func input vector length N=6 must not exceed func output vector length M")
+    if (box < 3 || box > PMI_MAX_BOX || (box & 1) == 0) { set_error("gausslq needs an odd box in [3, %d], got %d", PMI_MAX_BOX, box); return PMI_ERR_ARG; }
+    return PMI_OK;
+}
+
+// ---- locs_from_fits (gausslq.py:404-484, :547-589) -------------------------
+// float32 array arithmetic of the reference, one rounding per operation.
+__device__ __forceinline__ float lq_precision(float photons, float s, float s_orth, float bg, int em)
+{
+    const float s2 = s * s;
+    const float sa2 = s2 + (float)(1.0 / 12.0);
+    const float sa = sqrtf(sa2);
+    const float sa_orth2 = s_orth * s_orth + (float)(1.0 / 12.0);
+    const float sa_orth = sqrtf(sa_orth2);
+    float v = (float)(8.0 * 3.141592653589793) * sa;
+    v = v * sa_orth;
+    v = v * bg;
+    v = v / photons;
+    v = (float)(16.0 / 9.0) + v;
+    v = sa2 * v;
+    v = v / photons;
+    if (em) v = v * 2.0f;
+    return sqrtf(v);
+}
+
+struct LqCols { void *c[PMI_LQ_COLUMNS]; };
+__global__ void locs_from_fits_lq_kernel(const int32_t *__restrict__ frame, const int32_t *__restrict__ y,
+                                         const int32_t *__restrict__ x, const float *__restrict__ ng,
+                                         const float *__restrict__ th, int64_t N, const int64_t *__restrict__ d_n,
+                                         int em, LqCols cols)
+{
+    int64_t n = N;
+    if (d_n) { const int64_t dn = *d_n; n = dn < n ? dn : n; }
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float *t = th + i * 6;
+    ((uint32_t *)cols.c[0])[i] = (uint32_t)frame[i];
+    ((float *)cols.c[1])[i] = (float)((double)t[0] + (double)x[i]);
+    ((float *)cols.c[2])[i] = (float)((double)t[1] + (double)y[i]);
+    ((float *)cols.c[3])[i] = t[2];
+    ((float *)cols.c[4])[i] = t[4];
+    ((float *)cols.c[5])[i] = t[5];
+    ((float *)cols.c[6])[i] = t[3];
+    ((float *)cols.c[7])[i] = lq_precision(t[2], t[4], t[5], t[3], em);
+    ((float *)cols.c[8])[i] = lq_precision(t[2], t[5], t[4], t[3], em);
+    const float a = np_maxf(t[4], t[5]), b = np_minf(t[4], t[5]);
+    ((float *)cols.c[9])[i] = (a - b) / a;
+    ((float *)cols.c[10])[i] = ng[i];
+}
+
+}  // namespace lq
+
+int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X, int box, double min_ng,
+                  const int64_t *roi4, int64_t f_lo, int64_t f_hi, int64_t label_offset,
+                  int32_t *d_frame, int32_t *d_y, int32_t *d_x, float *d_ng, int64_t cap, int64_t *d_out_n,
+                  hipStream_t s);
+
+}  // namespace pmi
+
+extern "C" {
+
+int pmi_gausslq_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box, float *d_thetas,
+                    int32_t *d_info, int32_t *d_nfev, void *stream)
+{
+    using namespace pmi;
+    int rc = lq::check_box(box);
+    if (rc != PMI_OK) return rc;
+    if (N <= 0) return PMI_OK;
+    lq::Params p = {};
+    p.spots = d_spots; p.N = N; p.d_n = d_n; p.box = box; p.thetas = d_thetas; p.info = d_info; p.nfev = d_nfev;
+    ScopedKernelTimer tm((hipStream_t)stream, &g_last_times.fit_ms);
+    rc = lq::launch<false>(p, (hipStream_t)stream);
+    tm.stop();
+    return rc;
+}
+
+int pmi_gausslq_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
+                          const int32_t *d_frame, const int32_t *d_y, const int32_t *d_x, int64_t N,
+                          const int64_t *d_n, int box, double baseline, double sensitivity, double gain,
+                          float *d_thetas, int32_t *d_info, int32_t *d_nfev, void *stream)
+{
+    (void)F;
+    using namespace pmi;
+    int rc = lq::check_box(box);
+    if (rc != PMI_OK) return rc;
+    if (dtype < 0 || dtype > PMI_F32) { set_error("unknown dtype code %d", dtype); return PMI_ERR_ARG; }
+    if (N <= 0) return PMI_OK;
+    lq::Params p = {};
+    p.movie = d_movie; p.dtype = dtype; p.Y = Y; p.X = X; p.frame = d_frame; p.y = d_y; p.x = d_x;
+    p.baseline = (float)baseline; p.sensitivity = (float)sensitivity; p.gain = (float)gain;
+    p.N = N; p.d_n = d_n; p.box = box; p.thetas = d_thetas; p.info = d_info; p.nfev = d_nfev;
+    ScopedKernelTimer tm((hipStream_t)stream, &g_last_times.fit_ms);
+    rc = lq::launch<true>(p, (hipStream_t)stream);
+    tm.stop();
+    return rc;
+}
+
+int pmi_gausslq(const float *spots, int64_t N, int box, float *thetas, int32_t *info, int32_t *nfev)
+{
+    using namespace pmi;
+    if (pmi_device_count() < 1) { set_error("no HIP device"); return PMI_ERR_NODEVICE; }
+    int rc = lq::check_box(box);
+    if (rc != PMI_OK) return rc;
+    if (N == 0) return PMI_OK;
+    if (!spots || !thetas) { set_error("null pointer"); return PMI_ERR_ARG; }
+    void *d_in = nullptr, *d_out = nullptr;
+    const size_t in_bytes = (size_t)N * box * box * sizeof(float);
+    if ((rc = scratch(SCR_STAGE_A, in_bytes, &d_in)) != PMI_OK) return rc;
+    if ((rc = scratch(SCR_STAGE_B, (size_t)N * 8 * 4, &d_out)) != PMI_OK) return rc;
+    float *d_th = (float *)d_out;
+    int32_t *d_info = (int32_t *)(d_th + N * 6), *d_nfev = d_info + N;
+    PMI_HIP(hipMemcpy(d_in, spots, in_bytes, hipMemcpyHostToDevice));
+    rc = pmi_gausslq_dev((const float *)d_in, N, nullptr, box, d_th, d_info, d_nfev, nullptr);
+    if (rc != PMI_OK) return rc;
+    PMI_HIP(hipMemcpy(thetas, d_th, (size_t)N * 24, hipMemcpyDeviceToHost));
+    if (info) PMI_HIP(hipMemcpy(info, d_info, (size_t)N * 4, hipMemcpyDeviceToHost));
+    if (nfev) PMI_HIP(hipMemcpy(nfev, d_nfev, (size_t)N * 4, hipMemcpyDeviceToHost));
+    return PMI_OK;
+}
+
+int pmi_locs_from_fits_lq_dev(const int32_t *d_frame, const int32_t *d_y, const int32_t *d_x, const float *d_ng,
+                              const float *d_thetas, int64_t N, const int64_t *d_n, int em, void *const *d_cols,
+                              void *stream)
+{
+    using namespace pmi;
+    if (N <= 0) return PMI_OK;
+    lq::LqCols cols;
+    for (int c = 0; c < PMI_LQ_COLUMNS; c++) cols.c[c] = d_cols[c];
+    const unsigned blocks = (unsigned)((N + 255) / 256);
+    hipLaunchKernelGGL(lq::locs_from_fits_lq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_frame, d_y,
+                       d_x, d_ng, d_thetas, N, d_n, em, cols);
+    PMI_HIP(hipGetLastError());
+    return PMI_OK;
+}
+
+int pmi_localize_lq_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X, int box, double min_ng,
+                        const int64_t *roi4, int64_t f_lo, int64_t f_hi, double baseline, double sensitivity,
+                        double gain, int em, void *d_table, int64_t cap, int64_t *d_out_n, void *stream)
+{
+    using namespace pmi;
+    if (cap <= 0) { set_error("capacity must be positive"); return PMI_ERR_ARG; }
+    int rc = lq::check_box(box);
+    if (rc != PMI_OK) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    void *ptr = nullptr;
+    if ((rc = scratch(SCR_IDS, (size_t)cap * (16 + 6 * 4), &ptr)) != PMI_OK) return rc;
+    int32_t *d_f = (int32_t *)ptr, *d_y = d_f + cap, *d_x = d_y + cap;
+    float *d_ng = (float *)(d_x + cap);
+    float *d_th = d_ng + cap;
+    rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, f_lo, f_hi, 0, d_f, d_y, d_x, d_ng, cap, d_out_n, s);
+    if (rc != PMI_OK) return rc;
+    rc = pmi_gausslq_movie_dev(d_movie, dtype, F, Y, X, d_f, d_y, d_x, cap, d_out_n, box, baseline, sensitivity,
+                               gain, d_th, nullptr, nullptr, stream);
+    if (rc != PMI_OK) return rc;
+    void *cols[PMI_LQ_COLUMNS];
+    for (int c = 0; c < PMI_LQ_COLUMNS; c++) cols[c] = (char *)d_table + (size_t)c * cap * 4;
+    return pmi_locs_from_fits_lq_dev(d_f, d_y, d_x, d_ng, d_th, cap, d_out_n, em, cols, stream);
+}
+
+}  // extern "C"

@@ -2,17 +2,59 @@
 
 ``localization_precision`` (picasso/gausslq.py:547-589, Mortensen et al. 2010 with
 the diagonal-covariance correction), ``sigma_uncertainty`` (:592-633) and
-``locs_from_fits`` (:404-484).  The least-squares fit itself (scipy MINPACK lmdif,
-:206-244) has no HIP kernel yet; ``fit_spots`` raises instead of falling back.
+``locs_from_fits`` (:404-484) on the host, and ``fit_spots`` / ``fit_spots_parallel``
+(:247-401): the per-spot scipy.optimize.leastsq of the reference (MINPACK lmdif,
+:206-244) runs as one HIP kernel over all spots (csrc/gausslq.hip).
 """
 from __future__ import annotations
 
 import numpy as np
 import pandas as pd
 
+from . import backend
+
 
 def fit_spots(spots, progress_callback=None):
-    raise NotImplementedError("gausslq.fit_spots has no HIP kernel yet in picasso_amd; there is no CPU fallback")
+    """theta (N, 6) float32 = x, y, photons, bg, sx, sy; x, y relative to the box
+    centre (picasso/gausslq.py:247-268).  One kernel launch fits every spot, so a
+    callable progress_callback is called once, when the fit is done."""
+    theta = backend.gausslq_arrays(spots)
+    if callable(progress_callback) and len(theta):
+        progress_callback(len(theta) - 1)     # the reference reports the index of the last fitted spot
+    return theta
+
+
+def fit_spot(spot):
+    """One spot (picasso/gausslq.py:206-244); float64 like leastsq's result."""
+    return backend.gausslq_arrays(np.asarray(spot, np.float32)[None])[0].astype(np.float64)
+
+
+class _DoneFuture:
+    """concurrent.futures-shaped result holder for fit_spots_parallel(asynch=True)."""
+
+    def __init__(self, value):
+        self._value = value
+
+    def done(self):
+        return True
+
+    def result(self, timeout=None):
+        return self._value
+
+
+def fit_spots_parallel(spots, asynch: bool = False):
+    """picasso/gausslq.py:271-314.  The reference splits the spots over a process
+    pool; here the GPU fits them all in one call.  With asynch=True a list holding
+    one finished future is returned (the shape fits_from_futures expects)."""
+    theta = fit_spots(spots)
+    if asynch:
+        return [_DoneFuture(theta)]
+    return theta
+
+
+def fits_from_futures(futures):
+    """picasso/gausslq.py:317-333."""
+    return np.vstack([f.result() for f in futures])
 
 
 def localization_precision(photons, s, s_orth, bg, em: bool):

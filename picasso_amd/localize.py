@@ -17,7 +17,7 @@ from typing import Callable, Literal
 import numpy as np
 import pandas as pd
 
-from . import __version__, avgroi, backend, gaussmle
+from . import __version__, avgroi, backend, gausslq, gaussmle
 
 _CHUNK_BYTES = 1 << 30      # movie bytes per device call = progress / abort granularity
 FITTING_METHODS = ["gausslq", "gausslq-gpu", "gaussmle", "avg"]
@@ -222,6 +222,15 @@ def _fit2d_gaussmle(spots, identifications, box, eps=0.001, max_it=100, mle_meth
     return gaussmle.locs_from_fits(identifications, thetas, CRLBs, llhoods, iterations, box)
 
 
+def _fit2d_gausslq(spots, identifications, box, em, multiprocess=True, progress_callback=None, abort_callback=None):
+    """picasso/localize.py:1509-1538.  The fit is one kernel launch, so the abort
+    callback is polled once before it."""
+    if callable(abort_callback) and abort_callback():
+        return None
+    theta = gausslq.fit_spots(spots, progress_callback if callable(progress_callback) else None)
+    return gausslq.locs_from_fits(identifications, theta, box, em)
+
+
 def fit2D(movie, movie_info, camera_info: dict, identifications: pd.DataFrame, box: int,
           fitting_method: Literal["gausslq", "gausslq-gpu", "gaussmle", "avg"] = "gausslq", eps: float = 0.001,
           max_it: int = 100, mle_method: Literal["sigma", "sigmaxy"] = "sigmaxy", multiprocess: bool = True,
@@ -243,13 +252,15 @@ def fit2D(movie, movie_info, camera_info: dict, identifications: pd.DataFrame, b
                       "camera pixel size in nm. Assuming 130.")
         camera_info["Pixelsize"] = 130
 
-    if fitting_method not in ("gaussmle", "avg"):
+    if fitting_method == "gausslq-gpu":
         raise NotImplementedError(
-            f"fitting_method={fitting_method!r} has no HIP kernel yet in picasso_amd (only 'gaussmle' and 'avg'); "
-            "there is no CPU fallback — use the reference for this method")
+            "fitting_method='gausslq-gpu' is the reference's CUDA Gpufit binding (a different, float32 "
+            "Levenberg-Marquardt); picasso_amd has no equivalent — 'gausslq' already runs on the GPU here")
     spots = get_spots(movie, identifications, box, camera_info)
     em = camera_info["Gain"] > 1
-    if fitting_method == "gaussmle":
+    if fitting_method == "gausslq":
+        locs = _fit2d_gausslq(spots, identifications, box, em, multiprocess, progress_callback, abort_callback)
+    elif fitting_method == "gaussmle":
         locs = _fit2d_gaussmle(spots, identifications, box, eps, max_it, mle_method, multiprocess,
                                progress_callback, abort_callback)
     else:
@@ -295,15 +306,24 @@ def localize(movie, camera_info: dict, parameters: dict, *, roi=None, frame_boun
 
 
 def localize_resident(movie: np.ndarray, camera_info: dict, parameters: dict, *, roi=None, frame_bounds=None,
-                      eps: float = 0.001, max_it: int = 100, mle_method: str = "sigmaxy") -> pd.DataFrame:
+                      fitting_method: str = "gaussmle", eps: float = 0.001, max_it: int = 100,
+                      mle_method: str = "sigmaxy") -> pd.DataFrame:
     """The fused device pipeline (identify -> cut+fit -> table, one submission, no
     host round trip) for a movie that fits in HBM.  Same table as ``localize`` with
-    ``fitting_method="gaussmle"``; this is what bench.py times."""
+    the same ``fitting_method`` ("gaussmle" or "gausslq"); the gaussmle form is what
+    bench.py times."""
+    if fitting_method not in ("gaussmle", "gausslq"):
+        raise ValueError("localize_resident supports fitting_method 'gaussmle' or 'gausslq'")
     dm = backend.DeviceMovie(movie)
     try:
-        cols = backend.localize_mle_device(dm.ptr, dm.dtype, dm.shape, parameters["Box Size"],
-                                           parameters["Min. Net Gradient"], camera_info, eps, max_it, mle_method,
-                                           roi=roi, frame_bounds=frame_bounds)
+        if fitting_method == "gausslq":
+            cols = backend.localize_lq_device(dm.ptr, dm.dtype, dm.shape, parameters["Box Size"],
+                                              parameters["Min. Net Gradient"], camera_info, roi=roi,
+                                              frame_bounds=frame_bounds)
+        else:
+            cols = backend.localize_mle_device(dm.ptr, dm.dtype, dm.shape, parameters["Box Size"],
+                                               parameters["Min. Net Gradient"], camera_info, eps, max_it, mle_method,
+                                               roi=roi, frame_bounds=frame_bounds)
     finally:
         dm.free()
     return pd.DataFrame(cols)

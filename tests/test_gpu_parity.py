@@ -227,3 +227,101 @@ def test_identify_capacity_retry(be, orc, testdata_movie):
     b = orc.identify(mov, -1e9, 3, threads=4)
     assert len(a[0]) == len(b[0]) > 4096
     assert all(np.array_equal(p, q) for p, q in zip(a, b))
+
+
+# ---------------------------------------------------------------------------
+# gausslq: MINPACK lmdif per spot (picasso/gausslq.py:206-300)
+# ---------------------------------------------------------------------------
+def _check_lq(th, info, nfev, oth, oinfo, onfev, exact_frac=0.98):
+    """The kernel follows the oracle's float64 lmdif operation by operation except for the
+    order of the sums over the box; theta (float32) must coincide to the last bit for nearly
+    every spot and stay inside the north-star tolerance for all of them."""
+    assert th.shape == oth.shape
+    exact = np.all((th == oth) | (np.isnan(th) & np.isnan(oth)), axis=1)
+    assert exact.mean() >= exact_frac, f"only {exact.mean():.4f} bit-identical"
+    assert (info == oinfo).mean() >= exact_frac and (nfev == onfev).mean() >= exact_frac
+    fin = np.all(np.isfinite(oth), axis=1)
+    assert np.max(np.abs(th[fin][:, [0, 1, 4, 5]] - oth[fin][:, [0, 1, 4, 5]]), initial=0) < 1e-3
+    rel = np.abs(th[fin][:, 2:4] - oth[fin][:, 2:4]) / np.maximum(np.abs(oth[fin][:, 2:4]), 1.0)
+    assert np.max(rel, initial=0) < 1e-3
+
+
+@pytest.mark.parametrize("name", ["conftest_clean", "conftest_noisy", "testdata_real", "poisson7", "poisson13"])
+def test_gausslq_vs_oracle_and_goldens(be, orc, name):
+    g = golden("gausslq_" + name)
+    th, info, nfev = be.gausslq_arrays(g["spots"], full_output=True)
+    oth, oinfo, onfev = orc.gausslq(g["spots"], full=True, threads=4)
+    _check_lq(th, info, nfev, oth, oinfo, onfev)
+    # the reference's own output (float32 start values, scipy MINPACK): what ftol = xtol = 1e-2 leaves open
+    assert np.max(np.abs(th[:, :2] - g["theta"][:, :2])) < 5e-3
+    assert np.max(np.abs(th[:, 4:] - g["theta"][:, 4:])) < 5e-3
+    assert np.max(np.abs(th[:, 2] - g["theta"][:, 2]) / g["theta"][:, 2]) < 5e-3
+
+
+@pytest.mark.parametrize("box", [3, 5, 7, 9, 11, 13, 15, 17, 19, 21])
+def test_gausslq_all_boxes_vs_oracle(be, orc, box):
+    rng = np.random.default_rng(100 + box)
+    n, c = 128, box // 2
+    idx = np.arange(box) - c
+    spots = np.empty((n, box, box), np.float32)
+    for i in range(n):
+        x0, y0 = rng.uniform(-0.8, 0.8, 2)
+        sx, sy = rng.uniform(0.7, max(0.8, 0.22 * box), 2)
+        gx = np.exp(-0.5 * ((idx - x0) / sx) ** 2) / (np.sqrt(2 * np.pi) * sx)
+        gy = np.exp(-0.5 * ((idx - y0) / sy) ** 2) / (np.sqrt(2 * np.pi) * sy)
+        spots[i] = rng.poisson(rng.uniform(800, 9000) * np.outer(gy, gx) + rng.uniform(2, 40))
+    th, info, nfev = be.gausslq_arrays(spots, full_output=True)
+    oth, oinfo, onfev = orc.gausslq(spots, full=True, threads=4)
+    _check_lq(th, info, nfev, oth, oinfo, onfev, exact_frac=0.97)
+
+
+def test_gausslq_edge_cases(be, orc):
+    assert be.gausslq_arrays(np.zeros((0, 7, 7), np.float32)).shape == (0, 6)
+    from picasso_amd import _lib
+    with pytest.raises(_lib.HipBackendError, match="odd box"):
+        be.gausslq_arrays(np.zeros((1, 4, 4), np.float32))
+    # flat, empty and single-pixel spots: the sum <= 0 branch of the start values, zero Jacobian columns
+    spots = np.zeros((6, 7, 7), np.float32)
+    spots[1] += 5.0
+    spots[2, 3, 3] = 100.0
+    spots[3, 0, 0] = 1e6
+    spots[4] = np.arange(49, dtype=np.float32).reshape(7, 7)
+    spots[5] = -3.0
+    th, info, nfev = be.gausslq_arrays(spots, full_output=True)
+    oth, oinfo, onfev = orc.gausslq(spots, full=True)
+    assert np.array_equal(info, oinfo) and np.array_equal(nfev, onfev)
+    assert np.allclose(th, oth, rtol=1e-5, atol=1e-6, equal_nan=True)
+    # a NaN pixel must terminate (maxfev) and not poison its neighbours
+    bad = golden("gausslq_poisson7")["spots"][:3].copy()
+    bad[1, 2, 2] = np.nan
+    th = be.gausslq_arrays(bad)
+    good = orc.gausslq(bad[[0, 2]])
+    assert np.array_equal(th[[0, 2]], good)
+
+
+def test_localize_lq_pipeline_on_resident_movie(be, orc, testdata_movie):
+    """identify -> fused cut + lmdif -> 11-column table on device vs oracle fit + host table."""
+    import pandas as pd
+    from picasso_amd import gausslq
+    for gain in (1.0, 2.0):
+        cam = {"Baseline": 100.0, "Sensitivity": 0.5, "Gain": gain}
+        dm = be.DeviceMovie(testdata_movie)
+        try:
+            t = be.localize_lq_device(dm.ptr, dm.dtype, dm.shape, 7, 1500, cam)
+        finally:
+            dm.free()
+        fr, y, x, ng = orc.identify(testdata_movie, 1500, 7)
+        spots = orc.get_spots(testdata_movie, fr, y, x, 7, cam)
+        oth = orc.gausslq(spots, threads=4)
+        ids = pd.DataFrame({"frame": fr, "x": x, "y": y, "net_gradient": ng})
+        ref = gausslq.locs_from_fits(ids, oth, 7, em=gain > 1)
+        assert list(t) == list(ref.columns)
+        assert np.array_equal(t["frame"], ref["frame"].to_numpy())
+        assert np.array_equal(t["net_gradient"], ref["net_gradient"].to_numpy())
+        same = np.all(np.stack([t[c] == ref[c].to_numpy() for c in ("x", "y", "photons", "sx", "sy", "bg")]), axis=0)
+        assert same.mean() > 0.98
+        for c in ("lpx", "lpy", "ellipticity"):
+            a, b = t[c][same], ref[c].to_numpy()[same]
+            assert np.allclose(a, b, rtol=3e-7, atol=0, equal_nan=True), c
+        assert np.max(np.abs(t["x"] - ref["x"].to_numpy())) < 1e-3
+        assert np.max(np.abs(t["y"] - ref["y"].to_numpy())) < 1e-3

@@ -109,10 +109,18 @@ def test_fit2d_missing_pixelsize_warns_then_fails_loudly_without_gpu(testdata_mo
 
 
 def test_methods_without_a_kernel_raise_not_implemented(testdata_movie):
+    """'gausslq-gpu' is the reference's CUDA Gpufit binding: refused, never silently rerouted."""
     a = _fit2d_args(_Movie(testdata_movie))
-    for m in ("gausslq", "gausslq-gpu"):
-        with pytest.raises(NotImplementedError, match="no HIP kernel yet"):
-            localize.fit2D(**a, fitting_method=m)
+    with pytest.raises(NotImplementedError, match="Gpufit"):
+        localize.fit2D(**a, fitting_method="gausslq-gpu")
+
+
+def test_gausslq_fails_loudly_without_gpu(testdata_movie):
+    from picasso_amd import _lib, gausslq
+    if _lib.device_count() > 0:
+        pytest.skip("GPU present")
+    with pytest.raises(_lib.HipBackendError):
+        gausslq.fit_spots(np.ones((2, 7, 7), np.float32))
 
 
 def test_identify_deprecation_and_abort(testdata_movie):

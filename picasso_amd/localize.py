@@ -329,7 +329,7 @@ def localize_resident(movie: np.ndarray, camera_info: dict, parameters: dict, *,
     return pd.DataFrame(cols)
 
 
-def install(picasso_localize=None, picasso_gaussmle=None) -> None:
+def install(picasso_localize=None, picasso_gaussmle=None, picasso_gausslq=None) -> None:
     """Rebind the reference package's hot-path functions to this backend, so that
     picasso.__main__ and the GUI run on the GPU unchanged."""
     if picasso_localize is None:
@@ -341,5 +341,14 @@ def install(picasso_localize=None, picasso_gaussmle=None) -> None:
     for name in ("identify", "identify_by_frame_number", "identify_in_frame", "identify_in_image", "get_spots"):
         setattr(picasso_localize, name, getattr(me, name))
     picasso_localize._fit2d_gaussmle = _fit2d_gaussmle
+    picasso_localize._fit2d_gausslq = _fit2d_gausslq
     for name in ("gaussmle", "gaussmle_async"):
         setattr(picasso_gaussmle, name, getattr(gaussmle, name))
+    if picasso_gausslq is None:
+        try:
+            import picasso.gausslq as picasso_gausslq
+        except ImportError:
+            picasso_gausslq = None
+    if picasso_gausslq is not None:
+        for name in ("fit_spot", "fit_spots", "fit_spots_parallel", "fits_from_futures"):
+            setattr(picasso_gausslq, name, getattr(gausslq, name))

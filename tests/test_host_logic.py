@@ -193,3 +193,15 @@ def test_zfit_argument_checks():
         zfit.zfit(locs, [{"Pixelsize": 130}], calibration={"X Coefficients": [0] * 7})
     with pytest.raises(AssertionError, match="pixel size"):
         zfit.zfit(locs, [{}], calibration={"Magnification factor": 0.8})
+
+
+def test_install_rebinds_the_reference_functions():
+    """localize.install() on stand-in module objects."""
+    import types
+    from picasso_amd import gausslq, gaussmle as amd_mle
+    pl, pm, pq = types.SimpleNamespace(), types.SimpleNamespace(), types.SimpleNamespace()
+    localize.install(pl, pm, pq)
+    assert pl.identify is localize.identify and pl.get_spots is localize.get_spots
+    assert pl._fit2d_gaussmle is localize._fit2d_gaussmle and pl._fit2d_gausslq is localize._fit2d_gausslq
+    assert pm.gaussmle is amd_mle.gaussmle and pm.gaussmle_async is amd_mle.gaussmle_async
+    assert pq.fit_spots is gausslq.fit_spots and pq.fit_spots_parallel is gausslq.fit_spots_parallel

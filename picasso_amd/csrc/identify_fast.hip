@@ -17,14 +17,16 @@
 //     v >= max(R, U[r'+h]); the first half is folded into pre = max(sat(bef+1), R)
 //     at row r', the second is tested h rows later: sat(max(pre, U) - v) == 0;
 //   * candidates (~2 % of pixels on shot noise) go to a per-wave LDS list; a range
-//     bound |ng| <= C_box * (max - min over the band-local 24-column neighbourhood)
+//     bound |ng| <= P_box * (max - min over statistics cells covering the stencil)
 //     rejects the ones that cannot reach min_ng without touching memory again; the
 //     survivors get the exact float32 net gradient in the reference's (k,l) order.
 //
 // HBM traffic: every pixel is fetched once per band plus 2(h+2) halo rows
 // (RB = 64: +12.5 %, absorbed by L2/MALL because a frame's bands run on one XCD).
 #include <algorithm>
+#include <cmath>
 #include <cstdlib>
+#include <vector>
 
 #include "pmi_common.h"
 
@@ -38,6 +40,23 @@ namespace pmi {
 static __device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
 static __device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
 static __device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
+
+// float32 sqrt of 0..32 (the squared lengths that occur for box <= 9), correctly rounded; the host
+// checks them against sqrtf before the first launch (unit_vectors_match).
+constexpr float SQRT_F32[33] = {
+    0x0.0p+0f, 0x1.000000p+0f, 0x1.6a09e6p+0f, 0x1.bb67aep+0f, 0x1.000000p+1f, 0x1.1e377ap+1f, 0x1.3988e2p+1f,
+    0x1.52a7fap+1f, 0x1.6a09e6p+1f, 0x1.800000p+1f, 0x1.94c584p+1f, 0x1.a8872ap+1f, 0x1.bb67aep+1f, 0x1.cd82b4p+1f,
+    0x1.deeea2p+1f, 0x1.efbdecp+1f, 0x1.000000p+2f, 0x1.07e0f6p+2f, 0x1.0f876cp+2f, 0x1.16f834p+2f, 0x1.1e377ap+2f,
+    0x1.2548ecp+2f, 0x1.2c2fc6p+2f, 0x1.32eee8p+2f, 0x1.3988e2p+2f, 0x1.400000p+2f, 0x1.465656p+2f, 0x1.4c8dc2p+2f,
+    0x1.52a7fap+2f, 0x1.58a68ap+2f, 0x1.5e8adep+2f, 0x1.645640p+2f, 0x1.6a09e6p+2f};
+// unit vectors of picasso/localize.py:279-286 as compile-time float32 constants:
+// ux[k][l] = (H - l) / |(H - l, H - k)|, uy[k][l] = (H - k) / |...|  (float32 sqrt and divide)
+template <int H> constexpr float unit_x(int k, int l)
+{
+    const int vx = H - l, vy = H - k;
+    return (vx == 0 && vy == 0) ? 0.0f : (float)vx / SQRT_F32[vx * vx + vy * vy];
+}
+template <int H> constexpr float unit_y(int k, int l) { return unit_x<H>(l, k); }
 
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32;
@@ -76,7 +95,8 @@ struct FastParams {
     int bands, segs, bpf;      // bands per frame, 512-col segments per row, blocks per frame
     int box;
     double min_ng;
-    double bound_c;            // C_box: sum over the window of |ux|+|uy|, with margin
+    double bound_c;            // P_box: sum of the positive stencil weights, with margin
+    int dbg;
 };
 
 constexpr int FAST_WAVES = 4;
@@ -118,35 +138,60 @@ __device__ __forceinline__ u32 from_lane_below(u32 v, u32 edge) { return (u32)__
 __device__ __forceinline__ u32 from_lane_above(u32 v, u32 edge) { return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
 
 // Exact float32 net gradient of one candidate whose stencil does not wrap, in the reference's
-// (k, l) order, from a sliding three-row register window (each pixel is loaded once).
-template <int H>
-__device__ __forceinline__ float exact_ng_noWrap(const uint16_t *__restrict__ src, int64_t X, int i, int j,
-                                                 const float *__restrict__ sux, const float *__restrict__ suy)
+// (k, l) order.  The (2H+3)^2 neighbourhood is fetched as packed pixel pairs (one wide load + one
+// 2-byte load per row) in two batches of rows whose loads are all in flight together: the rows
+// have usually left L2 by now and a row-by-row loop pays the memory latency 2H+1 times, while
+// holding all 2H+3 rows at once does not fit the register budget of four waves per SIMD.
+// The rows are only 2-byte aligned; gfx950 runs global loads in unaligned mode.
+template <int H, int K0, int K1>
+__device__ __forceinline__ float exact_ng_rows(const uint16_t *__restrict__ base, int64_t X, float ng)
 {
-    constexpr int BOX = 2 * H + 1, W = 2 * H + 3;
-    const uint16_t *base = src + (int64_t)(i - H - 1) * X + (j - H - 1);
-    float rowA[W], rowB[W], rowC[W];      // rows k, k+1, k+2 of the (2H+3)^2 neighbourhood
+    constexpr int BOX = 2 * H + 1, W = 2 * H + 3, NP = (W - 1) / 2;   // W is odd: NP pairs + one single pixel
+    constexpr int R0 = K0, NR = K1 - K0 + 2;                           // window rows K0..K1-1 need neighbourhood rows K0..K1+1
+    struct __attribute__((packed, aligned(2))) Pairs { u32 v[NP]; };
+    u32 pk[NR][NP];
+    u32 last[NR];
 #pragma unroll
-    for (int b = 0; b < W; b++) { rowA[b] = (float)base[b]; rowB[b] = (float)base[X + b]; }
-    float ng = 0.0f;
-#pragma unroll 1                               // rolled: a fully unrolled body keeps ~160 VGPRs live and costs a wave of occupancy
-    for (int k = 0; k < BOX; k++) {
-        const uint16_t *rc = base + (int64_t)(k + 2) * X;
+    for (int r = 0; r < NR; r++) {
+        const uint16_t *row = base + (int64_t)(R0 + r) * X;
+        const Pairs t = *reinterpret_cast<const Pairs *>(row);
 #pragma unroll
-        for (int b = 0; b < W; b++) rowC[b] = (float)rc[b];
-        const float *cy_ = suy + k * BOX, *cx_ = sux + k * BOX;
+        for (int q = 0; q < NP; q++) pk[r][q] = t.v[q];
+        last[r] = row[W - 1];
+    }
+    auto px = [&](int r, int b) -> float {
+        r -= R0;
+        if (b == W - 1) return (float)last[r];
+        return (float)((b & 1) ? (pk[r][b >> 1] >> 16) : (pk[r][b >> 1] & 0xffffu));
+    };
+#pragma unroll
+    for (int k = K0; k < K1; k++) {
 #pragma unroll
         for (int l = 0; l < BOX; l++) {
-            // window pixel (k, l) sits at neighbourhood (k+1, l+1): rowB[l+1]
-            float gy = sub_rn(rowC[l + 1], rowA[l + 1]);
-            float gx = sub_rn(rowB[l + 2], rowB[l]);
-            float sacc = add_rn(mul_rn(gy, cy_[l]), mul_rn(gx, cx_[l]));
-            ng = (k == H && l == H) ? ng : add_rn(ng, sacc);      // the centre is skipped (its unit vector is 0/0)
+            if (k == H && l == H) continue;                        // the centre is skipped (its unit vector is 0/0)
+            // window pixel (k, l) sits at neighbourhood (k+1, l+1); the unit vectors are literals
+            const float cy = unit_y<H>(k, l), cx = unit_x<H>(k, l);
+            const float gy = sub_rn(px(k + 2, l + 1), px(k, l + 1));
+            const float gx = sub_rn(px(k + 1, l + 2), px(k + 1, l));
+            // A zero component contributes +-0, which never changes the float32 sum (ng starts at +0
+            // and x + (-0) == x): the product with it is dropped instead of computed.
+            const float sacc = cy == 0.0f ? mul_rn(gx, cx) : (cx == 0.0f ? mul_rn(gy, cy) : add_rn(mul_rn(gy, cy), mul_rn(gx, cx)));
+            ng = add_rn(ng, sacc);
         }
-#pragma unroll
-        for (int b = 0; b < W; b++) { rowA[b] = rowB[b]; rowB[b] = rowC[b]; }
     }
     return ng;
+}
+
+template <int H>
+__device__ __forceinline__ float exact_ng_noWrap(const uint16_t *__restrict__ src, int64_t X, int i, int j, int p_dbg)
+{
+    constexpr int BOX = 2 * H + 1, KM = (BOX + 1) / 2;
+    const uint16_t *base = src + (int64_t)(i - H - 1) * X + (((p_dbg & 4) ? ((j - H - 1) & ~7) : (j - H - 1)));
+    float ng = exact_ng_rows<H, 0, KM>(base, X, 0.0f);
+    // the second batch starts only when the first sum is done (keeps its loads from being hoisted
+    // above the first batch, which would double the live registers)
+    asm volatile("" : "+v"(ng), "+v"(base));
+    return exact_ng_rows<H, KM, BOX>(base, X, ng);
 }
 
 template <int H, int RB, int D>
@@ -156,27 +201,35 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
 {
     constexpr int BOX = 2 * H + 1;
     constexpr int HR = H > 1 ? H - 1 : 1;                 // Hrow ring length (unused when H == 1)
-    constexpr int U_ = (H == 1) ? 2 : H * (H - 1);         // unroll period of both rings
+    constexpr int U_ = (H <= 2) ? 4 : H * (H - 1);         // unroll period: a multiple of both ring lengths
     static_assert(U_ % D == 0, "prefetch depth must divide the unroll period");
-    constexpr int GS = U_ >= 6 ? U_ : 8;                   // rows per min/max statistics group
+    constexpr int GS = U_ >= 6 ? U_ : 8;                   // rows per MIN statistics group (cells of 8 columns)
+    constexpr int GM = H <= 2 ? 2 : H;                     // rows per MAX statistics group (cells of 4 columns)
+    static_assert(U_ % GM == 0 && GS % GM == 0, "max groups close inside the unrolled body");
+    static_assert(2 * H + 2 <= 3 * GM && 2 * H + 2 <= 2 * GS, "the stored windows (4 max groups, 3 min groups) must cover the stencil rows");
     constexpr int NR = RB + 2 * H + 2;                     // pipeline rows: band + H halo + 1 stats row each side
     constexpr int NRP = ((NR + GS - 1) / GS) * GS;
-    constexpr int NG = NRP / GS;
+    constexpr int NG = NRP / GS, NGM = NRP / GM;
     // Local maxima are > H apart, so a band holds at most RB*512/(H+1)^2 of them; shot noise gives ~1/(2H+1)^2
     // per pixel.  The list is sized at 3/4 of the geometric bound (4 workgroups per CU fit in LDS);
     // a denser band takes the exact rescan path below.
-    constexpr int LIST = (RB * 512 / ((H + 1) * (H + 1))) * 3 / 4;
+    constexpr int LIST_GEO = (RB * 512 / ((H + 1) * (H + 1))) * 3 / 4;
+    constexpr int LIST = LIST_GEO < 1024 ? LIST_GEO : 1024;
     static_assert(RB <= 128, "list entries keep the row in 7 bits");
 
     __shared__ unsigned short s_list[FAST_WAVES][LIST];   // (row - band_lo) << 9 | (col - 512 * seg)
-    __shared__ int s_cnt[FAST_WAVES];
-    __shared__ unsigned s_stat[FAST_WAVES][NG][64];       // (max << 16) | min of each lane's 8-column strip per row group
+    // Range statistics for the |ng| bound.  The minimum barely varies (background floor): one value
+    // per lane (8 columns) per GS rows.  The maximum is what a nearby emitter inflates, so it is kept
+    // on a finer grid: two 4-column cells per lane per GM rows (low half = left cell).  What is stored
+    // for group g is already the extreme over the window of groups ending at g (4 max groups, 3 min
+    // groups), so that a candidate's query is one entry per lane it touches instead of one per group.
+    __shared__ unsigned short s_min[FAST_WAVES][NG][64];
+    __shared__ unsigned s_max[FAST_WAVES][NGM][64];
     __shared__ float s_u[2 * BOX * BOX];
 
     const int lane = threadIdx.x & 63;
     const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id as a scalar: row addressing stays on the SALU
     for (int i = threadIdx.x; i < 2 * BOX * BOX; i += FAST_WAVES * 64) s_u[i] = uxy[i];
-    if (lane == 0) s_cnt[w] = 0;
     __syncthreads();
 
     // XCD-aware mapping: all blocks of a frame share blockIdx % 8 (= the XCD they run on)
@@ -219,12 +272,12 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
     const unsigned off_e = (unsigned)(lane == 0 ? col_l : col_r) * 2u;
     const bool edge_lane = lane == 0 || lane == 63;
     const char *frame_base = reinterpret_cast<const char *>(src);
-    const int64_t pitch = p.X * 2;
+    const unsigned pitch = (unsigned)p.X * 2u;         // X <= 65535 on this path
     // interior bands never touch a row outside the crop: no clamping in their row loop
     const bool interior = rs0 >= 0 && rs0 + NRP + D <= p.cy;
     auto load_row = [&](int r) -> RowRegs {
         const int rc = interior ? r : min(max(r, 0), p.cy - 1);
-        const char *row = frame_base + (int64_t)rc * pitch;
+        const char *row = frame_base + (uint64_t)(unsigned)rc * pitch;      // 32x32 -> 64: s_mul_i32 + s_mul_hi_u32
         RowRegs o;
         o.m = *reinterpret_cast<const uint4 *>(row + off_m);
         o.e = make_uint2(0u, 0u);
@@ -241,8 +294,12 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
 #pragma unroll
         for (int t = 0; t < H; t++) { Dv[t][q] = 0u; Dpre[t][q] = 0xffffffffu; }
     }
-    u32 mn = 0xffffffffu, mx = 0u;
+    u32 mn = 0xffffffffu, mxL = 0u, mxR = 0u;
+    u32 mprev = 0u, mpair1 = 0u, mpair2 = 0u;         // previous max group, pair maxima of groups (g-1, g-2) and (g-2, g-3)
+    u32 lo1 = 0xffffu, lo2 = 0xffffu;                 // minima of the previous two min groups
     u32 acc = 0;                                      // "failed the test" bits of up to four rows
+    int cnt = 0;                                      // candidates found so far (wave-uniform)
+    const u32 lane8 = (u32)lane << 3;
 
     RowRegs pf[D];
 #pragma unroll
@@ -261,6 +318,8 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
 #pragma unroll
             for (int k = 1; k < 8; k++) Bp[k] = __builtin_amdgcn_alignbit(A[k], A[k - 1], 16);
             mn = pk_min(pk_min(mn, pk_min(A[2], A[3])), pk_min(A[4], A[5]));
+            mxL = pk_max(mxL, pk_max(A[2], A[3]));
+            mxR = pk_max(mxR, pk_max(A[4], A[5]));
 
             u32 L[4], R[4];
             L[0] = LR<H, 2, 0>::left(A, Bp); R[0] = LR<H, 2, 0>::right(A, Bp);
@@ -272,7 +331,6 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
             for (int q = 0; q < 4; q++) {
                 const u32 v = A[q + 2];
                 const u32 hrow = pk_max(pk_max(L[q], v), R[q]);
-                if (q == 0 || q == 3) mx = pk_max(mx, hrow);   // row-window maxima of pixels 0,1 and 6,7 cover all 8 columns
                 u32 Ucur = hrow;
                 if (H > 1) {
 #pragma unroll
@@ -298,24 +356,41 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
                     if (rd0 + tt >= row_lo && rd0 + tt < row_hi) rowmask |= 0x000f000fu << (4 * tt);
                 u32 pass = ~acc & rowmask & colmask;
                 acc = 0;
-                if (pass) {
-                    int slot = atomicAdd(&s_cnt[w], __popc(pass));
-                    while (pass) {
-                        const int b = __ffs(pass) - 1;
+                // Append to the wave's own list: every round each lane that still has a candidate emits
+                // its lowest one, slots come from a ballot prefix count and the list length stays in a
+                // scalar register.  (An LDS atomicAdd per lane is turned into a serial per-lane scan by
+                // the compiler's atomic optimizer: ~9 SALU instructions per active lane, per flush.)
+                const u32 ebase = (u32)((rd0 - band_lo) << 9) + lane8;
+                for (;;) {
+                    const bool has = pass != 0;
+                    const unsigned long long bal = __ballot(has);
+                    if (bal == 0) break;
+                    if (has) {
+                        const u32 b = (u32)__ffs(pass) - 1u;
                         pass &= pass - 1;
-                        const int within = b & 15;
-                        const int rd = rd0 + (within >> 2);
-                        const int j = c8 * 8 + ((within & 3) << 1) + (b >> 4);
-                        if (slot < LIST) s_list[w][slot] = (unsigned short)(((rd - band_lo) << 9) | (j - seg * 512));
-                        slot++;
+                        // bit b: row slot (b >> 2) & 3, pixel 2 * (b & 3) + (b >> 4)
+                        const u32 e = ebase + (((b >> 2) & 3u) << 9) + ((b & 3u) << 1) + (b >> 4);
+                        const int slot = cnt + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                        if (slot < LIST) s_list[w][slot] = (unsigned short)e;
                     }
+                    cnt += __popcll(bal);
                 }
             }
+            if ((u + 1) % GM == 0) {                   // close a maximum group: (right cell << 16) | left cell
+                const u32 lo2_ = __builtin_amdgcn_perm(mxR, mxL, 0x05040100u), hi2_ = __builtin_amdgcn_perm(mxR, mxL, 0x07060302u);
+                const u32 m0 = pk_max(lo2_, hi2_);
+                const u32 pair = pk_max(m0, mprev);                   // groups g, g-1
+                s_max[w][sb / GM + (u + 1) / GM - 1][lane] = pk_max(pair, mpair2);   // + groups g-2, g-3
+                mpair2 = mpair1; mpair1 = pair;
+                mprev = m0;
+                mxL = 0u; mxR = 0u;
+            }
         }
-        if (((sb + U_) % GS) == 0) {                   // close a statistics group
-            const u32 lo = min(mn & 0xffffu, mn >> 16), hi = max(mx & 0xffffu, mx >> 16);
-            s_stat[w][(sb + U_) / GS - 1][lane] = (hi << 16) | lo;
-            mn = 0xffffffffu; mx = 0u;
+        if (((sb + U_) % GS) == 0) {                   // close a minimum group (window of three groups)
+            const u32 lo0 = min(mn & 0xffffu, mn >> 16);
+            s_min[w][(sb + U_) / GS - 1][lane] = (unsigned short)min(lo0, min(lo1, lo2));
+            lo2 = lo1; lo1 = lo0;
+            mn = 0xffffffffu;
         }
     }
     __builtin_amdgcn_wave_barrier();
@@ -330,6 +405,7 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
     float buf_ng[KBUF];
     const int shard = blockIdx.x & 7;
     auto flush = [&]() {
+        if (p.dbg & 2) { nbuf = 0; return; }
         unsigned long long bal[KBUF];
         int total = 0;
 #pragma unroll
@@ -399,7 +475,7 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
         append(i, j, ng);
     };
 
-    const int found = s_cnt[w];
+    const int found = cnt;
     if (found <= LIST) {
         // pass 1: cheap level-1 bound on every candidate; survivors are compacted in place
         // (ballot + prefix count) so that the exact evaluation runs with full lanes
@@ -412,20 +488,26 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
                 e = s_list[w][q];
                 const int i = band_lo + (int)(e >> 9), j = seg * 512 + (int)(e & 511u);
                 keep = true;
-                if (i != H && j != H) {       // |ng| <= C_box * (max - min) over the statistics cells covering the stencil
-                    const int ol = (j >> 3) & 63;
-                    const bool need_l = (j & 7) < H + 1, need_r = (j & 7) + H + 1 > 7;
-                    const int l0 = ol - (need_l ? 1 : 0), l1 = ol + (need_r ? 1 : 0);
-                    if (l0 >= 0 && l1 <= 63) {
-                        const int g0 = (i - H - 1 - rs0) / GS, g1 = (i + H + 1 - rs0) / GS;
-                        unsigned lo = 0xffffu, hi = 0u;
-                        for (int g = g0; g <= g1; g++)
-                            for (int l = l0; l <= l1; l++) {
-                                const unsigned sv = s_stat[w][g][l];
-                                lo = min(lo, sv & 0xffffu); hi = max(hi, sv >> 16);
-                            }
-                        if ((double)(hi - lo) * p.bound_c < p.min_ng) keep = false;
+                const int jl = j - seg * 512;
+                // |ng| <= P_box * (max - min) over statistics cells covering the (2H+3)^2 stencil; candidates whose
+                // stencil wraps or leaves this wave's 512 columns are always kept
+                if (i != H && j != H && jl - H - 1 >= 0 && jl + H + 1 <= 511) {
+                    const int rr = i - rs0;
+                    const int jlo = jl - H - 1, jhi = jl + H + 1;
+                    constexpr int NLANE = (2 * H + 2) / 8 + 2;               // lanes (8 columns each) a stencil row can touch
+                    unsigned lo = 0xffffu, hi = 0u;
+                    const unsigned short *mrow = s_min[w][(rr + H + 1) / GS];
+                    const unsigned *xrow = s_max[w][(rr + H + 1) / GM];
+                    const int la = jlo >> 3, lb = jhi >> 3, c0 = jlo >> 2, c1 = jhi >> 2;
+#pragma unroll
+                    for (int t = 0; t < NLANE; t++) {
+                        const int l = min(la + t, lb);
+                        lo = min(lo, (unsigned)mrow[l]);
+                        const unsigned sv = xrow[l];
+                        if (2 * l >= c0) hi = max(hi, sv & 0xffffu);         // left cell of lane l is cell 2l
+                        if (2 * l + 1 <= c1) hi = max(hi, sv >> 16);
                     }
+                    if ((double)(hi - lo) * p.bound_c < p.min_ng) keep = false;
                 }
             }
             const unsigned long long bal = __ballot(keep);
@@ -446,7 +528,8 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
                 const bool wraps = (i == H) || (j == H);
                 // the packed test cannot see ties at 65535 (saturating +1): those are rechecked exactly
                 const bool saturated = src[(int64_t)i * p.X + j] == 0xffffu;
-                if (!wraps && !saturated) append(i, j, exact_ng_noWrap<H>(src, p.X, i, j, sux, suy));
+                if (p.dbg & 1) append(i, j, (e & 7) == 0 ? 1e9f : 0.0f);
+                else if (!wraps && !saturated) append(i, j, exact_ng_noWrap<H>(src, p.X, i, j, p.dbg));
                 else process_slow(i, j, saturated);
             }
             if (++rounds == KBUF) { flush(); rounds = 0; }
@@ -477,6 +560,26 @@ static int launch_fast(const FastParams &p, const float *d_tab, Record *recs, lo
     return PMI_OK;
 }
 
+// The compile-time unit vectors against the runtime float32 sqrtf/divide the generic path uploads.
+template <int H> static bool unit_vectors_match_h()
+{
+    for (int k = 0; k <= 2 * H; k++)
+        for (int l = 0; l <= 2 * H; l++) {
+            if (k == H && l == H) continue;
+            volatile float vx = (float)(H - l), vy = (float)(H - k);
+            volatile float n2 = vx * vx + vy * vy;
+            volatile float n = sqrtf(n2);
+            volatile float ux = vx / n, uy = vy / n;
+            if (ux != unit_x<H>(k, l) || uy != unit_y<H>(k, l)) return false;
+        }
+    return true;
+}
+static bool unit_vectors_match()
+{
+    static const bool ok = unit_vectors_match_h<1>() && unit_vectors_match_h<2>() && unit_vectors_match_h<3>() && unit_vectors_match_h<4>();
+    return ok;
+}
+
 // Returns PMI_OK and sets *handled when the fast path applies.
 int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
                          int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
@@ -487,8 +590,9 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     if (force_generic) return PMI_OK;
     const int h = box / 2;
     if (h < 1 || h > 4) return PMI_OK;
+    if (!unit_vectors_match()) return PMI_OK;          // never expected; the generic kernel uses the runtime table
     if ((X & 7) || (x0 & 7) || (cx & 7) || cx < 16 || ((uintptr_t)d_movie & 15)) return PMI_OK;
-    if (cy > 65535 || cx > 65535) return PMI_OK;
+    if (cy > 65535 || cx > 65535 || X > 65535) return PMI_OK;
     const int RB = h == 1 ? 16 : (h == 2 ? 32 : 64);     // keeps the per-wave candidate list <= 8.5 KB of LDS
     FastParams p;
     p.movie = (const uint16_t *)d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;
@@ -496,12 +600,26 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     p.bands = (cy + RB - 1) / RB;
     p.segs = (cx / 8 + 63) / 64;
     p.bpf = (p.bands * p.segs + FAST_WAVES - 1) / FAST_WAVES;
-    // C_box = sum over the window (centre excluded) of |ux| + |uy|, in double, +0.1 % margin
+    // ng is a linear functional sum_p w(p) f(p) of the (2H+3)^2 neighbourhood with sum_p w(p) = 0 (a constant
+    // image has no gradient), hence |ng| <= P_box * (max - min), P_box = sum of the positive weights
+    // (35.06 for box 7; the cruder sum of |ux| + |uy| is 60.9).  Double precision, +0.1 % margin for the
+    // float32 rounding of the reference's own summation.
     double c = 0.0;
-    for (int k = -h; k <= h; k++)
-        for (int l = -h; l <= h; l++)
-            if (k || l) c += (std::abs((double)k) + std::abs((double)l)) / std::sqrt((double)(k * k + l * l));
+    {
+        const int n = 2 * h + 3;
+        std::vector<double> wgt((size_t)n * n, 0.0);
+        for (int k = 0; k <= 2 * h; k++)
+            for (int l = 0; l <= 2 * h; l++) {
+                if (k == h && l == h) continue;
+                const double vx = h - l, vy = h - k, r = std::sqrt(vx * vx + vy * vy);
+                wgt[(size_t)(k + 2) * n + (l + 1)] += vy / r; wgt[(size_t)k * n + (l + 1)] -= vy / r;
+                wgt[(size_t)(k + 1) * n + (l + 2)] += vx / r; wgt[(size_t)(k + 1) * n + l] -= vx / r;
+            }
+        for (double v : wgt) if (v > 0) c += v;
+    }
     p.bound_c = c * 1.001;
+    static const int dbg = getenv("PMI_IDENTIFY_DBG") ? atoi(getenv("PMI_IDENTIFY_DBG")) : 0;
+    p.dbg = dbg;
     int rc;
     static const int deep = getenv("PMI_IDENTIFY_D6") ? 0 : 1;     // A/B switch for the prefetch depth (default 3 rows)
     switch (h) {

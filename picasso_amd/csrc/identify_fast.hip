@@ -96,7 +96,7 @@ struct FastParams {
     int box;
     double min_ng;
     double bound_c;            // P_box: sum of the positive stencil weights, with margin
-    int dbg;
+    int dbg;                   // PMI_IDENTIFY_DBG: 1 = skip the exact net gradient, 2 = skip the record append (timing only)
 };
 
 constexpr int FAST_WAVES = 4;
@@ -183,10 +183,10 @@ __device__ __forceinline__ float exact_ng_rows(const uint16_t *__restrict__ base
 }
 
 template <int H>
-__device__ __forceinline__ float exact_ng_noWrap(const uint16_t *__restrict__ src, int64_t X, int i, int j, int p_dbg)
+__device__ __forceinline__ float exact_ng_noWrap(const uint16_t *__restrict__ src, int64_t X, int i, int j)
 {
     constexpr int BOX = 2 * H + 1, KM = (BOX + 1) / 2;
-    const uint16_t *base = src + (int64_t)(i - H - 1) * X + (((p_dbg & 4) ? ((j - H - 1) & ~7) : (j - H - 1)));
+    const uint16_t *base = src + (int64_t)(i - H - 1) * X + (j - H - 1);
     float ng = exact_ng_rows<H, 0, KM>(base, X, 0.0f);
     // the second batch starts only when the first sum is done (keeps its loads from being hoisted
     // above the first batch, which would double the live registers)
@@ -271,17 +271,27 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
     const unsigned off_m = (unsigned)col_m * 2u;
     const unsigned off_e = (unsigned)(lane == 0 ? col_l : col_r) * 2u;
     const bool edge_lane = lane == 0 || lane == 63;
-    const char *frame_base = reinterpret_cast<const char *>(src);
-    const unsigned pitch = (unsigned)p.X * 2u;         // X <= 65535 on this path
+    // Rows are fetched with buffer loads: the frame base sits in a scalar resource descriptor, the
+    // row offset in a scalar register and the lane's column offset in one VGPR, so a row costs no
+    // vector address arithmetic at all (a 64-bit global address per lane would take two VALU adds).
+    typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<uint16_t *>(src), 0, 0x7fffffff, 0x00020000 /* raw 32-bit buffer, gfx94x/gfx950 */);
+    const unsigned pitch = (unsigned)p.X * 2u;         // Y * pitch < 2^31 on this path
     // interior bands never touch a row outside the crop: no clamping in their row loop
     const bool interior = rs0 >= 0 && rs0 + NRP + D <= p.cy;
     auto load_row = [&](int r) -> RowRegs {
         const int rc = interior ? r : min(max(r, 0), p.cy - 1);
-        const char *row = frame_base + (uint64_t)(unsigned)rc * pitch;      // 32x32 -> 64: s_mul_i32 + s_mul_hi_u32
+        const unsigned soff = (unsigned)rc * pitch;
         RowRegs o;
-        o.m = *reinterpret_cast<const uint4 *>(row + off_m);
+        const u32x4_t m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_m, (int)soff, 0);
+        o.m = make_uint4(m.x, m.y, m.z, m.w);
         o.e = make_uint2(0u, 0u);
-        if (edge_lane) o.e = *reinterpret_cast<const uint2 *>(row + off_e);
+        if (edge_lane) {
+            const u32x2_t e = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off_e, (int)soff, 0);
+            o.e = make_uint2(e.x, e.y);
+        }
         return o;
     };
 
@@ -529,7 +539,7 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
                 // the packed test cannot see ties at 65535 (saturating +1): those are rechecked exactly
                 const bool saturated = src[(int64_t)i * p.X + j] == 0xffffu;
                 if (p.dbg & 1) append(i, j, (e & 7) == 0 ? 1e9f : 0.0f);
-                else if (!wraps && !saturated) append(i, j, exact_ng_noWrap<H>(src, p.X, i, j, p.dbg));
+                else if (!wraps && !saturated) append(i, j, exact_ng_noWrap<H>(src, p.X, i, j));
                 else process_slow(i, j, saturated);
             }
             if (++rounds == KBUF) { flush(); rounds = 0; }
@@ -592,7 +602,7 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     if (h < 1 || h > 4) return PMI_OK;
     if (!unit_vectors_match()) return PMI_OK;          // never expected; the generic kernel uses the runtime table
     if ((X & 7) || (x0 & 7) || (cx & 7) || cx < 16 || ((uintptr_t)d_movie & 15)) return PMI_OK;
-    if (cy > 65535 || cx > 65535 || X > 65535) return PMI_OK;
+    if (cy > 65535 || cx > 65535 || X > 65535 || Y * X * 2 >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets
     const int RB = h == 1 ? 16 : (h == 2 ? 32 : 64);     // keeps the per-wave candidate list <= 8.5 KB of LDS
     FastParams p;
     p.movie = (const uint16_t *)d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;

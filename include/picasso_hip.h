@@ -34,6 +34,8 @@
  *                      (+ :547-589 localization_precision)
  *   pmi_localize_lq_dev     picasso/localize.py:1682-1815 localize with
  *                      fitting_method="gausslq"
+ *   pmi_render_*       picasso/render.py:37-175 render -> :798-853 _render_hist,
+ *                      :1020-1070 _render_gaussian (ang=None), :177-232, :451-467, :494-575
  *   pmi_localize_mle_dev    picasso/localize.py:1682-1815 localize with
  *                      fitting_method="gaussmle" (identify -> get_spots -> fit
  *                      -> table) as one asynchronous device pipeline
@@ -194,6 +196,32 @@ int pmi_zfit_dev(const float *d_sx, const float *d_sy, int64_t N, const int64_t 
  * theta (N,6) = [0, 0, sum, sum, 1, 1] with a float64 ROI sum.               */
 int pmi_avgroi(const float *spots, int64_t N, int box, float *theta);
 int pmi_avgroi_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box, float *d_theta, void *stream);
+
+/* ---- render (picasso/render.py:37-175 render with blur_method None / "gaussian") --- *
+ * x, y (and lpx, lpy) are the float32 columns of the localization table in
+ * camera pixels.  The viewport (y_min, x_min)-(y_max, x_max) and oversampling
+ * define an image of ny x nx = ceil(oversampling * extent) float32 pixels
+ * (pmi_render_dims; render.py:177-232); localizations strictly inside the
+ * viewport are drawn, *n_rendered receives their number.
+ *   hist:     image[int(y'), int(x')] += 1                       (render.py:451-467)
+ *   gaussian: separable Gaussian over +-3 sigma, sigma = oversampling *
+ *             max(lp, min_blur_width), in TABLE ORDER per pixel   (render.py:494-575)
+ * The image buffer is overwritten (zeroed first).                            */
+int pmi_render_dims(double oversampling, double y_min, double x_min, double y_max, double x_max,
+                    int64_t *ny, int64_t *nx);
+int pmi_render_hist(const float *x, const float *y, int64_t N, double oversampling,
+                    double y_min, double x_min, double y_max, double x_max,
+                    float *image, int64_t ny, int64_t nx, int64_t *n_rendered);
+int pmi_render_hist_dev(const float *d_x, const float *d_y, int64_t N, double oversampling,
+                        double y_min, double x_min, double y_max, double x_max,
+                        float *d_image, int64_t ny, int64_t nx, int64_t *d_n_rendered, void *stream);
+int pmi_render_gaussian(const float *x, const float *y, const float *lpx, const float *lpy, int64_t N,
+                        double oversampling, double y_min, double x_min, double y_max, double x_max,
+                        double min_blur_width, float *image, int64_t ny, int64_t nx, int64_t *n_rendered);
+int pmi_render_gaussian_dev(const float *d_x, const float *d_y, const float *d_lpx, const float *d_lpy,
+                            int64_t N, double oversampling, double y_min, double x_min, double y_max,
+                            double x_max, double min_blur_width, float *d_image, int64_t ny, int64_t nx,
+                            int64_t *d_n_rendered, void *stream);
 
 /* ---- timing hooks for bench.py (HIP events on the given stream) ------- */
 int pmi_event_create(void **event);

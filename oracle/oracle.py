@@ -200,3 +200,33 @@ def gausslq_from(spots, theta0, threads=1):
     th = np.zeros((N, 6), np.float32)
     lib().orc_gausslq_from(_ptr(spots), N, box, _ptr(theta0), _ptr(th), int(threads))
     return th
+
+
+def render(x, y, oversampling, viewport, lpx=None, lpy=None, blur_method=None, min_blur_width=0.0):
+    """render._render_hist / _render_gaussian restated: -> (n, image float32)."""
+    import ctypes
+    x = np.ascontiguousarray(x, np.float32); y = np.ascontiguousarray(y, np.float32)
+    (y_min, x_min), (y_max, x_max) = viewport
+    ny = ctypes.c_int64(); nx = ctypes.c_int64()
+    L = lib()
+    f64 = ctypes.c_double
+    L.orc_render_dims.argtypes = [f64] * 5 + [ctypes.c_void_p] * 2
+    L.orc_render_dims(float(oversampling), float(y_min), float(x_min), float(y_max), float(x_max), ctypes.byref(ny), ctypes.byref(nx))
+    image = np.zeros((ny.value, nx.value), np.float32)
+    if blur_method is None:
+        L.orc_render_hist.restype = ctypes.c_int64
+        L.orc_render_hist.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64] + [f64] * 5 + [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+        n = L.orc_render_hist(_ptr(x), _ptr(y), len(x), float(oversampling), float(y_min), float(x_min), float(y_max),
+                              float(x_max), _ptr(image), ny.value, nx.value)
+    elif blur_method == "gaussian":
+        lpx = np.ascontiguousarray(lpx, np.float32); lpy = np.ascontiguousarray(lpy, np.float32)
+        L.orc_render_gaussian.restype = ctypes.c_int64
+        L.orc_render_gaussian.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [f64] * 6 + [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+        n = L.orc_render_gaussian(_ptr(x), _ptr(y), _ptr(lpx), _ptr(lpy), len(x), float(oversampling), float(y_min),
+                                  float(x_min), float(y_max), float(x_max), float(min_blur_width), _ptr(image),
+                                  ny.value, nx.value)
+        if n < 0:
+            raise ValueError("footprint too large for the oracle")
+    else:
+        raise ValueError("blur_method not understood.")
+    return int(n), image

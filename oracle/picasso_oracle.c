@@ -1121,6 +1121,95 @@ int orc_gausslq_initial(const float *spots, int64_t N, int box, float *theta)
     return 0;
 }
 
+/* ------------------------------------------------------------------------
+ * render  (picasso/render.py:177-232 _render_setup, :451-467 _fill,
+ *          :494-575 _draw_gaussian_loc / _fill_gaussian, :798-853, :1020-1070)
+ *
+ * numba promotion: the float32 coordinates become float64 inside _render_setup
+ * (array(float32) - float64 scalar), so the image coordinates, the footprint
+ * bounds and the two 1-D profiles are float64, rounded to float32 when stored
+ * into gx / gy; the outer product and the accumulation into the image are
+ * float32, in localization order.  The blur widths are computed outside numba:
+ * float32(oversampling) * max(lp, float32(min_blur_width)) in float32.
+ * ---------------------------------------------------------------------- */
+/* float64 -> int32 as compiled x86-64 code does it (cvttsd2si): INT_MIN for NaN / out of range */
+static inline int32_t to_int32(double v)
+{
+    return (v != v || v >= 2147483648.0 || v < -2147483648.0) ? INT32_MIN : (int32_t)v;
+}
+
+static void render_dims(double oversampling, double y_min, double x_min, double y_max, double x_max,
+                        int64_t *ny, int64_t *nx)
+{
+    *ny = (int64_t)ceil(oversampling * (y_max - y_min));
+    *nx = (int64_t)ceil(oversampling * (x_max - x_min));
+}
+
+/* image (ny, nx) float32, zeroed by the caller.  Returns the number of localizations in view. */
+int64_t orc_render_hist(const float *x, const float *y, int64_t N, double oversampling, double y_min, double x_min,
+                        double y_max, double x_max, float *image, int64_t ny, int64_t nx)
+{
+    int64_t n = 0;
+    for (int64_t i = 0; i < N; i++) {
+        const double xd = (double)x[i], yd = (double)y[i];
+        if (!(xd > x_min && yd > y_min && xd < x_max && yd < y_max)) continue;
+        const int32_t xi = to_int32(oversampling * (xd - x_min)), yi = to_int32(oversampling * (yd - y_min));
+        image[(int64_t)yi * nx + xi] += 1.0f;
+        n++;
+    }
+    (void)ny;
+    return n;
+}
+
+int64_t orc_render_gaussian(const float *x, const float *y, const float *lpx, const float *lpy, int64_t N,
+                            double oversampling, double y_min, double x_min, double y_max, double x_max,
+                            double min_blur_width, float *image, int64_t ny, int64_t nx)
+{
+    const float osf = (float)oversampling, mbw = (float)min_blur_width;
+    float gx[4096], gy[4096];
+    int64_t n = 0;
+    for (int64_t i = 0; i < N; i++) {
+        const double xd = (double)x[i], yd = (double)y[i];
+        if (!(xd > x_min && yd > y_min && xd < x_max && yd < y_max)) continue;
+        n++;
+        const double x_ = oversampling * (xd - x_min), y_ = oversampling * (yd - y_min);
+        const float sx_ = osf * np_maxf(lpx[i], mbw), sy_ = osf * np_maxf(lpy[i], mbw);
+        const double max_y_off = 3.0 * (double)sy_, max_x_off = 3.0 * (double)sx_;
+        int64_t i_min = to_int32(y_ - max_y_off);
+        if (i_min < 0) i_min = 0;
+        int64_t i_max = to_int32(y_ + max_y_off + 1);
+        if (i_max > ny) i_max = ny;
+        int64_t j_min = to_int32(x_ - max_x_off);
+        if (j_min < 0) j_min = 0;
+        int64_t j_max = (int64_t)to_int32(x_ + max_x_off) + 1;
+        if (j_max > nx) j_max = nx;
+        const int64_t cx = j_max - j_min, cy = i_max - i_min;
+        if (cx <= 0 || cy <= 0) continue;
+        if (cx > 4096 || cy > 4096) return -1;                      /* footprint larger than this restatement allows */
+        const double inv_2sx2 = 1.0 / (2.0 * (double)sx_ * (double)sx_);
+        const double inv_2sy2 = 1.0 / (2.0 * (double)sy_ * (double)sy_);
+        const double norm = 1.0 / (6.283185307179586 * (double)sx_ * (double)sy_);
+        for (int64_t jj = 0; jj < cx; jj++) {
+            const double dx = (double)(j_min + jj) + 0.5 - x_;
+            gx[jj] = (float)exp(-dx * dx * inv_2sx2);
+        }
+        for (int64_t ii = 0; ii < cy; ii++) {
+            const double dy = (double)(i_min + ii) + 0.5 - y_;
+            gy[ii] = (float)(norm * exp(-dy * dy * inv_2sy2));
+        }
+        for (int64_t ii = 0; ii < cy; ii++) {
+            float *row = image + (i_min + ii) * nx;
+            for (int64_t jj = 0; jj < cx; jj++) row[j_min + jj] += gy[ii] * gx[jj];
+        }
+    }
+    return n;
+}
+
+void orc_render_dims(double oversampling, double y_min, double x_min, double y_max, double x_max, int64_t *ny, int64_t *nx)
+{
+    render_dims(oversampling, y_min, x_min, y_max, x_max, ny, nx);
+}
+
 int orc_max_threads(void)
 {
 #ifdef _OPENMP

@@ -183,6 +183,34 @@ def zfit_arrays(sx, sy, cx, cy):
     return z, sq
 
 
+def render_arrays(x, y, oversampling, y_min, x_min, y_max, x_max, lpx=None, lpy=None, min_blur_width=0.0):
+    """-> (n, image float32).  lpx/lpy None = histogram, else the Gaussian render."""
+    _lib.require_gpu()
+    L = _lib.load()
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.ascontiguousarray(y, np.float32)
+    N = len(x)
+    ny, nx = ctypes.c_int64(), ctypes.c_int64()
+    _lib.check(L.pmi_render_dims(float(oversampling), float(y_min), float(x_min), float(y_max), float(x_max),
+                                 ctypes.byref(ny), ctypes.byref(nx)), "pmi_render_dims")
+    if ny.value <= 0 or nx.value <= 0:
+        raise ValueError("empty viewport")
+    image = np.empty((ny.value, nx.value), np.float32)
+    n = ctypes.c_int64(0)
+    with _lib.lock():
+        if lpx is None:
+            rc = L.pmi_render_hist(_lib.ptr(x), _lib.ptr(y), N, float(oversampling), float(y_min), float(x_min),
+                                   float(y_max), float(x_max), _lib.ptr(image), ny.value, nx.value, ctypes.byref(n))
+        else:
+            lpx = np.ascontiguousarray(lpx, np.float32)
+            lpy = np.ascontiguousarray(lpy, np.float32)
+            rc = L.pmi_render_gaussian(_lib.ptr(x), _lib.ptr(y), _lib.ptr(lpx), _lib.ptr(lpy), N, float(oversampling),
+                                       float(y_min), float(x_min), float(y_max), float(x_max), float(min_blur_width),
+                                       _lib.ptr(image), ny.value, nx.value, ctypes.byref(n))
+    _lib.check(rc, "pmi_render")
+    return int(n.value), image
+
+
 class DeviceMovie:
     """A movie resident in HBM (pmi_malloc), for repeated calls without H2D."""
 

@@ -1,8 +1,10 @@
-"""The two picasso.lib helpers the localization path depends on
-(picasso/lib.py:878-920 get_from_metadata, :1786-1832 ensure_sanity)."""
+"""The picasso.lib helpers the localization / undrift path depends on
+(picasso/lib.py:878-920 get_from_metadata, :1786-1832 ensure_sanity, :2034-2078 minimize_shifts)."""
 from __future__ import annotations
 
 from typing import Any
+
+import warnings
 
 import numpy as np
 import pandas as pd
@@ -35,3 +37,32 @@ def ensure_sanity(locs: pd.DataFrame, info) -> pd.DataFrame:
         if attr in locs.columns:
             locs = locs[locs[attr] >= 0]
     return locs
+
+
+def deprecation_warning(message: str) -> None:
+    warnings.warn(message, DeprecationWarning, stacklevel=3)
+
+
+def minimize_shifts(shifts_x, shifts_y, shifts_z=None):
+    """Least-squares consistent shifts from all pairwise shifts (picasso/lib.py:2034-2078):
+    r_ij = sum of the segment-to-segment displacements D_i..D_{j-1}; D = pinv(A) r."""
+    n = shifts_x.shape[0]
+    n_pairs = int(n * (n - 1) / 2)
+    n_dims = 2 if shifts_z is None else 3
+    rij = np.zeros((n_pairs, n_dims))
+    A = np.zeros((n_pairs, n - 1))
+    flag = 0
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            rij[flag, 0] = shifts_y[i, j]
+            rij[flag, 1] = shifts_x[i, j]
+            if n_dims == 3:
+                rij[flag, 2] = shifts_z[i, j]
+            A[flag, i:j] = 1
+            flag += 1
+    Dj = np.dot(np.linalg.pinv(A), rij)
+    shift_y = np.insert(np.cumsum(Dj[:, 0]), 0, 0)
+    shift_x = np.insert(np.cumsum(Dj[:, 1]), 0, 0)
+    if n_dims == 2:
+        return shift_y, shift_x
+    return shift_y, shift_x, np.insert(np.cumsum(Dj[:, 2]), 0, 0)

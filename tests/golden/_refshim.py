@@ -3,8 +3,8 @@
 TEST INFRASTRUCTURE. Runs ONLY in the build container, where the reference
 tree is mounted read-only at /root/reference. Nothing here travels to the GPU
 box as reference code: this module loads the reference's ``gaussmle.py``,
-``gausslq.py``, ``avgroi.py``, ``zfit.py`` and ``localize.py`` *from where they
-lie* and executes them as plain Python behind stand-in modules for the
+``gausslq.py``, ``avgroi.py``, ``zfit.py``, ``localize.py``, ``render.py`` and
+``imageprocess.py`` *from where they lie* and executes them as plain Python behind stand-in modules for the
 packages this image lacks (numba, dask, h5py/Qt-dependent ``picasso.lib`` /
 ``picasso.io``).  See SURVEY.md section 8c for why the real numba path cannot
 run here.
@@ -57,7 +57,7 @@ def load_reference():
         m = sys.modules
         return {
             k: m["picasso." + k]
-            for k in ("gaussmle", "gausslq", "avgroi", "zfit", "localize")
+            for k in ("gaussmle", "gausslq", "avgroi", "zfit", "localize", "render", "imageprocess")
         }
 
     numba = types.ModuleType("numba")
@@ -149,8 +149,44 @@ def load_reference():
     sys.modules["picasso.postprocess"] = postprocess
     pkg.postprocess = postprocess
 
+    # stand-ins for GUI / image-file packages render.py and imageprocess.py import at module level
+    class _StubMeta(type):
+        def __getattr__(cls, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return _Stub
+
+    class _Stub(metaclass=_StubMeta):        # callable, subclassable, any attribute
+        def __init__(self, *a, **k):
+            pass
+
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            return _Stub()
+
+        def __call__(self, *a, **k):
+            return _Stub()
+
+    class _Anything(types.ModuleType):
+        def __getattr__(self, name):
+            if name.startswith("__"):
+                raise AttributeError(name)
+            full = self.__name__ + "." + name
+            if full in sys.modules:
+                return sys.modules[full]
+            return _Stub
+    for modname in ("imageio", "imageio.v2", "PyQt6", "PyQt6.QtGui", "PyQt6.QtCore", "PyQt6.QtSvg", "PyQt6.QtWidgets"):
+        if modname not in sys.modules:
+            try:
+                importlib.import_module(modname)
+            except ImportError:
+                sys.modules[modname] = _Anything(modname)
+    import matplotlib
+    matplotlib.use("Agg")
+
     out = {}
-    for name in ("gaussmle", "gausslq", "avgroi", "zfit", "localize"):
+    for name in ("gaussmle", "gausslq", "avgroi", "zfit", "localize", "render", "imageprocess"):
         path = os.path.join(REF, "picasso", name + ".py")
         spec = importlib.util.spec_from_file_location("picasso." + name, path)
         mod = importlib.util.module_from_spec(spec)

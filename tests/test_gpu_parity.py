@@ -325,3 +325,62 @@ def test_localize_lq_pipeline_on_resident_movie(be, orc, testdata_movie):
             assert np.allclose(a, b, rtol=3e-7, atol=0, equal_nan=True), c
         assert np.max(np.abs(t["x"] - ref["x"].to_numpy())) < 1e-3
         assert np.max(np.abs(t["y"] - ref["y"].to_numpy())) < 1e-3
+
+
+# ---------------------------------------------------------------------------
+# render (picasso/render.py): histogram and order-preserving Gaussian
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_render_vs_goldens_and_oracle(be, orc, case):
+    g = golden("render_cases")
+    (y_min, x_min), (y_max, x_max) = g[case + "_viewport"]
+    osamp, mbw = float(g[case + "_oversampling"]), float(g[case + "_min_blur"])
+    n, hist = be.render_arrays(g["x"], g["y"], osamp, y_min, x_min, y_max, x_max)
+    assert n == int(g[case + "_n"]) and np.array_equal(hist, g[case + "_hist"])
+    n, img = be.render_arrays(g["x"], g["y"], osamp, y_min, x_min, y_max, x_max, g["lpx"], g["lpy"], mbw)
+    ref = g[case + "_gauss_numba"]
+    assert n == int(g[case + "_n"]) and img.shape == ref.shape and img.dtype == np.float32
+    # same additions in the same order; only a 1-ulp float64 exp difference can survive the float32 rounding
+    assert (img != ref).mean() < 1e-3
+    assert np.max(np.abs(img - ref)) <= 4e-7 * float(ref.max())
+
+
+def test_render_large_random_vs_oracle(be, orc):
+    """~2e5 localizations, oversampling 10 on a 128 px field (1280^2 image) and the undrift-style
+    oversampling 1 / min_blur 1 render (every pixel receives thousands of ordered additions)."""
+    rng = np.random.default_rng(5)
+    N = 200_000
+    x = rng.uniform(-2, 130, N).astype(np.float32)
+    y = rng.uniform(-2, 130, N).astype(np.float32)
+    lpx = rng.uniform(0.01, 0.15, N).astype(np.float32)
+    lpy = rng.uniform(0.01, 0.15, N).astype(np.float32)
+    lpx[:5] = np.nan                                        # NaN precision: np.maximum propagates, nothing is drawn
+    for osamp, mbw in ((10.0, 0.0), (1.0, 1.0)):
+        n, img = be.render_arrays(x, y, osamp, 0, 0, 128, 128, lpx, lpy, mbw)
+        on, oimg = orc.render(x, y, osamp, [(0, 0), (128, 128)], lpx, lpy, "gaussian", mbw)
+        assert n == on and img.shape == oimg.shape
+        assert (img != oimg).mean() < 1e-3
+        assert np.nanmax(np.abs(img - oimg)) <= 1e-6 * float(np.nanmax(oimg))
+        n, hist = be.render_arrays(x, y, osamp, 0, 0, 128, 128)
+        on, ohist = orc.render(x, y, osamp, [(0, 0), (128, 128)])
+        assert n == on and np.array_equal(hist, ohist) and hist.sum() == n
+
+
+def test_render_edge_cases(be, orc):
+    e = np.zeros(0, np.float32)
+    n, img = be.render_arrays(e, e, 2.0, 0, 0, 8, 8, e, e, 0.0)
+    assert n == 0 and img.shape == (16, 16) and not img.any()
+    n, img = be.render_arrays(e, e, 2.0, 0, 0, 8, 8)
+    assert n == 0 and not img.any()
+    # on the viewport border: strict inequalities (render.py:226)
+    x = np.array([0.0, 8.0, 4.0, 7.99], np.float32)
+    y = np.array([4.0, 4.0, 0.0, 7.99], np.float32)
+    lp = np.full(4, 0.3, np.float32)
+    n, img = be.render_arrays(x, y, 3.0, 0, 0, 8, 8, lp, lp, 0.0)
+    on, oimg = orc.render(x, y, 3.0, [(0, 0), (8, 8)], lp, lp, "gaussian", 0.0)
+    assert n == on == 1 and np.allclose(img, oimg, rtol=1e-6, atol=0)
+    # a footprint wider than the image, non-square viewport
+    x = np.array([5.0], np.float32); y = np.array([2.0], np.float32); lp = np.array([40.0], np.float32)
+    n, img = be.render_arrays(x, y, 1.5, 0, 1, 5, 9, lp, lp, 0.0)
+    on, oimg = orc.render(x, y, 1.5, [(0, 1), (5, 9)], lp, lp, "gaussian", 0.0)
+    assert img.shape == oimg.shape == (8, 12) and np.allclose(img, oimg, rtol=1e-6, atol=0)

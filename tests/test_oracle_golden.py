@@ -199,3 +199,22 @@ def test_gausslq_matches_scipy_minpack():
     for i in range(len(spots)):
         r = optimize.leastsq(resid, t0[i], args=(spots[i], 7), ftol=1e-2, xtol=1e-2, full_output=True)
         assert np.array_equal(r[0].astype(np.float32), th[i]) and r[4] == info[i] and r[2]["nfev"] == nfev[i]
+
+
+@pytest.mark.parametrize("case", ["a", "b", "c"])
+def test_render_against_goldens(case):
+    """render._render_hist / _render_gaussian (picasso/render.py:177-232, 451-467, 494-575).
+    'numba' goldens: the reference's own functions fed float64-widened inputs, i.e. numba's promotion
+    of the float32 columns -> bit-identical.  'numpy' goldens: the reference as NumPy executes it
+    (float32 coordinates), which moves narrow Gaussians by ~1e-6 px."""
+    g = golden("render_cases")
+    vp = [tuple(g[case + "_viewport"][0]), tuple(g[case + "_viewport"][1])]
+    osamp, mbw = float(g[case + "_oversampling"]), float(g[case + "_min_blur"])
+    n, hist = orc.render(g["x"], g["y"], osamp, vp)
+    assert n == int(g[case + "_n"]) and np.array_equal(hist, g[case + "_hist"])
+    n, img = orc.render(g["x"], g["y"], osamp, vp, g["lpx"], g["lpy"], "gaussian", mbw)
+    assert n == int(g[case + "_n"]) and img.dtype == np.float32
+    assert np.array_equal(img, g[case + "_gauss_numba"])
+    ref = g[case + "_gauss_numpy"]
+    assert np.max(np.abs(img - ref)) < 2e-4 * max(1.0, float(ref.max()))
+    assert abs(float(img.sum()) - float(ref.sum())) < 1e-3 * float(ref.sum())

@@ -36,6 +36,8 @@
  *                      fitting_method="gausslq"
  *   pmi_render_*       picasso/render.py:37-175 render -> :798-853 _render_hist,
  *                      :1020-1070 _render_gaussian (ang=None), :177-232, :451-467, :494-575
+ *   pmi_xcorr, pmi_rcc_pairs   picasso/imageprocess.py:27-50 xcorr, :53-161
+ *                      get_image_shift (up to its curve_fit), :164-217 rcc
  *   pmi_localize_mle_dev    picasso/localize.py:1682-1815 localize with
  *                      fitting_method="gaussmle" (identify -> get_spots -> fit
  *                      -> table) as one asynchronous device pipeline
@@ -222,6 +224,22 @@ int pmi_render_gaussian_dev(const float *d_x, const float *d_y, const float *d_l
                             int64_t N, double oversampling, double y_min, double x_min, double y_max,
                             double x_max, double min_blur_width, float *d_image, int64_t ny, int64_t nx,
                             int64_t *d_n_rendered, void *stream);
+
+/* ---- cross-correlation for RCC undrift (picasso/imageprocess.py:27-217) ---- *
+ * pmi_xcorr: out = fftshift(real(ifft2(fft2(A) * conj(fft2(B))))) / sqrt(Y*X),
+ * float64 images of Y x X (imageprocess.py:27-50).
+ * pmi_rcc_pairs: for every pair i < j of n_seg float64 images (pair index in
+ * the order of imageprocess.py:197-205), everything get_image_shift (:53-161)
+ * does before its curve_fit: correlation, centre crop to `roi` (0 = none;
+ * crop_yx = {Y_, X_} rows/columns removed on each side), first maximum in
+ * row-major order (peak_yx[2p], peak_yx[2p+1], cropped coordinates) and the
+ * box x box window around it (fit_rois[p*box*box ..]).  valid[p] = 1 when the
+ * window lies inside the cropped correlation, 0 when numpy's slicing would
+ * truncate it (the reference then reports a zero shift), -1 when one of the
+ * two images is empty (zero shift by imageprocess.py:85-86).                  */
+int pmi_xcorr(const double *image_a, const double *image_b, int64_t Y, int64_t X, double *out);
+int pmi_rcc_pairs(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
+                  int32_t *peak_yx, int32_t *valid, double *fit_rois, int32_t *crop_yx);
 
 /* ---- timing hooks for bench.py (HIP events on the given stream) ------- */
 int pmi_event_create(void **event);

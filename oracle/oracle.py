@@ -230,3 +230,38 @@ def render(x, y, oversampling, viewport, lpx=None, lpy=None, blur_method=None, m
     else:
         raise ValueError("blur_method not understood.")
     return int(n), image
+
+
+def xcorr(image_a, image_b):
+    """imageprocess.xcorr restated with numpy's FFT (picasso/imageprocess.py:27-50)."""
+    fa = np.fft.fft2(image_a)
+    cfb = np.conj(np.fft.fft2(image_b))
+    return np.fft.fftshift(np.real(np.fft.ifft2(fa * cfb))) / np.sqrt(np.asarray(image_a).size)
+
+
+def peak_window(image_a, image_b, box, roi=None):
+    """get_image_shift up to its curve_fit (picasso/imageprocess.py:85-119):
+    -> None for an empty image, else (y_max, x_max, Y_, X_, fit window or None if truncated)."""
+    if np.sum(image_a) == 0 or np.sum(image_b) == 0:
+        return None
+    xc = xcorr(image_a, image_b)
+    Y, X = np.asarray(image_a).shape
+    if roi is not None:
+        Y_ = int((Y - roi) / 2)
+        X_ = int((X - roi) / 2)
+        if Y_ > 0:
+            xc = xc[Y_:-Y_, :]
+        else:
+            Y_ = 0
+        if X_ > 0:
+            xc = xc[:, X_:-X_]
+        else:
+            X_ = 0
+    else:
+        Y_ = X_ = 0
+    h = int(box / 2)
+    y_max_, x_max_ = np.unravel_index(xc.argmax(), xc.shape)
+    win = xc[y_max_ - h:y_max_ + h + 1, x_max_ - h:x_max_ + h + 1] if (y_max_ - h >= 0 and x_max_ - h >= 0) else np.zeros((0, 0))
+    if 0 in win.shape or win.shape[0] != win.shape[1] or win.shape[0] != box:
+        win = None
+    return int(y_max_), int(x_max_), Y_, X_, win

@@ -211,6 +211,39 @@ def render_arrays(x, y, oversampling, y_min, x_min, y_max, x_max, lpx=None, lpy=
     return int(n.value), image
 
 
+def xcorr_array(image_a, image_b) -> np.ndarray:
+    _lib.require_gpu()
+    a = np.ascontiguousarray(image_a, np.float64)
+    b = np.ascontiguousarray(image_b, np.float64)
+    if a.ndim != 2 or a.shape != b.shape:
+        raise ValueError("images must be 2-D and of the same shape")
+    out = np.empty_like(a)
+    with _lib.lock():
+        rc = _lib.load().pmi_xcorr(_lib.ptr(a), _lib.ptr(b), a.shape[0], a.shape[1], _lib.ptr(out))
+    _lib.check(rc, "pmi_xcorr")
+    return out
+
+
+def rcc_pairs_arrays(segments, roi, box: int):
+    """All pairs i < j of the segment images -> peak (n_pairs, 2), valid (n_pairs), fit windows
+    (n_pairs, box, box) float64 and the crop offsets (Y_, X_)."""
+    _lib.require_gpu()
+    seg = np.ascontiguousarray(segments, np.float64)
+    if seg.ndim != 3:
+        raise ValueError("segments must have shape (n, Y, X)")
+    n, Y, X = seg.shape
+    n_pairs = n * (n - 1) // 2
+    peak = np.zeros((n_pairs, 2), np.int32)
+    valid = np.zeros(n_pairs, np.int32)
+    rois = np.zeros((n_pairs, box, box), np.float64)
+    crop = np.zeros(2, np.int32)
+    with _lib.lock():
+        rc = _lib.load().pmi_rcc_pairs(_lib.ptr(seg), n, Y, X, int(roi) if roi is not None else 0, int(box),
+                                       _lib.ptr(peak), _lib.ptr(valid), _lib.ptr(rois), _lib.ptr(crop))
+    _lib.check(rc, "pmi_rcc_pairs")
+    return peak, valid, rois, (int(crop[0]), int(crop[1]))
+
+
 class DeviceMovie:
     """A movie resident in HBM (pmi_malloc), for repeated calls without H2D."""
 

@@ -384,3 +384,39 @@ def test_render_edge_cases(be, orc):
     n, img = be.render_arrays(x, y, 1.5, 0, 1, 5, 9, lp, lp, 0.0)
     on, oimg = orc.render(x, y, 1.5, [(0, 1), (5, 9)], lp, lp, "gaussian", 0.0)
     assert img.shape == oimg.shape == (8, 12) and np.allclose(img, oimg, rtol=1e-6, atol=0)
+
+
+# ---------------------------------------------------------------------------
+# cross-correlation / RCC pairs (picasso/imageprocess.py:27-161)
+# ---------------------------------------------------------------------------
+@pytest.mark.parametrize("shape,roi", [((64, 64), 32), ((45, 70), 32), ((33, 31), None), ((128, 96), 200), ((20, 50), 16)])
+def test_xcorr_and_peak_windows_vs_numpy(be, orc, shape, roi):
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    Y, X = shape
+    n = 5
+    yy, xx = np.mgrid[0:Y, 0:X]
+    segs = np.zeros((n, Y, X))
+    cy, cx = rng.uniform(0.3 * Y, 0.7 * Y, 6), rng.uniform(0.3 * X, 0.7 * X, 6)
+    for s in range(n):
+        dy, dx = rng.uniform(-3, 3, 2)
+        for k in range(6):
+            segs[s] += np.exp(-0.5 * (((yy - cy[k] - dy) / 1.3) ** 2 + ((xx - cx[k] - dx) / 1.3) ** 2))
+        segs[s] += rng.uniform(0, 0.02, (Y, X))
+    segs[3] = 0.0                                             # an empty segment
+    xc = be.xcorr_array(segs[0], segs[1])
+    ref = orc.xcorr(segs[0], segs[1])
+    assert xc.shape == ref.shape and np.max(np.abs(xc - ref)) < 1e-12 * np.abs(ref).max()
+    peak, valid, rois, (Y_, X_) = be.rcc_pairs_arrays(segs, roi, 5)
+    p = 0
+    for i in range(n - 1):
+        for j in range(i + 1, n):
+            want = orc.peak_window(segs[i], segs[j], 5, roi)
+            if want is None:
+                assert valid[p] == -1
+            else:
+                ym, xm, wy, wx, win = want
+                assert (Y_, X_) == (wy, wx) and tuple(peak[p]) == (ym, xm)
+                assert (valid[p] == 1) == (win is not None)
+                if win is not None:
+                    assert np.max(np.abs(rois[p] - win)) < 1e-12 * np.abs(ref).max()
+            p += 1

@@ -11,6 +11,7 @@
 // The transforms are hipFFT plans (double precision), cached per image size.
 #include <hipfft/hipfft.h>
 
+#include <algorithm>
 #include <cmath>
 #include <map>
 #include <utility>
@@ -43,21 +44,22 @@ static int get_plans(int64_t Y, int64_t X, Plans *out)
     return PMI_OK;
 }
 
-// nonzero[i] = 1 when image i has a non-zero sum (picasso/imageprocess.py:85-86; the images are
-// non-negative renders, so "sum == 0" is "all zero"; a float64 tree sum decides the general case)
+// sums[i] != 0 when image i is not empty (picasso/imageprocess.py:85-86 tests np.sum(image) == 0; the
+// images are non-negative renders, so that is "all pixels zero").  grid = (chunks, images); every block
+// adds the float64 sum of its chunk of non-negative magnitudes to the image's total.
 __global__ __launch_bounds__(256) void sum_kernel(const double *__restrict__ img, int64_t npix, double *__restrict__ sums)
 {
     __shared__ double s[256];
-    const double *p = img + (int64_t)blockIdx.x * npix;
+    const double *p = img + (int64_t)blockIdx.y * npix;
     double acc = 0.0;
-    for (int64_t i = threadIdx.x; i < npix; i += 256) acc += p[i];
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < npix; i += (int64_t)gridDim.x * 256) acc += fabs(p[i]);
     s[threadIdx.x] = acc;
     __syncthreads();
     for (int o = 128; o > 0; o >>= 1) {
         if ((int)threadIdx.x < o) s[threadIdx.x] += s[threadIdx.x + o];
         __syncthreads();
     }
-    if (threadIdx.x == 0) sums[blockIdx.x] = s[0];
+    if (threadIdx.x == 0 && s[0] != 0.0) atomicAdd(&sums[blockIdx.y], s[0]);
 }
 
 __global__ void product_kernel(const hipfftDoubleComplex *__restrict__ fa, const hipfftDoubleComplex *__restrict__ fb,
@@ -193,7 +195,9 @@ int pmi_rcc_pairs(const double *segments, int64_t n_seg, int64_t Y, int64_t X, i
     double *d_sums = d_rois + n_pairs * box * box;
     xc::PeakOut *d_peaks = (xc::PeakOut *)(d_sums + n_seg);
     PMI_HIP(hipMemcpy(dseg, segments, (size_t)n_seg * npix * 8, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(xc::sum_kernel, dim3((unsigned)n_seg), dim3(256), 0, 0, dseg, npix, d_sums);
+    PMI_HIP(hipMemsetAsync(d_sums, 0, (size_t)n_seg * 8, 0));
+    hipLaunchKernelGGL(xc::sum_kernel, dim3((unsigned)std::min<int64_t>(64, (npix + 255) / 256), (unsigned)n_seg), dim3(256), 0, 0,
+                       dseg, npix, d_sums);
     for (int64_t i = 0; i < n_seg; i++)
         if (hipfftExecD2Z(pl.fwd, dseg + i * npix, spec + i * nspec) != HIPFFT_SUCCESS) { set_error("hipfftExecD2Z failed"); return PMI_ERR_HIP; }
     std::vector<double> sums((size_t)n_seg);

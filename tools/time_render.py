@@ -54,6 +54,14 @@ for label, os_, mbw in (("gaussian os=%g" % osamp, osamp, 0.0), ("gaussian os=1 
               f"algorithmic {alg / 1e6:.1f} MB -> {alg / t / 1e9:.1f} GB/s")
     L.pmi_free(img); L.pmi_free(dn)
 
+# CPU beside it: the C restatement of the reference's sequential loop (oracle), one core
+from oracle import oracle as orc  # noqa: E402
+for label, os_, mbw in (("gaussian os=%g" % osamp, osamp, 0.0), ("gaussian os=1 min_blur=1", 1.0, 1.0)):
+    t0 = time.perf_counter()
+    orc.render(x, y, os_, [(0, 0), (field, field)], lpx, lpy, "gaussian", mbw)
+    t = time.perf_counter() - t0
+    print(f"cpu oracle (1 core) {label:30s}: {t * 1e3:9.1f} ms  {N / t / 1e6:7.2f} M loc/s")
+
 # RCC: 10 segments of field x field (config 2: 10k frames, segmentation 1000)
 segs = np.zeros((10, field, field))
 for s in range(10):
@@ -64,3 +72,9 @@ t0 = time.perf_counter()
 peak, valid, rois, crop = backend.rcc_pairs_arrays(segs, 32, 5)
 t = time.perf_counter() - t0
 print(f"rcc_pairs: 10 segments {field}x{field}, 45 pairs (host buffers in/out): {t * 1e3:.2f} ms")
+t0 = time.perf_counter()
+for i in range(9):
+    for j in range(i + 1, 10):
+        orc.peak_window(segs[i], segs[j], 5, 32)
+t = time.perf_counter() - t0
+print(f"cpu numpy restatement of the same 45 correlations + peak windows: {t * 1e3:.1f} ms")

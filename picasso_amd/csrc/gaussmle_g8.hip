@@ -10,10 +10,11 @@
 //     x and for y — B+1 <= 8 boundaries serve all B pixels, a 7x cut over evaluating
 //     four erf per pixel;
 //   * boundary k+1 comes from lane j+1 by DPP row_shl:1; the per-column x terms of all
-//     B columns are exchanged inside the group through 160 B of LDS;
+//     B columns are exchanged inside the group through LDS;
 //   * the model is separable, so each lane accumulates ten row-local sums over its B
-//     pixels and multiplies by its row constants once; 12 group reductions of three
-//     DPP steps (quad_perm, quad_perm, row_half_mirror) serve 8 spots at once;
+//     pixels (packed float32: two sums per v_pk_fma_f32) and multiplies by its row
+//     constants once; the 12 group sums go through LDS so that lane l receives the
+//     numerator and denominator of parameter l and updates that one parameter;
 //   * three kernels: g8_init (initial theta and max_step per spot), g8_iterate (persistent
 //     waves; a group that converges stores its theta and immediately REFILLS with the next
 //     spot of its wave's chunk, so the eight groups never wait for the slowest spot — the
@@ -140,38 +141,70 @@ __device__ __forceinline__ void load_row(const FitParams &p, int64_t sidx, int j
 }
 
 // One Newton iteration for the eight groups of a wave (gaussmle.py:745-884 / :533-670).
-// th is updated in place when `active`; returns whether the group is still iterating.
+//
+// LDS of a group (G8_LDS floats):
+//   cols[8][12]  per column i: (Ax, Ex, Sx, A2x | S2x, 1, Ax^2, Ex^2 | Sx^2, 1, Sx*Ex, -), written by lane i
+//   red[8][12]   per row lane r: (num0, den0, ..., num5, den5) before the group sum
+//   bc[8]        the updated parameters, written by the lane that owns each one
+// The pixel loop feeds five packed-float32 accumulator pairs (v_pk_fma_f32: two sums per
+// instruction); the group sum goes through LDS so that lane l ends up with num[l], den[l] only
+// and updates ITS parameter (sixteen instructions in parallel instead of six parameters in
+// sequence in every lane), then the six new values are broadcast back through LDS.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+constexpr int G8_LDS = 8 * 12 + 8 * 12 + 8;
+
+struct LaneRole {          // what lane j does in the update stage: parameter j (j < NP)
+    float ms;              // max_step of its parameter
+    float floor_, cap;     // lower / upper clamp of its parameter (-inf / +inf = none)
+    float th;              // current value of its parameter
+    bool conv_rel;         // its parameter takes part in the convergence test
+};
+
 template <int NP, int B>
-__device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6], const float (&ms)[6], float *xs,
+__device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6], LaneRole &role, float *lds,
                                             int j, bool rowok, bool active, int &kk, double eps, int max_it)
 {
+    float *cols = lds, *red = lds + 96, *bc = lds + 192;
     const float jf = (float)j;
     const float sgy = NP == 6 ? th[5] : th[4];
     const BTerms tx = boundary_terms(jf, th[0], th[4]);     // column j
     const BTerms ty = boundary_terms(jf, th[1], sgy);       // row j
     __builtin_amdgcn_wave_barrier();
-    xs[0 * 8 + j] = tx.E; xs[1 * 8 + j] = tx.A; xs[2 * 8 + j] = tx.A2; xs[3 * 8 + j] = tx.S; xs[4 * 8 + j] = tx.S2;
+    {
+        float4 *c = reinterpret_cast<float4 *>(cols + j * 12);
+        c[0] = make_float4(tx.A, tx.E, tx.S, tx.A2);
+        c[1] = make_float4(tx.S2, 1.0f, tx.A * tx.A, tx.E * tx.E);
+        c[2] = make_float4(tx.S * tx.S, 1.0f, tx.S * tx.E, 0.0f);
+    }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
 
     const float N_ = th[2], bg = th[3];
     const float NEy = N_ * ty.E;
-    float a_cA = 0.f, a_cE = 0.f, a_c = 0.f, a_cS = 0.f, a_cA2 = 0.f, a_cS2 = 0.f;
-    float a_dA = 0.f, a_dE = 0.f, a_d = 0.f, a_dS = 0.f, a_dSE = 0.f;
+    f32x2 pA_E = {0.f, 0.f}, pS_A2 = {0.f, 0.f}, pS2_1 = {0.f, 0.f};      // cf * (Ax, Ex), (Sx, A2x), (S2x, 1)
+    f32x2 qA_E = {0.f, 0.f}, qS_1 = {0.f, 0.f};                           // df * (Ax^2, Ex^2), (Sx^2, 1)
+    float a_dSE = 0.f;
 #pragma unroll
     for (int i = 0; i < B; i++) {
-        const float Ex = xs[0 * 8 + i], Ax = xs[1 * 8 + i], A2x = xs[2 * 8 + i], Sx = xs[3 * 8 + i], S2x = xs[4 * 8 + i];
-        const float model = NEy * Ex + bg;
+        const float4 *c = reinterpret_cast<const float4 *>(cols + i * 12);
+        const float4 c0 = c[0], c1 = c[1], c2 = c[2];
+        const float model = NEy * c0.y + bg;
         const float r = rcp_f32(model);
         const float dr = d[i] * r;
         const bool ok = model > 10e-3f;             // gaussmle.py:831: otherwise cf = df = 0
         // plain fminf: a NaN can only enter through a NaN pixel, and then theta is NaN from g8_init on
         const float cf = ok ? fminf(dr - 1.f, 10e4f) : 0.f;
         const float df = ok ? fminf(dr * r, 10e4f) : 0.f;
-        a_cA += cf * Ax; a_cE += cf * Ex; a_c += cf; a_cS += cf * Sx; a_cA2 += cf * A2x; a_cS2 += cf * S2x;
-        a_dA += df * Ax * Ax; a_dE += df * Ex * Ex; a_d += df; a_dS += df * Sx * Sx;
-        if (NP == 5) a_dSE += df * Sx * Ex;
+        const f32x2 cf2 = {cf, cf}, df2 = {df, df};
+        pA_E = cf2 * (f32x2){c0.x, c0.y} + pA_E;
+        pS_A2 = cf2 * (f32x2){c0.z, c0.w} + pS_A2;
+        pS2_1 = cf2 * (f32x2){c1.x, c1.y} + pS2_1;
+        qA_E = df2 * (f32x2){c1.z, c1.w} + qA_E;
+        qS_1 = df2 * (f32x2){c2.x, c2.y} + qS_1;
+        if (NP == 5) a_dSE += df * c2.z;
     }
+    const float a_cA = pA_E.x, a_cE = pA_E.y, a_cS = pS_A2.x, a_cA2 = pS_A2.y, a_cS2 = pS2_1.x, a_c = pS2_1.y;
+    const float a_dA = qA_E.x, a_dE = qA_E.y, a_dS = qS_1.x, a_d = qS_1.y;
     float num[6], den[6];
     const float NAy = N_ * ty.A, NA2y = N_ * ty.A2, NSy = N_ * ty.S, NS2y = N_ * ty.S2;
     num[0] = NEy * a_cA;              den[0] = NEy * a_cA2 - NEy * NEy * a_dA;
@@ -192,41 +225,61 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
 #pragma unroll
         for (int l = 0; l < 6; l++) { num[l] = 0.f; den[l] = 0.f; }
     }
-#pragma unroll
-    for (int l = 0; l < NP; l++) { num[l] = sum8(num[l]); den[l] = sum8(den[l]); }
-
-    float nt[6];
-#pragma unroll
-    for (int l = 0; l < 6; l++) nt[l] = th[l];
-    bool conv;
-    if (NP == 6) {                                  // gaussmle.py:860-884
-#pragma unroll
-        for (int l = 0; l < 6; l++) {
-            const float stepz = np_signf(num[l]) * ms[l];                 // zero denominator (gaussmle.py:873)
-            const float stepn = clip_np(num[l] * rcp_f32(den[l]), ms[l]);
-            nt[l] = th[l] - (den[l] == 0.0f ? stepz : stepn);
-        }
-        nt[2] = max_np(nt[2], 1.0f); nt[3] = max_np(nt[3], 0.01f);
-        nt[4] = max_np(nt[4], 0.01f); nt[5] = max_np(nt[5], 0.01f);
-        conv = ((double)fabsf(th[0] - nt[0]) < eps) && ((double)fabsf(th[1] - nt[1]) < eps) &&
-               ((double)fabsf(th[4] - nt[4]) < eps) && ((double)fabsf(th[5] - nt[5]) < eps);
-    } else {                                        // gaussmle.py:647-670
-#pragma unroll
-        for (int l = 0; l < 5; l++) {
-            const float stepz = np_signf(num[l] * ms[l]);                 // +-1, not +-max_step (gaussmle.py:658)
-            const float stepn = clip_np(num[l] * rcp_f32(den[l]), ms[l]);
-            nt[l] = th[l] - (den[l] == 0.0f ? stepz : stepn);
-        }
-        nt[2] = max_np(nt[2], 1.0f); nt[3] = max_np(nt[3], 0.01f);
-        nt[4] = max_np(nt[4], 0.01f); nt[4] = min_np(nt[4], (float)B);
-        conv = ((double)fabsf(th[0] - nt[0]) < eps) && ((double)fabsf(th[1] - nt[1]) < eps);
+    {
+        float4 *ro = reinterpret_cast<float4 *>(red + j * 12);
+        ro[0] = make_float4(num[0], den[0], num[1], den[1]);
+        ro[1] = make_float4(num[2], den[2], num[3], den[3]);
+        ro[2] = make_float4(num[4], den[4], num[5], den[5]);
     }
-    // the previous-iteration values the reference compares with ARE th (old_x = theta after every pass);
-    // finished groups keep their state (selects, no branch)
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    // lane l sums (num[l], den[l]) over the eight row lanes, in row order
+    const int l = j < 6 ? j : 5;
+    f32x2 nd = {0.f, 0.f};
 #pragma unroll
-    for (int l = 0; l < 6; l++) th[l] = active ? nt[l] : th[l];
+    for (int r = 0; r < 8; r++) {
+        const float2 v = *reinterpret_cast<const float2 *>(red + r * 12 + 2 * l);
+        nd = nd + (f32x2){v.x, v.y};
+    }
+    const float numl = nd.x, denl = nd.y;
+    // update of this lane's parameter (gaussmle.py:860-884 / :647-670); zero denominator:
+    // sigmaxy steps sign(num) * max_step (:873), sigma steps sign(num * max_step) = +-1 (:658)
+    const float stepz = NP == 6 ? np_signf(numl) * role.ms : np_signf(numl * role.ms);
+    const float stepn = clip_np(numl * rcp_f32(denl), role.ms);
+    float nt = role.th - (denl == 0.0f ? stepz : stepn);
+    nt = max_np(nt, role.floor_);
+    nt = min_np(nt, role.cap);
+    const bool conv_l = !role.conv_rel || ((double)fabsf(role.th - nt) < eps);
+    const unsigned long long vote = __ballot(conv_l);
+    const bool conv = ((vote >> (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & ~7u)) & 0xffull) == 0xffull;
+    // the previous-iteration values the reference compares with ARE th (old_x = theta after every pass);
+    // finished groups keep their state
+    role.th = active ? nt : role.th;
+    bc[j] = role.th;
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    {
+        const float4 t0 = *reinterpret_cast<const float4 *>(bc);
+        const float2 t1 = *reinterpret_cast<const float2 *>(bc + 4);
+        th[0] = t0.x; th[1] = t0.y; th[2] = t0.z; th[3] = t0.w; th[4] = t1.x;
+        if (NP == 6) th[5] = t1.y;
+    }
     kk += active ? 1 : 0;
     return active && !(conv || kk >= max_it);
+}
+
+// role of lane j for a freshly loaded spot
+template <int NP, int B>
+__device__ __forceinline__ LaneRole make_role(const float (&th)[6], const float (&ms)[6], int j)
+{
+    LaneRole r;
+    r.ms = 0.f; r.th = 0.f;
+#pragma unroll
+    for (int l = 0; l < 6; l++) { r.ms = (j == l) ? ms[l] : r.ms; r.th = (j == l) ? th[l] : r.th; }
+    r.floor_ = j == 2 ? 1.0f : ((j == 3 || j == 4 || (NP == 6 && j == 5)) ? 0.01f : -INFINITY);
+    r.cap = (NP == 5 && j == 4) ? (float)B : INFINITY;
+    r.conv_rel = NP == 6 ? (j == 0 || j == 1 || j == 4 || j == 5) : (j == 0 || j == 1);
+    return r;
 }
 
 // ---- kernel 1: initial parameters (gaussmle.py:28-168) ----------------------
@@ -331,7 +384,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_init_kernel(FitParams p, float *__r
 template <int NP, int B, bool FROM_MOVIE>
 __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const float *__restrict__ state)
 {
-    __shared__ float s_x[FIT_WAVES][8][5][8];       // x terms of every column: [wave][group][term][col]
+    __shared__ __attribute__((aligned(16))) float s_x[FIT_WAVES][8][G8_LDS];       // per group: columns, reduction, broadcast
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = lane >> 3, j = lane & 7;
     const bool rowok = j < B;
@@ -347,12 +400,13 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
     const int64_t end = next + chunk < n ? next + chunk : n;
     if (next >= end) return;
 
-    float *xs = &s_x[wid][g][0][0];
+    float *xs = &s_x[wid][g][0];
     float d[B], th[6], ms[6];
 #pragma unroll
     for (int i = 0; i < B; i++) d[i] = 1.f;
 #pragma unroll
     for (int l = 0; l < 6; l++) { th[l] = 1.f; ms[l] = 1.f; }
+    LaneRole role = make_role<NP, B>(th, ms, j);
     int kk = 0;
     int64_t sidx = -1;
     bool active = false;
@@ -379,6 +433,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
                     th[0] = s0.x; th[1] = s0.y; th[2] = s0.z; th[3] = s0.w; th[4] = s1.x; th[5] = s1.y;
                     ms[0] = s1.z; ms[1] = s1.w; ms[2] = s2.x; ms[3] = s2.y; ms[4] = s2.z; ms[5] = s2.w;
                     load_row<B, FROM_MOVIE>(p, sidx, j, rowok, d);
+                    role = make_role<NP, B>(th, ms, j);
                     kk = 0;
                     active = p.max_it > 0;
                     if (!active && j == 0) {          // max_it == 0: the initial theta is the result
@@ -397,7 +452,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
                 continue;
             }
         }
-        active = newton_step<NP, B>(d, th, ms, xs, j, rowok, active, kk, p.eps, p.max_it);
+        active = newton_step<NP, B>(d, th, role, xs, j, rowok, active, kk, p.eps, p.max_it);
     }
 }
 

@@ -15,7 +15,7 @@ import threading
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libpicasso_hip.so")
+LIB_PATH = os.environ.get("PICASSO_AMD_LIB") or os.path.join(_HERE, "libpicasso_hip.so")      # override: A/B builds
 
 PMI_OK = 0
 PMI_ERR_CAPACITY = 1

@@ -151,6 +151,9 @@ __device__ __forceinline__ void load_row(const FitParams &p, int64_t sidx, int j
 // and updates ITS parameter (sixteen instructions in parallel instead of six parameters in
 // sequence in every lane), then the six new values are broadcast back through LDS.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+#ifndef G8_REFILL_K
+#define G8_REFILL_K 2
+#endif
 constexpr int G8_LDS = 8 * 12 + 8 * 12 + 8;
 
 struct LaneRole {          // what lane j does in the update stage: parameter j (j < NP)
@@ -413,7 +416,14 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
     const unsigned long long below = (1ull << (lane & ~7)) - 1ull;     // lanes of lower groups
 
     for (;;) {
-        if (__any(!active)) {
+        // Refills are batched: the refill block (publish theta, fetch state and pixels of the next spot)
+        // costs about as much as a Newton iteration for the whole wave, and with eight groups that
+        // converge after ~8 iterations each it would run almost every iteration.  A finished group
+        // therefore waits until G8_REFILL_K groups are finished (or nothing else is running).
+        const unsigned long long pend = __ballot(!active && sidx >= 0 && j == 0);      // finished, not yet published
+        const unsigned long long empty = __ballot(!active && sidx < 0 && j == 0);      // no spot at all
+        const bool any_active = __any(active);
+        if (__popcll(pend) >= G8_REFILL_K || (pend != 0 && !any_active) || (empty != 0 && next < end)) {
             // finished groups publish theta / iteration count, then take the next spots of the chunk
             if (!active && sidx >= 0 && j == 0) {
                 float *to = p.thetas + sidx * 6;
@@ -422,7 +432,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
                 to[5] = NP == 6 ? th[5] : th[4];
                 p.iterations[sidx] = kk;
             }
-            const unsigned long long want = __ballot(!active && j == 0);
+            const unsigned long long want = pend | empty;
             const int64_t cand = next + __popcll(want & below);
             if (!active) {
                 sidx = -1;
@@ -451,6 +461,8 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
                 if (next >= end) break;
                 continue;
             }
+        } else if (!any_active) {
+            break;                                     // nothing running, nothing pending, chunk exhausted
         }
         active = newton_step<NP, B>(d, th, role, xs, j, rowok, active, kk, p.eps, p.max_it);
     }

@@ -4,10 +4,11 @@
 // MINPACK lmdif with a forward-difference Jacobian (epsfcn = float32 eps because
 // the residual vector is float32), gtol = 0, factor = 100, maxfev = 1400, on the
 // residuals of a point-sampled elliptical Gaussian whose model is stored in
-// float32 (gausslq.py:151-203).  This file restates that algorithm for one
-// wavefront per spot:
+// float32 (gausslq.py:151-203).  This file restates that algorithm for one group of lanes
+// per spot — a 16-lane DPP row for boxes up to 7x7 (four spots per wavefront), the whole
+// wavefront for larger boxes:
 //
-//   - residual row r = i*size + j lives in lane r % 64, element r / 64, so the
+//   - residual row r = i*size + j lives in lane r % GS, element r / GS, so the
 //     m x 6 Jacobian is six register columns per lane; column norms and the
 //     Householder dot products of qrfac are DPP wave reductions in float64;
 //   - the 6 x 6 triangular factor, lmpar and qrsolv are wave-uniform register code
@@ -57,6 +58,48 @@ __device__ __forceinline__ double wave_max_d(double v)
     for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
     return v;
 }
+
+// A spot is fitted by a group of GS lanes: the whole wavefront (GS = 64) or one 16-lane DPP row
+// (GS = 16, four spots per wavefront — for boxes up to 7x7 the 6x6 stage, which every lane of the
+// group executes identically, is most of the work).  All lanes of a group follow the same control
+// flow, so row-wide DPP and bpermute never read an inactive lane.
+template <int GS> struct Grp;
+template <> struct Grp<64> {
+    static __device__ __forceinline__ double sum_d(double v) { return wave_sum_d(v); }
+    static __device__ __forceinline__ double max_d(double v) { return wave_max_d(v); }
+    static __device__ __forceinline__ float min_f(float v) { return wave_min(v); }
+    static __device__ __forceinline__ double bcast_d(double v, int k) { return readlane_d(v, k); }
+    static __device__ __forceinline__ bool any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
+};
+template <> struct Grp<16> {
+    static __device__ __forceinline__ double sum_d(double v)
+    {
+        v += dpp_d<0xB1>(v);          // quad_perm [1,0,3,2]
+        v += dpp_d<0x4E>(v);          // quad_perm [2,3,0,1]
+        v += dpp_d<0x141>(v);         // row_half_mirror
+        v += dpp_d<0x140>(v);         // row_mirror: every lane of the row holds the row sum
+        return v;
+    }
+    static __device__ __forceinline__ double max_d(double v)
+    {
+        for (int off = 8; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+        return v;
+    }
+    static __device__ __forceinline__ float min_f(float v)
+    {
+        for (int off = 8; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+        return v;
+    }
+    static __device__ __forceinline__ double bcast_d(double v, int k)
+    {
+        return __shfl(v, (int)((threadIdx.x & 63u) & ~15u) + k);
+    }
+    static __device__ __forceinline__ bool any(bool c)
+    {
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(c);
+        return ((b >> ((threadIdx.x & 63u) & ~15u)) & 0xffffull) != 0;
+    }
+};
 // Indexing a 6-vector by a run-time (wave-uniform) index without leaving registers.
 // The empty asm hides the loads from InstCombine, which otherwise rewrites the select
 // chain into one load through a computed address and pins the array in scratch memory.
@@ -102,7 +145,7 @@ __device__ __forceinline__ double enorm6(const double (&x)[6])
 // enorm over rows [row_lo, m) of a register column.  Mid-range components (all of
 // them, for finite photon data) take one reduction; the scaled accumulators of
 // MINPACK are only formed when a component is tiny, huge or NaN.
-template <int E>
+template <int GS, int E>
 __device__ __forceinline__ double enorm_rows(const double (&v)[E], int lane, int row_lo, int m)
 {
     const double agiant = RGIANT / (double)(m - row_lo);
@@ -110,20 +153,20 @@ __device__ __forceinline__ double enorm_rows(const double (&v)[E], int lane, int
     bool odd = false;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int r = lane + 64 * e;
+        const int r = lane + GS * e;
         if (r >= row_lo && r < m) {
             const double xabs = fabs(v[e]);
             if (xabs > RDWARF && xabs < agiant) s2 += xabs * xabs;
             else if (xabs != 0) odd = true;
         }
     }
-    s2 = wave_sum_d(s2);
-    if (__builtin_amdgcn_ballot_w64(odd) == 0) return sqrt(s2);
+    s2 = Grp<GS>::sum_d(s2);
+    if (!Grp<GS>::any(odd)) return sqrt(s2);
     double big = 0, small = 0;
     bool isnan_ = false;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int r = lane + 64 * e;
+        const int r = lane + GS * e;
         if (r >= row_lo && r < m) {
             const double xabs = fabs(v[e]);
             if (xabs != xabs) isnan_ = true;
@@ -131,20 +174,20 @@ __device__ __forceinline__ double enorm_rows(const double (&v)[E], int lane, int
             else if (xabs <= RDWARF) small = fmax(small, xabs);
         }
     }
-    if (__builtin_amdgcn_ballot_w64(isnan_) != 0) return __builtin_nan("");
-    const double x1max = wave_max_d(big), x3max = wave_max_d(small);
+    if (Grp<GS>::any(isnan_)) return __builtin_nan("");
+    const double x1max = Grp<GS>::max_d(big), x3max = Grp<GS>::max_d(small);
     double s1 = 0, s3 = 0;
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int r = lane + 64 * e;
+        const int r = lane + GS * e;
         if (r >= row_lo && r < m) {
             const double xabs = fabs(v[e]);
             if (xabs >= agiant) { double q = xabs / x1max; s1 += q * q; }
             else if (xabs <= RDWARF && xabs != 0) { double q = xabs / x3max; s3 += q * q; }
         }
     }
-    s1 = wave_sum_d(s1);
-    s3 = wave_sum_d(s3);
+    s1 = Grp<GS>::sum_d(s1);
+    s3 = Grp<GS>::sum_d(s3);
     if (s1 != 0) return x1max * sqrt(s1 + (s2 / x1max) / x1max);
     if (s2 != 0) {
         if (s2 >= x3max) return sqrt(s2 * (1 + (x3max / s2) * (x3max * s3)));
@@ -156,7 +199,7 @@ __device__ __forceinline__ double enorm_rows(const double (&v)[E], int lane, int
 // Residuals of the float32-stored model (gausslq.py:151-203).  Lanes [0, size)
 // evaluate the x profile, lanes [size, 2 size) the y profile; every row then
 // fetches its two factors.
-template <int E>
+template <int GS, int E>
 __device__ __forceinline__ void residuals(const double (&th)[6], const float (&sp)[E], const int (&ri)[E],
                                           const int (&rj)[E], const bool (&act)[E], int size, int lane,
                                           double (&out)[E])
@@ -172,8 +215,9 @@ __device__ __forceinline__ void residuals(const double (&th)[6], const float (&s
     const float prof = (float)(nrm * exp(-0.5 * (t * t)));
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const float mxv = __shfl(prof, rj[e]);
-        const float myv = __shfl(prof, size + ri[e]);
+        const int gbase = GS == 64 ? 0 : (int)((threadIdx.x & 63u) & ~15u);     // first lane of this group
+        const float mxv = __shfl(prof, gbase + rj[e]);
+        const float myv = __shfl(prof, gbase + size + ri[e]);
         const float model = (float)(th[2] * (double)myv * (double)mxv + th[3]);
         const float res = sp[e] - model;
         out[e] = act[e] ? (double)res : 0.0;
@@ -339,7 +383,7 @@ __device__ __forceinline__ void lmpar(double (&R)[6][6], const int (&ipvt)[6], c
 
 // One column of MINPACK qrfac (pivot, Householder vector, update of the trailing
 // columns and of their running norms).  rdiag = wa1, wa = wa3.
-template <int E, int j>
+template <int GS, int E, int j>
 __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], double (&wa3)[6], int (&ipvt)[6],
                                            int lane, int m)
 {
@@ -365,32 +409,32 @@ __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], 
         ipvt[j] = sw ? u : t;
         ipvt[k] = sw ? t : u;
     }
-    double ajnorm = enorm_rows<E>(a[j], lane, j, m);
+    double ajnorm = enorm_rows<GS, E>(a[j], lane, j, m);
     if (ajnorm != 0) {
-        if (readlane_d(a[j][0], j) < 0) ajnorm = -ajnorm;
+        if (Grp<GS>::bcast_d(a[j][0], j) < 0) ajnorm = -ajnorm;
 #pragma unroll
         for (int e = 0; e < E; e++)
             if (e > 0 || lane >= j) a[j][e] /= ajnorm;
         if (lane == j) a[j][0] += 1;
-        const double ajj = readlane_d(a[j][0], j);
+        const double ajj = Grp<GS>::bcast_d(a[j][0], j);
 #pragma unroll
         for (int k = j + 1; k < 6; k++) {
             double sum = 0;
 #pragma unroll
             for (int e = 0; e < E; e++)
                 if (e > 0 || lane >= j) sum += a[j][e] * a[k][e];
-            sum = wave_sum_d(sum);
+            sum = Grp<GS>::sum_d(sum);
             double temp = sum / ajj;
 #pragma unroll
             for (int e = 0; e < E; e++)
                 if (e > 0 || lane >= j) a[k][e] -= temp * a[j][e];
             if (wa1[k] != 0) {
-                temp = readlane_d(a[k][0], j) / wa1[k];
+                temp = Grp<GS>::bcast_d(a[k][0], j) / wa1[k];
                 const double t2 = 1 - temp * temp;
                 wa1[k] *= sqrt(t2 > 0 ? t2 : 0);
                 const double q = wa1[k] / wa3[k];
                 if (0.05 * (q * q) <= EPSMCH) {
-                    wa1[k] = enorm_rows<E>(a[k], lane, j + 1, m);
+                    wa1[k] = enorm_rows<GS, E>(a[k], lane, j + 1, m);
                     wa3[k] = wa1[k];
                 }
             }
@@ -399,10 +443,12 @@ __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], 
     wa1[j] = -ajnorm;
 }
 
-template <int E, bool FROM_MOVIE>
+template <int GS, int E, bool FROM_MOVIE>
 __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
 {
-    const int lane = threadIdx.x & 63;
+    constexpr int NGRP = 64 / GS;                              // spots per wavefront
+    const int lane = (threadIdx.x & 63) % GS;                  // lane inside the group
+    const int grp = (threadIdx.x & 63) / GS;
     const int64_t wave0 = (int64_t)blockIdx.x * LQ_WAVES + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * LQ_WAVES;
     int64_t n = p.N;
@@ -412,7 +458,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
     bool act[E];
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int r = lane + 64 * e;
+        const int r = lane + GS * e;
         act[e] = r < m;
         const int rr = act[e] ? r : 0;
         ri[e] = rr / size;
@@ -422,7 +468,10 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
     const int maxfev = 200 * (6 + 1);
     const double eps = sqrt(1.1920928955078125e-07);     // sqrt(max(epsfcn, epsmch)), epsfcn = float32 eps
 
-    for (int64_t s = wave0; s < n; s += nwaves) {
+    for (int64_t s0 = wave0 * NGRP; s0 < n; s0 += nwaves * NGRP) {
+        // a group past the end refits the last spot and does not store (keeps the groups in lockstep)
+        const bool store = s0 + grp < n;
+        const int64_t s = store ? s0 + grp : n - 1;
         // ---- the spot: rows of this lane ----
         float sp[E];
         if (FROM_MOVIE) {
@@ -437,7 +486,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
             }
         } else {
 #pragma unroll
-            for (int e = 0; e < E; e++) sp[e] = act[e] ? p.spots[s * m + lane + 64 * e] : 0.f;
+            for (int e = 0; e < E; e++) sp[e] = act[e] ? p.spots[s * m + lane + GS * e] : 0.f;
         }
 
         // ---- initial parameters (gausslq.py:95-112) ----
@@ -448,8 +497,8 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
 #pragma unroll
             for (int e = 0; e < E; e++)
                 if (act[e]) { mn = fminf(mn, sp[e]); anynan |= sp[e] != sp[e]; }
-            mn = wave_min(mn);
-            if (__builtin_amdgcn_ballot_w64(anynan) != 0) mn = __builtin_nanf("");
+            mn = Grp<GS>::min_f(mn);
+            if (Grp<GS>::any(anynan)) mn = __builtin_nanf("");
             double sy = 0, sx = 0, sum = 0;
             double v[E];
 #pragma unroll
@@ -459,7 +508,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
                 sx += v[e] * (double)rj[e];
                 sum += v[e];
             }
-            sy = wave_sum_d(sy); sx = wave_sum_d(sx); sum = wave_sum_d(sum);
+            sy = Grp<GS>::sum_d(sy); sx = Grp<GS>::sum_d(sx); sum = Grp<GS>::sum_d(sum);
             if (sum <= 0.0) { sum = 0.01; sy = (size - 1) / 2.0; sx = (size - 1) / 2.0; }
             else { sy /= sum; sx /= sum; }
             float t1 = (float)sy, t0 = (float)sx;
@@ -471,7 +520,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
                 sdy += v[e] * (dy * dy);
                 sdx += v[e] * (dx * dx);
             }
-            sdy = wave_sum_d(sdy); sdx = wave_sum_d(sdx);
+            sdy = Grp<GS>::sum_d(sdy); sdx = Grp<GS>::sum_d(sdx);
             const float t5 = (float)sqrt(sdy / sum), t4 = (float)sqrt(sdx / sum);
             t0 = t0 - (float)hsz;
             t1 = t1 - (float)hsz;
@@ -486,8 +535,8 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
         int ipvt[6];
         int info = 0, nfev = 1, iter = 1;
         double par = 0, delta = 0, xnorm = 0, gnorm = 0, fnorm, fnorm1, actred, prered, dirder, ratio, pnorm;
-        residuals<E>(x, sp, ri, rj, act, size, lane, fv);
-        fnorm = enorm_rows<E>(fv, lane, 0, m);
+        residuals<GS, E>(x, sp, ri, rj, act, size, lane, fv);
+        fnorm = enorm_rows<GS, E>(fv, lane, 0, m);
         for (;;) {
             // fdjac2
 #pragma unroll
@@ -496,7 +545,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
                 double hstep = eps * fabs(temp);
                 if (hstep == 0) hstep = eps;
                 x[j] = temp + hstep;
-                residuals<E>(x, sp, ri, rj, act, size, lane, w4);
+                residuals<GS, E>(x, sp, ri, rj, act, size, lane, w4);
                 x[j] = temp;
 #pragma unroll
                 for (int e = 0; e < E; e++) a[j][e] = (w4[e] - fv[e]) / hstep;
@@ -505,17 +554,17 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
             // qrfac with column pivoting: rdiag = wa1, acnorm = wa2, wa = wa3
 #pragma unroll
             for (int j = 0; j < 6; j++) {
-                wa2[j] = enorm_rows<E>(a[j], lane, 0, m);
+                wa2[j] = enorm_rows<GS, E>(a[j], lane, 0, m);
                 wa1[j] = wa2[j];
                 wa3[j] = wa1[j];
                 ipvt[j] = j;
             }
-            qrfac_step<E, 0>(a, wa1, wa3, ipvt, lane, m);
-            qrfac_step<E, 1>(a, wa1, wa3, ipvt, lane, m);
-            qrfac_step<E, 2>(a, wa1, wa3, ipvt, lane, m);
-            qrfac_step<E, 3>(a, wa1, wa3, ipvt, lane, m);
-            qrfac_step<E, 4>(a, wa1, wa3, ipvt, lane, m);
-            qrfac_step<E, 5>(a, wa1, wa3, ipvt, lane, m);
+            qrfac_step<GS, E, 0>(a, wa1, wa3, ipvt, lane, m);
+            qrfac_step<GS, E, 1>(a, wa1, wa3, ipvt, lane, m);
+            qrfac_step<GS, E, 2>(a, wa1, wa3, ipvt, lane, m);
+            qrfac_step<GS, E, 3>(a, wa1, wa3, ipvt, lane, m);
+            qrfac_step<GS, E, 4>(a, wa1, wa3, ipvt, lane, m);
+            qrfac_step<GS, E, 5>(a, wa1, wa3, ipvt, lane, m);
             if (iter == 1) {
 #pragma unroll
                 for (int j = 0; j < 6; j++) { diag[j] = wa2[j]; if (wa2[j] == 0) diag[j] = 1; }
@@ -530,25 +579,25 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
             for (int e = 0; e < E; e++) w4[e] = fv[e];
 #pragma unroll
             for (int j = 0; j < 6; j++) {
-                const double ajj = readlane_d(a[j][0], j);
+                const double ajj = Grp<GS>::bcast_d(a[j][0], j);
                 if (ajj != 0) {
                     double sum = 0;
 #pragma unroll
                     for (int e = 0; e < E; e++)
                         if (e > 0 || lane >= j) sum += a[j][e] * w4[e];
-                    sum = wave_sum_d(sum);
+                    sum = Grp<GS>::sum_d(sum);
                     const double temp = -sum / ajj;
 #pragma unroll
                     for (int e = 0; e < E; e++)
                         if (e > 0 || lane >= j) w4[e] += a[j][e] * temp;
                 }
                 if (lane == j) a[j][0] = wa1[j];
-                qtf[j] = readlane_d(w4[0], j);
+                qtf[j] = Grp<GS>::bcast_d(w4[0], j);
             }
 #pragma unroll
             for (int j = 0; j < 6; j++)
 #pragma unroll
-                for (int i = 0; i < 6; i++) R[i][j] = (i <= j) ? readlane_d(a[j][0], i) : 0.0;
+                for (int i = 0; i < 6; i++) R[i][j] = (i <= j) ? Grp<GS>::bcast_d(a[j][0], i) : 0.0;
             gnorm = 0;
             if (fnorm != 0) {
 #pragma unroll
@@ -573,9 +622,9 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
                 for (int j = 0; j < 6; j++) { wa1[j] = -wa1[j]; wa2[j] = x[j] + wa1[j]; wa3[j] = diag[j] * wa1[j]; }
                 pnorm = enorm6(wa3);
                 if (iter == 1 && pnorm < delta) delta = pnorm;
-                residuals<E>(wa2, sp, ri, rj, act, size, lane, w4);
+                residuals<GS, E>(wa2, sp, ri, rj, act, size, lane, w4);
                 nfev++;
-                fnorm1 = enorm_rows<E>(w4, lane, 0, m);
+                fnorm1 = enorm_rows<GS, E>(w4, lane, 0, m);
                 actred = -1;
                 if (0.1 * fnorm1 < fnorm) { const double r = fnorm1 / fnorm; actred = 1 - r * r; }
 #pragma unroll
@@ -624,8 +673,8 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
             }
             if (info != 0) break;
         }
-        if (lane < 6) p.thetas[s * 6 + lane] = (float)get6(x, lane);
-        if (lane == 0) {
+        if (store && lane < 6) p.thetas[s * 6 + lane] = (float)get6(x, lane);
+        if (store && lane == 0) {
             if (p.info) p.info[s] = info;
             if (p.nfev) p.nfev[s] = nfev;
         }
@@ -639,14 +688,22 @@ static int launch(const Params &p, hipStream_t s)
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int m = p.box * p.box;
-    const int e = (m + 63) / 64;
-    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((p.N + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16));
-    dim3 grid((unsigned)blocks), block(LQ_WAVES * 64);
-    if (e <= 1) hipLaunchKernelGGL((lq_fit_kernel<1, FROM_MOVIE>), grid, block, 0, s, p);
-    else if (e <= 2) hipLaunchKernelGGL((lq_fit_kernel<2, FROM_MOVIE>), grid, block, 0, s, p);
-    else if (e <= 3) hipLaunchKernelGGL((lq_fit_kernel<3, FROM_MOVIE>), grid, block, 0, s, p);
-    else if (e <= 4) hipLaunchKernelGGL((lq_fit_kernel<4, FROM_MOVIE>), grid, block, 0, s, p);
-    else hipLaunchKernelGGL((lq_fit_kernel<7, FROM_MOVIE>), grid, block, 0, s, p);
+    dim3 block(LQ_WAVES * 64);
+    if (p.box <= 7) {
+        // four spots per wavefront (2 * box <= 16 lanes evaluate the two profiles of a residual evaluation)
+        const int64_t waves = (p.N + 3) / 4;
+        dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
+        if (m <= 16) hipLaunchKernelGGL((lq_fit_kernel<16, 1, FROM_MOVIE>), grid, block, 0, s, p);
+        else if (m <= 32) hipLaunchKernelGGL((lq_fit_kernel<16, 2, FROM_MOVIE>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((lq_fit_kernel<16, 4, FROM_MOVIE>), grid, block, 0, s, p);
+    } else {
+        const int e = (m + 63) / 64;
+        dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((p.N + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
+        if (e <= 2) hipLaunchKernelGGL((lq_fit_kernel<64, 2, FROM_MOVIE>), grid, block, 0, s, p);
+        else if (e <= 3) hipLaunchKernelGGL((lq_fit_kernel<64, 3, FROM_MOVIE>), grid, block, 0, s, p);
+        else if (e <= 4) hipLaunchKernelGGL((lq_fit_kernel<64, 4, FROM_MOVIE>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((lq_fit_kernel<64, 7, FROM_MOVIE>), grid, block, 0, s, p);
+    }
     PMI_HIP(hipGetLastError());
     return PMI_OK;
 }

@@ -240,6 +240,11 @@ int pmi_render_gaussian_dev(const float *d_x, const float *d_y, const float *d_l
 int pmi_xcorr(const double *image_a, const double *image_b, int64_t Y, int64_t X, double *out);
 int pmi_rcc_pairs(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
                   int32_t *peak_yx, int32_t *valid, double *fit_rois, int32_t *crop_yx);
+/* The same for an explicit list of n_pairs (i, j) index pairs — the share of one rank when the
+ * n(n-1)/2 correlations of RCC are split over several GPUs.      */
+int pmi_rcc_pair_list(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
+                      const int32_t *pairs, int64_t n_pairs, int32_t *peak_yx, int32_t *valid,
+                      double *fit_rois, int32_t *crop_yx);
 
 /* ---- timing hooks for bench.py (HIP events on the given stream) ------- */
 int pmi_event_create(void **event);

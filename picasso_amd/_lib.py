@@ -72,6 +72,7 @@ SYMBOLS = {
     "pmi_render_gaussian_dev": (_i32, [_p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _p, _i64, _i64, _p, _p]),
     "pmi_xcorr": (_i32, [_p, _p, _i64, _i64, _p]),
     "pmi_rcc_pairs": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p]),
+    "pmi_rcc_pair_list": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _i64, _p, _p, _p, _p]),
     "pmi_event_create": (_i32, [_p]),
     "pmi_event_record": (_i32, [_p, _p]),
     "pmi_event_elapsed_ms": (_i32, [_p, _p, _p]),

@@ -224,23 +224,27 @@ def xcorr_array(image_a, image_b) -> np.ndarray:
     return out
 
 
-def rcc_pairs_arrays(segments, roi, box: int):
-    """All pairs i < j of the segment images -> peak (n_pairs, 2), valid (n_pairs), fit windows
-    (n_pairs, box, box) float64 and the crop offsets (Y_, X_)."""
+def rcc_pairs_arrays(segments, roi, box: int, pairs=None):
+    """Pairs (i, j) of the segment images (all i < j when `pairs` is None) -> peak (n_pairs, 2),
+    valid (n_pairs), fit windows (n_pairs, box, box) float64 and the crop offsets (Y_, X_)."""
     _lib.require_gpu()
     seg = np.ascontiguousarray(segments, np.float64)
     if seg.ndim != 3:
         raise ValueError("segments must have shape (n, Y, X)")
     n, Y, X = seg.shape
-    n_pairs = n * (n - 1) // 2
+    if pairs is None:
+        pairs = [(i, j) for i in range(n - 1) for j in range(i + 1, n)]
+    pairs = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+    n_pairs = len(pairs)
     peak = np.zeros((n_pairs, 2), np.int32)
     valid = np.zeros(n_pairs, np.int32)
     rois = np.zeros((n_pairs, box, box), np.float64)
     crop = np.zeros(2, np.int32)
     with _lib.lock():
-        rc = _lib.load().pmi_rcc_pairs(_lib.ptr(seg), n, Y, X, int(roi) if roi is not None else 0, int(box),
-                                       _lib.ptr(peak), _lib.ptr(valid), _lib.ptr(rois), _lib.ptr(crop))
-    _lib.check(rc, "pmi_rcc_pairs")
+        rc = _lib.load().pmi_rcc_pair_list(_lib.ptr(seg), n, Y, X, int(roi) if roi is not None else 0, int(box),
+                                           _lib.ptr(pairs), n_pairs, _lib.ptr(peak), _lib.ptr(valid), _lib.ptr(rois),
+                                           _lib.ptr(crop))
+    _lib.check(rc, "pmi_rcc_pair_list")
     return peak, valid, rois, (int(crop[0]), int(crop[1]))
 
 

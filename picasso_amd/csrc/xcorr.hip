@@ -163,13 +163,16 @@ int pmi_xcorr(const double *image_a, const double *image_b, int64_t Y, int64_t X
     return PMI_OK;
 }
 
-int pmi_rcc_pairs(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
-                  int32_t *peak_yx, int32_t *valid, double *fit_rois, int32_t *crop_yx)
+int pmi_rcc_pair_list(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
+                      const int32_t *pairs, int64_t n_pairs, int32_t *peak_yx, int32_t *valid, double *fit_rois,
+                      int32_t *crop_yx)
 {
     using namespace pmi;
     if (pmi_device_count() < 1) { set_error("no HIP device"); return PMI_ERR_NODEVICE; }
-    if (!segments || !peak_yx || !valid || !fit_rois || !crop_yx) { set_error("null pointer"); return PMI_ERR_ARG; }
-    if (n_seg < 2 || Y < 1 || X < 1 || Y > 0x7fffffff || X > 0x7fffffff || box < 1 || box > 15 || !(box & 1)) { set_error("rcc: bad arguments"); return PMI_ERR_ARG; }
+    if (!segments || !peak_yx || !valid || !fit_rois || !crop_yx || (n_pairs > 0 && !pairs)) { set_error("null pointer"); return PMI_ERR_ARG; }
+    if (n_seg < 1 || n_pairs < 0 || Y < 1 || X < 1 || Y > 0x7fffffff || X > 0x7fffffff || box < 1 || box > 15 || !(box & 1)) { set_error("rcc: bad arguments"); return PMI_ERR_ARG; }
+    for (int64_t p = 0; p < n_pairs; p++)
+        if (pairs[2 * p] < 0 || pairs[2 * p] >= n_seg || pairs[2 * p + 1] < 0 || pairs[2 * p + 1] >= n_seg) { set_error("rcc: pair %lld out of range", (long long)p); return PMI_ERR_ARG; }
     xc::Plans pl;
     int rc = xc::get_plans(Y, X, &pl);
     if (rc != PMI_OK) return rc;
@@ -181,8 +184,8 @@ int pmi_rcc_pairs(const double *segments, int64_t n_seg, int64_t Y, int64_t X, i
     }
     const int64_t cy = Y - 2 * Y_, cx = X - 2 * X_;
     crop_yx[0] = (int32_t)Y_; crop_yx[1] = (int32_t)X_;
+    if (n_pairs == 0) return PMI_OK;
     const int64_t npix = Y * X, nspec = Y * (X / 2 + 1);
-    const int64_t n_pairs = n_seg * (n_seg - 1) / 2;
     void *d_img = nullptr, *d_spec = nullptr, *d_work = nullptr, *d_out = nullptr;
     if ((rc = scratch(SCR_STAGE_A, (size_t)n_seg * npix * 8, &d_img)) != PMI_OK) return rc;
     if ((rc = scratch(SCR_STAGE_B, (size_t)n_seg * nspec * 16, &d_spec)) != PMI_OK) return rc;
@@ -198,22 +201,23 @@ int pmi_rcc_pairs(const double *segments, int64_t n_seg, int64_t Y, int64_t X, i
     PMI_HIP(hipMemsetAsync(d_sums, 0, (size_t)n_seg * 8, 0));
     hipLaunchKernelGGL(xc::sum_kernel, dim3((unsigned)std::min<int64_t>(64, (npix + 255) / 256), (unsigned)n_seg), dim3(256), 0, 0,
                        dseg, npix, d_sums);
+    std::vector<char> used((size_t)n_seg, 0);
+    for (int64_t p = 0; p < 2 * n_pairs; p++) used[(size_t)pairs[p]] = 1;
     for (int64_t i = 0; i < n_seg; i++)
-        if (hipfftExecD2Z(pl.fwd, dseg + i * npix, spec + i * nspec) != HIPFFT_SUCCESS) { set_error("hipfftExecD2Z failed"); return PMI_ERR_HIP; }
+        if (used[(size_t)i] && hipfftExecD2Z(pl.fwd, dseg + i * npix, spec + i * nspec) != HIPFFT_SUCCESS) { set_error("hipfftExecD2Z failed"); return PMI_ERR_HIP; }
     std::vector<double> sums((size_t)n_seg);
     PMI_HIP(hipMemcpy(sums.data(), d_sums, (size_t)n_seg * 8, hipMemcpyDeviceToHost));
     const double inv_n = 1.0 / (double)npix, inv_sqrt = 1.0 / std::sqrt((double)npix);
     std::vector<int64_t> skipped;
-    int64_t pidx = 0;
-    for (int64_t i = 0; i < n_seg - 1; i++)
-        for (int64_t j = i + 1; j < n_seg; j++, pidx++) {
-            if (sums[(size_t)i] == 0.0 || sums[(size_t)j] == 0.0) { skipped.push_back(pidx); continue; }   // shift (0, 0), imageprocess.py:85-86
-            hipLaunchKernelGGL(xc::product_kernel, dim3((unsigned)((nspec + 255) / 256)), dim3(256), 0, 0, spec + i * nspec,
-                               spec + j * nspec, nspec, prod);
-            if (hipfftExecZ2D(pl.inv, prod, corr) != HIPFFT_SUCCESS) { set_error("hipfftExecZ2D failed"); return PMI_ERR_HIP; }
-            hipLaunchKernelGGL(xc::peak_kernel, dim3(1), dim3(256), 0, 0, corr, Y, X, Y_, X_, cy, cx, inv_n, inv_sqrt, box,
-                               d_peaks + pidx, d_rois + pidx * box * box);
-        }
+    for (int64_t pidx = 0; pidx < n_pairs; pidx++) {
+        const int64_t i = pairs[2 * pidx], j = pairs[2 * pidx + 1];
+        if (sums[(size_t)i] == 0.0 || sums[(size_t)j] == 0.0) { skipped.push_back(pidx); continue; }   // shift (0, 0), imageprocess.py:85-86
+        hipLaunchKernelGGL(xc::product_kernel, dim3((unsigned)((nspec + 255) / 256)), dim3(256), 0, 0, spec + i * nspec,
+                           spec + j * nspec, nspec, prod);
+        if (hipfftExecZ2D(pl.inv, prod, corr) != HIPFFT_SUCCESS) { set_error("hipfftExecZ2D failed"); return PMI_ERR_HIP; }
+        hipLaunchKernelGGL(xc::peak_kernel, dim3(1), dim3(256), 0, 0, corr, Y, X, Y_, X_, cy, cx, inv_n, inv_sqrt, box,
+                           d_peaks + pidx, d_rois + pidx * box * box);
+    }
     PMI_HIP(hipGetLastError());
     std::vector<xc::PeakOut> peaks((size_t)n_pairs);
     PMI_HIP(hipMemcpy(peaks.data(), d_peaks, (size_t)n_pairs * sizeof(xc::PeakOut), hipMemcpyDeviceToHost));
@@ -227,6 +231,17 @@ int pmi_rcc_pairs(const double *segments, int64_t n_seg, int64_t Y, int64_t X, i
         for (int k = 0; k < box * box; k++) fit_rois[p * box * box + k] = 0.0;
     }
     return PMI_OK;
+}
+
+int pmi_rcc_pairs(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
+                  int32_t *peak_yx, int32_t *valid, double *fit_rois, int32_t *crop_yx)
+{
+    if (n_seg < 2) { pmi::set_error("rcc: needs at least two segments"); return PMI_ERR_ARG; }
+    std::vector<int32_t> pairs;                       // every pair i < j, in the order of imageprocess.py:197-205
+    for (int64_t i = 0; i < n_seg - 1; i++)
+        for (int64_t j = i + 1; j < n_seg; j++) { pairs.push_back((int32_t)i); pairs.push_back((int32_t)j); }
+    return pmi_rcc_pair_list(segments, n_seg, Y, X, roi, box, pairs.data(), (int64_t)pairs.size() / 2, peak_yx, valid,
+                             fit_rois, crop_yx);
 }
 
 }  // extern "C"

@@ -92,3 +92,69 @@ def localize_sharded(movie_shard: torch.Tensor, first_frame: int, camera_info: d
         cap = n
     table[0, :n] += int(first_frame)        # shard-local frame index -> movie frame label
     return table_to_columns(allgather_table(table, n, group))
+
+
+# ---------------------------------------------------------------------------
+# RCC undrift over frame shards (SURVEY 8e "undrift at scale"; picasso/postprocess.py:2900-2961)
+# ---------------------------------------------------------------------------
+def _all_reduce_sum(a: np.ndarray, device, group=None) -> np.ndarray:
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return a
+    t = torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t.cpu().numpy()
+
+
+def rcc_sharded(segments: np.ndarray, max_shift=32, group=None, device="cpu", pair_shift_fn=None):
+    """imageprocess.rcc with the n(n-1)/2 correlations split round-robin over the ranks.
+    `segments` must be identical on every rank (see undrift_sharded).  Every rank returns the
+    minimized (shift_y, shift_x) of all segments.  `pair_shift_fn(segments, box, roi, pairs)`
+    defaults to the GPU path (imageprocess._shifts_of_pairs); the CPU tests inject a numpy one."""
+    from . import imageprocess, lib
+    fn = pair_shift_fn or imageprocess._shifts_of_pairs
+    world = dist.get_world_size(group) if dist.is_available() and dist.is_initialized() else 1
+    rank = dist.get_rank(group) if world > 1 else 0
+    n = len(segments)
+    pairs = [(i, j) for i in range(n - 1) for j in range(i + 1, n)]
+    mine = pairs[rank::world]
+    shifts = np.zeros((2, n, n))
+    if mine:
+        for (i, j), (sy, sx) in zip(mine, fn(np.asarray(segments, np.float64), 5, max_shift, mine)):
+            shifts[0, i, j], shifts[1, i, j] = sy, sx
+    shifts = _all_reduce_sum(shifts, device, group)          # disjoint supports: the sum is the union
+    return lib.minimize_shifts(shifts[1], shifts[0])
+
+
+def undrift_sharded(locs_shard, info, segmentation: int, group=None, device="cpu", render_fn=None,
+                    pair_shift_fn=None):
+    """RCC undrift when every rank holds the localizations of its own frame range.
+    Each rank renders its share of every temporal segment (Gaussian, min_blur_width 1); segment
+    bounds come from the global frame count, so a segment that straddles two shards is the SUM of
+    two partial images (all-reduce; the render is additive).  The correlations are split over the
+    ranks (rcc_sharded); drift spline and its application are local.
+    -> (drift DataFrame over all frames, undrifted localizations of this shard)."""
+    import warnings
+
+    import pandas as pd
+    from scipy import interpolate
+
+    from . import postprocess, render
+    rfn = render_fn or render.render
+    Y, X, n_frames = info[0]["Height"], info[0]["Width"], info[0]["Frames"]
+    n_seg = postprocess.n_segments(info, segmentation)
+    bounds = np.linspace(0, n_frames - 1, n_seg + 1, dtype=np.uint32)
+    segments = np.zeros((n_seg, Y, X))
+    locs_shard = locs_shard.copy()
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore", DeprecationWarning)
+        for i in range(n_seg):
+            part = locs_shard[(locs_shard["frame"] >= bounds[i]) & (locs_shard["frame"] < bounds[i + 1])]
+            if len(part):
+                _, segments[i] = rfn(part, info, blur_method="gaussian", min_blur_width=1)
+    segments = _all_reduce_sum(segments, device, group)
+    shift_y, shift_x = rcc_sharded(segments, 32, group, device, pair_shift_fn)
+    t = (bounds[1:] + bounds[:-1]) / 2
+    t_inter = np.arange(n_frames)
+    drift = pd.DataFrame({"x": interpolate.InterpolatedUnivariateSpline(t, shift_x, k=3)(t_inter),
+                          "y": interpolate.InterpolatedUnivariateSpline(t, shift_y, k=3)(t_inter)})
+    return drift, postprocess.apply_drift(locs_shard, info, drift=drift)

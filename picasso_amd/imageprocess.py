@@ -36,10 +36,11 @@ def _fit_peak(fit_roi, box, y_max_, x_max_, Y_, X_, Y, X):
     return -yc, -xc
 
 
-def _shifts_of_pairs(segments, box, roi):
+def _shifts_of_pairs(segments, box, roi, pairs=None):
+    """(-yc, -xc) of every pair (all i < j when `pairs` is None)."""
     segments = np.asarray(segments)
     _, Y, X = segments.shape
-    peak, valid, rois, (Y_, X_) = backend.rcc_pairs_arrays(segments, roi, box)
+    peak, valid, rois, (Y_, X_) = backend.rcc_pairs_arrays(segments, roi, box, pairs)
     out = []
     for p in range(len(valid)):
         if valid[p] == 1:

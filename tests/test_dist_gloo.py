@@ -73,3 +73,86 @@ def test_allgather_table_world2(counts):
             got = np.array(results[r][name], dtype=dt)
             assert np.array_equal(got, want[name]), (r, name)
         assert np.all(np.diff(np.array(results[r]["frame"], dtype=np.int64)) >= 0)
+
+
+# ---------------------------------------------------------------------------
+# RCC undrift over two frame shards == single-process undrift (same pair function)
+# ---------------------------------------------------------------------------
+def _cpu_pair_shifts(segments, box, roi, pairs=None):
+    """The reference's get_image_shift per pair with numpy's FFT (the oracle restatement) and the
+    backend's own host-side peak fit -- stands in for the GPU correlation in the gloo tests."""
+    from oracle import oracle as orc
+    from picasso_amd import imageprocess
+    n, Y, X = segments.shape
+    if pairs is None:
+        pairs = [(i, j) for i in range(n - 1) for j in range(i + 1, n)]
+    out = []
+    for i, j in pairs:
+        w = orc.peak_window(segments[i], segments[j], box, roi)
+        if w is None or w[4] is None:
+            out.append((0, 0))
+        else:
+            ym, xm, Y_, X_, win = w
+            out.append(imageprocess._fit_peak(win, box, ym, xm, Y_, X_, Y, X))
+    return out
+
+
+def _cpu_render(locs, info, blur_method=None, min_blur_width=0.0):
+    from oracle import oracle as orc
+    return orc.render(locs["x"].to_numpy(), locs["y"].to_numpy(), 1.0, [(0, 0), (info[0]["Height"], info[0]["Width"])],
+                      locs["lpx"].to_numpy(), locs["lpy"].to_numpy(), blur_method, min_blur_width)
+
+
+def _undrift_inputs():
+    import pandas as pd
+    from conftest import golden
+    g = golden("undrift_rcc")
+    locs = pd.DataFrame({"frame": g["frame"], "x": g["x"], "y": g["y"], "lpx": g["lpx"], "lpy": g["lpy"]})
+    info = [{"Frames": int(g["frames"]), "Height": int(g["size"]), "Width": int(g["size"]), "Pixelsize": 130}]
+    return g, locs, info
+
+
+def _undrift_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g, locs, info = _undrift_inputs()
+        lo, hi = pdist.shard_frames(info[0]["Frames"] + 333, world, rank)       # shard edges that cut through segments
+        hi = info[0]["Frames"] if rank == world - 1 else hi
+        shard = locs[(locs["frame"] >= lo) & (locs["frame"] < hi)]
+        drift, und = pdist.undrift_sharded(shard, info, int(g["segmentation"]), render_fn=_cpu_render,
+                                           pair_shift_fn=_cpu_pair_shifts)
+        q.put((rank, drift["x"].tolist(), drift["y"].tolist(), und["x"].tolist(), und.index.tolist()))
+    except Exception as exc:
+        q.put((rank, repr(exc)))
+        raise
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def test_undrift_sharded_world2_matches_reference_goldens():
+    g, locs, info = _undrift_inputs()
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_undrift_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(len(r) == 5 for r in results), results
+    und_x = np.full(len(locs), np.nan)
+    for rank, dx, dy, ux, idx in results:
+        # every rank ends with the same drift, and it is the reference's (segments differ only by the
+        # float32-vs-float64 coordinate promotion and the split sums)
+        assert np.max(np.abs(np.array(dx) - g["drift_x"])) < 2e-4 and np.max(np.abs(np.array(dy) - g["drift_y"])) < 2e-4
+        und_x[np.array(idx, dtype=np.int64)] = ux
+    assert not np.isnan(und_x).any()                      # the two shards cover every localization exactly once
+    assert np.max(np.abs(und_x - g["undrifted_x"])) < 2e-4
+    # single process == sharded, with the same stand-in functions
+    d1, u1 = pdist.undrift_sharded(locs, info, int(g["segmentation"]), render_fn=_cpu_render, pair_shift_fn=_cpu_pair_shifts)
+    assert np.max(np.abs(d1["x"].to_numpy() - np.array(results[0][1]))) < 1e-9

@@ -420,3 +420,9 @@ def test_xcorr_and_peak_windows_vs_numpy(be, orc, shape, roi):
                 if win is not None:
                     assert np.max(np.abs(rois[p] - win)) < 1e-12 * np.abs(ref).max()
             p += 1
+    # an explicit pair list (the share of one rank in dist.rcc_sharded) equals the same rows of the full run
+    allp = [(i, j) for i in range(n - 1) for j in range(i + 1, n)]
+    sub = allp[1::3]
+    pk2, va2, ro2, crop2 = be.rcc_pairs_arrays(segs, roi, 5, pairs=sub)
+    assert crop2 == (Y_, X_) and np.array_equal(pk2, peak[1::3]) and np.array_equal(va2, valid[1::3])
+    assert np.array_equal(ro2, rois[1::3])

@@ -469,10 +469,16 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
 }
 
 // ---- kernel 3: Fisher matrix and log-likelihood (gaussmle.py:673-742, 887-954)
+// M[k][l] = sum over pixels of du_k du_l / model.  Every derivative is (row factor) x (column
+// function): du = (N Ey * Ax, N Ay * Ex, Ey * Ex, 1, N Ey * Sx, N Sy * Ex) — so a lane (one row)
+// only accumulates the ten products of the four column functions {Ax, Ex, 1, Sx} weighted by
+// 1/model (float64, like the reference's accumulation), forms its 21 entries from them with its
+// row factors once, and the 8-lane sums go through LDS, lane j collecting entries j, j+8, j+16.
 template <int NP, int B, bool FROM_MOVIE>
 __global__ __launch_bounds__(FIT_NT) void g8_final_kernel(FitParams p)
 {
-    __shared__ float s_x[FIT_WAVES][8][3][8];
+    // per group: 8 columns x 12 floats (pair products), then reused as 8 lanes x 7 doubles per reduction round
+    __shared__ __attribute__((aligned(16))) double s_x[FIT_WAVES][8][8 * 7];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = lane >> 3, j = lane & 7;
     const bool rowok = j < B;
@@ -487,51 +493,101 @@ __global__ __launch_bounds__(FIT_NT) void g8_final_kernel(FitParams p)
     load_row<B, FROM_MOVIE>(p, sidx, j, spot_ok && rowok, d);
 #pragma unroll
     for (int l = 0; l < 6; l++) th[l] = spot_ok ? p.thetas[sidx * 6 + l] : 1.f;
-    float *xs = &s_x[wid][g][0][0];
+    double *red = &s_x[wid][g][0];
+    float *cols = reinterpret_cast<float *>(red);
     const float sgy = NP == 6 ? th[5] : th[4];
     const BTerms tx = boundary_terms(jf, th[0], th[4]);
     const BTerms ty = boundary_terms(jf, th[1], sgy);
-    xs[0 * 8 + j] = tx.E; xs[1 * 8 + j] = tx.A; xs[2 * 8 + j] = tx.S;
+    {
+        // column j: (AA, AE, A, AS | EE, E, ES, 1 | S, SS, -, -)
+        float4 *c = reinterpret_cast<float4 *>(cols + j * 12);
+        c[0] = make_float4(tx.A * tx.A, tx.A * tx.E, tx.A, tx.A * tx.S);
+        c[1] = make_float4(tx.E * tx.E, tx.E, tx.E * tx.S, 1.0f);
+        c[2] = make_float4(tx.S, tx.S * tx.S, 0.f, 0.f);
+    }
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
-    double Mloc[21];
+    // T: AA AE A1 AS EE E1 ES 11 S1 SS
+    double T[10];
 #pragma unroll
-    for (int e = 0; e < 21; e++) Mloc[e] = 0.0;
+    for (int e = 0; e < 10; e++) T[e] = 0.0;
     float ll_loc = 0.f;
     const float N_ = th[2];
+    const float NEy = N_ * ty.E;
 #pragma unroll
     for (int i = 0; i < B; i++) {
-        const float Ex = xs[0 * 8 + i], Ax = xs[1 * 8 + i], Sx = xs[2 * 8 + i];
-        float du[6];
-        du[0] = N_ * ty.E * Ax;
-        du[1] = N_ * Ex * ty.A;
-        du[2] = Ex * ty.E;
-        du[3] = 1.f;
-        if (NP == 6) { du[4] = N_ * ty.E * Sx; du[5] = N_ * Ex * ty.S; }
-        else { du[4] = N_ * (ty.E * Sx + Ex * ty.S); du[5] = 0.f; }
-        const float model = N_ * Ex * ty.E + th[3];
+        const float4 *c = reinterpret_cast<const float4 *>(cols + i * 12);
+        const float4 c0 = c[0], c1 = c[1];
+        const float2 c2 = *reinterpret_cast<const float2 *>(cols + i * 12 + 8);
+        const float model = NEy * c1.y + th[3];
         if (rowok) {
             const double md = (double)model;
             double inv = (double)rcp_f32(model);
             inv = inv * (2.0 - md * inv);                       // ~1e-14 relative: one Newton step on a 1-ulp float seed
             inv = inv * (2.0 - md * inv);
-            int e = 0;
-#pragma unroll
-            for (int k = 0; k < NP; k++)
-#pragma unroll
-                for (int l = k; l < NP; l++) { Mloc[e] += (double)(du[l] * du[k]) * inv; e++; }
+            T[0] += (double)c0.x * inv; T[1] += (double)c0.y * inv; T[2] += (double)c0.z * inv; T[3] += (double)c0.w * inv;
+            T[4] += (double)c1.x * inv; T[5] += (double)c1.y * inv; T[6] += (double)c1.z * inv; T[7] += inv;
+            T[8] += (double)c2.x * inv; T[9] += (double)c2.y * inv;
             if (model > 0.f) {
                 if (d[i] > 0.f) ll_loc += d[i] * __logf(model / d[i]) - (model - d[i]);
                 else ll_loc += -model;
             }
         }
     }
-    // group sums; lane j stores entries j, j+8, j+16 of its spot's Fisher triangle
-    double *fo = p.fisher + (sidx - p.first) * FISHER_STRIDE;
+    __builtin_amdgcn_wave_barrier();
+    // this row's contribution to the upper triangle, in the order (0,0) (0,1) ... (NP-1,NP-1)
+    const double rNE = (double)NEy, rNA = (double)(N_ * ty.A), rE = (double)ty.E, rNS = (double)(N_ * ty.S);
+    double Mloc[21];
 #pragma unroll
-    for (int e = 0; e < NP * (NP + 1) / 2; e++) {
-        const double v = sum8_d(Mloc[e]);
-        if (spot_ok && j == (e & 7)) fo[e] = v;
+    for (int e = 0; e < 21; e++) Mloc[e] = 0.0;
+    if (NP == 6) {
+        // column function of parameter k: A E E 1 S E; row factor: NE NA E 1 NE NS
+        Mloc[0] = rNE * rNE * T[0];  Mloc[1] = rNE * rNA * T[1];  Mloc[2] = rNE * rE * T[1];   Mloc[3] = rNE * T[2];
+        Mloc[4] = rNE * rNE * T[3];  Mloc[5] = rNE * rNS * T[1];
+        Mloc[6] = rNA * rNA * T[4];  Mloc[7] = rNA * rE * T[4];   Mloc[8] = rNA * T[5];        Mloc[9] = rNA * rNE * T[6];
+        Mloc[10] = rNA * rNS * T[4];
+        Mloc[11] = rE * rE * T[4];   Mloc[12] = rE * T[5];        Mloc[13] = rE * rNE * T[6];  Mloc[14] = rE * rNS * T[4];
+        Mloc[15] = T[7];             Mloc[16] = rNE * T[8];       Mloc[17] = rNS * T[5];
+        Mloc[18] = rNE * rNE * T[9]; Mloc[19] = rNE * rNS * T[6];
+        Mloc[20] = rNS * rNS * T[4];
+    } else {
+        // parameter 4 = isotropic sigma: du4 = NE * S + NS * E (two separable terms)
+        Mloc[0] = rNE * rNE * T[0];  Mloc[1] = rNE * rNA * T[1];  Mloc[2] = rNE * rE * T[1];   Mloc[3] = rNE * T[2];
+        Mloc[4] = rNE * (rNE * T[3] + rNS * T[1]);
+        Mloc[5] = rNA * rNA * T[4];  Mloc[6] = rNA * rE * T[4];   Mloc[7] = rNA * T[5];
+        Mloc[8] = rNA * (rNE * T[6] + rNS * T[4]);
+        Mloc[9] = rE * rE * T[4];    Mloc[10] = rE * T[5];        Mloc[11] = rE * (rNE * T[6] + rNS * T[4]);
+        Mloc[12] = T[7];             Mloc[13] = rNE * T[8] + rNS * T[5];
+        Mloc[14] = rNE * rNE * T[9] + 2.0 * rNE * rNS * T[6] + rNS * rNS * T[4];
+    }
+    // group sums through LDS, seven entries per round; lane j keeps entries j, j+8, j+16
+    constexpr int NE_ = NP * (NP + 1) / 2;
+    double mine[3] = {0.0, 0.0, 0.0};
+#pragma unroll
+    for (int r0 = 0; r0 < 21; r0 += 7) {
+        if (r0 < NE_) {
+#pragma unroll
+            for (int e = 0; e < 7; e++) red[j * 7 + e] = Mloc[r0 + e];
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+#pragma unroll
+            for (int t = 0; t < 3; t++) {
+                const int e = j + 8 * t - r0;                   // entry j + 8t lives in this round when 0 <= e < 7
+                if (e >= 0 && e < 7) {
+                    double acc = 0.0;
+#pragma unroll
+                    for (int r = 0; r < 8; r++) acc += red[r * 7 + e];
+                    mine[t] = acc;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    double *fo = p.fisher + (sidx - p.first) * FISHER_STRIDE;
+    if (spot_ok) {
+#pragma unroll
+        for (int t = 0; t < 3; t++)
+            if (j + 8 * t < NE_) fo[j + 8 * t] = mine[t];
     }
     const float ll = sum8(ll_loc);
     if (spot_ok && j == 0) p.loglik[sidx] = ll;

@@ -197,15 +197,38 @@ __global__ void scatter_by_frame_kernel(const Record *__restrict__ recs, const u
 {
     if ((long long)counters[ID_SHARDS] > cap) return;   // overflow: the caller retries with a larger capacity
     const int shard = blockIdx.y;
-    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long long)counters[shard]) return;
-    Record r = recs[(long long)shard * cap + i];
-    int fi = (int)(r.frame - f_first);
-    int slot = base[fi] + atomicAdd(&cursor[fi], 1);
-    grouped[slot] = r;
+    const long long n = (long long)counters[shard];
+    // fixed grid, grid-stride loop: the shard sizes are only known on the device.  A shard holds runs of
+    // records of the same frame (one flush of the scan kernel appends several), so the lanes of a run
+    // share ONE cursor atomic: the head lane of the run reserves the slots of the whole run.
+    const int lane = threadIdx.x & 63;
+    const long long stride = (long long)gridDim.x * blockDim.x;
+    for (long long i0 = (long long)blockIdx.x * blockDim.x + (threadIdx.x & ~63); i0 < n; i0 += stride) {
+        const long long i = i0 + lane;
+        const bool valid = i < n;
+        Record r = {};
+        int fi = -1;
+        if (valid) { r = recs[(long long)shard * cap + i]; fi = (int)(r.frame - f_first); }
+        const int prev = __shfl_up(fi, 1);
+        const bool head = valid && (lane == 0 || prev != fi);
+        const unsigned long long heads = __ballot(head);
+        const unsigned long long vmask = __ballot(valid);
+        if (valid) {
+            const unsigned long long below = heads & ((2ull << lane) - 1ull);        // heads at or below this lane
+            const int hl = 63 - __clzll(below);
+            const unsigned long long above = heads & ~((2ull << lane) - 1ull);       // next head above, else end of valid lanes
+            const int next = above ? __ffsll((long long)above) - 1 : __popcll(vmask);
+            int slot0 = 0;
+            if (head) slot0 = base[fi] + atomicAdd(&cursor[fi], next - lane);
+            slot0 = __shfl(slot0, hl);
+            grouped[slot0 + (lane - hl)] = r;
+        }
+    }
 }
 
-// one wave per frame: rank of each record among the frame's records by (y, x)
+// one wave per frame: rank of each record among the frame's records by (y, x); the frame's keys
+// are staged in LDS when they fit (they do unless a frame holds more than SORT_LDS maxima)
+constexpr int SORT_LDS = 1024;
 __global__ __launch_bounds__(PMI_WAVE) void sort_in_frame_kernel(const Record *__restrict__ grouped,
                                                                  const int *__restrict__ base,
                                                                  const int *__restrict__ count,
@@ -214,17 +237,30 @@ __global__ __launch_bounds__(PMI_WAVE) void sort_in_frame_kernel(const Record *_
                                                                  int32_t *__restrict__ o_frame, int32_t *__restrict__ o_y,
                                                                  int32_t *__restrict__ o_x, float *__restrict__ o_ng)
 {
+    __shared__ unsigned long long s_key[SORT_LDS];
     if ((long long)counters[ID_SHARDS] > cap) return;   // overflow: the caller retries with a larger capacity
     const int fi = blockIdx.x;
     const int m = count[fi], b = base[fi];
+    if (m == 0) return;
+    const bool in_lds = m <= SORT_LDS;
+    if (in_lds) {
+        for (int q = threadIdx.x; q < m; q += PMI_WAVE) {
+            const Record o = grouped[b + q];
+            s_key[q] = ((unsigned long long)(unsigned)o.y << 32) | (unsigned)o.x;
+        }
+        __syncthreads();
+    }
     for (int q = threadIdx.x; q < m; q += PMI_WAVE) {
-        Record r = grouped[b + q];
-        long long key = ((long long)r.y << 32) | (unsigned)r.x;
+        const Record r = grouped[b + q];
+        const unsigned long long key = ((unsigned long long)(unsigned)r.y << 32) | (unsigned)r.x;
         int rank = 0;
-        for (int t = 0; t < m; t++) {
-            Record o = grouped[b + t];
-            long long ok = ((long long)o.y << 32) | (unsigned)o.x;
-            rank += ok < key;
+        if (in_lds) {
+            for (int t = 0; t < m; t++) rank += s_key[t] < key;          // uniform address: one LDS broadcast per step
+        } else {
+            for (int t = 0; t < m; t++) {
+                const Record o = grouped[b + t];
+                rank += (((unsigned long long)(unsigned)o.y << 32) | (unsigned)o.x) < key;
+            }
         }
         o_frame[b + rank] = r.frame;
         o_y[b + rank] = r.y;
@@ -232,6 +268,7 @@ __global__ __launch_bounds__(PMI_WAVE) void sort_in_frame_kernel(const Record *_
         o_ng[b + rank] = r.ng;
     }
 }
+
 
 // float32 unit-vector tables, built on the host with IEEE float ops exactly as
 // localize.py:279-286 does, cached on the device per box size.
@@ -355,7 +392,7 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
     hipLaunchKernelGGL(frame_scan_kernel, dim3(1), dim3(1024), 0, s, count, base, cursor, (int)nf, d_total,
                        (long long *)d_out_n);
     if (cap > 0) {
-        unsigned sb = (unsigned)((cap + 255) / 256);
+        const unsigned sb = (unsigned)std::min<long long>((cap + 255) / 256, 512);
         hipLaunchKernelGGL(scatter_by_frame_kernel, dim3(sb, ID_SHARDS), dim3(256), 0, s, recs, d_total, (long long)cap,
                            (long long)(f_lo + label_offset), base, cursor, grouped);
         hipLaunchKernelGGL(sort_in_frame_kernel, dim3((unsigned)nf), dim3(PMI_WAVE), 0, s, grouped, base, count,

@@ -239,7 +239,13 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
     if (fi >= p.nframes || unit >= p.bands * p.segs) return;
     const int band = unit / p.segs, seg = unit - band * p.segs;
 
-    const int nch = p.cx >> 3;                        // 8-pixel chunks per row
+    // The crop may start at any column: lanes work on 8-pixel chunks aligned in the FRAME (16-byte
+    // loads), xoff pixels of the first chunk lie left of the crop.  Positions outside the crop are
+    // masked; every allowed position has its whole window inside the crop, so looking at frame pixels
+    // beyond the crop edge never changes a decision.  Column indices in the candidate list and the
+    // statistics cells are relative to the aligned origin, j = ja - xoff is relative to the crop.
+    const int xoff = p.x0 & 7;
+    const int nch = (xoff + p.cx + 7) >> 3;           // 8-pixel chunks per row
     const int c8 = seg * 64 + lane;
     const bool lane_valid = c8 < nch;
     const int cm = min(c8, nch - 1);
@@ -257,7 +263,7 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
     if (lane_valid) {
 #pragma unroll
         for (int b = 0; b < 8; b++) {
-            int j = c8 * 8 + b;
+            int j = c8 * 8 + b - xoff;
             if (j >= H && j < p.cx - H - 1) colmask |= 1u << ((b >> 1) + 16 * (b & 1));
         }
         colmask *= 0x1111u;
@@ -277,7 +283,7 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t *>(src), 0, 0x7fffffff, 0x00020000 /* raw 32-bit buffer, gfx94x/gfx950 */);
+        const_cast<uint16_t *>(src - xoff), 0, 0x7fffffff, 0x00020000 /* raw 32-bit buffer, gfx94x/gfx950 */);
     const unsigned pitch = (unsigned)p.X * 2u;         // Y * pitch < 2^31 on this path
     // interior bands never touch a row outside the crop: no clamping in their row loop
     const bool interior = rs0 >= 0 && rs0 + NRP + D <= p.cy;
@@ -496,9 +502,9 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
             unsigned short e = 0;
             if (q < found) {
                 e = s_list[w][q];
-                const int i = band_lo + (int)(e >> 9), j = seg * 512 + (int)(e & 511u);
+                const int i = band_lo + (int)(e >> 9), j = seg * 512 + (int)(e & 511u) - xoff;
                 keep = true;
-                const int jl = j - seg * 512;
+                const int jl = (int)(e & 511u);
                 // |ng| <= P_box * (max - min) over statistics cells covering the (2H+3)^2 stencil; candidates whose
                 // stencil wraps or leaves this wave's 512 columns are always kept
                 if (i != H && j != H && jl - H - 1 >= 0 && jl + H + 1 <= 511) {
@@ -534,7 +540,7 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
             const int q = q0 + lane;
             if (q < kept) {
                 const unsigned e = s_list[w][q];
-                const int i = band_lo + (int)(e >> 9), j = seg * 512 + (int)(e & 511u);
+                const int i = band_lo + (int)(e >> 9), j = seg * 512 + (int)(e & 511u) - xoff;
                 const bool wraps = (i == H) || (j == H);
                 // the packed test cannot see ties at 65535 (saturating +1): those are rechecked exactly
                 const bool saturated = src[(int64_t)i * p.X + j] == 0xffffu;
@@ -548,7 +554,7 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
     } else {
         // More candidates than local maxima can exist: a saturated (65535) plateau flooded the
         // packed test.  Rescan this band pixel by pixel with the exact test (slow, rare).
-        const int j0 = seg * 512, j1 = min(j0 + 512, p.cx);
+        const int j0 = seg * 512 - xoff, j1 = min(j0 + 512, p.cx);
         for (int idx0 = 0; idx0 < RB * 512; idx0 += 64) {
             const int idx = idx0 + lane;
             const int i = band_lo + idx / 512, j = j0 + (idx & 511);
@@ -601,14 +607,14 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     const int h = box / 2;
     if (h < 1 || h > 4) return PMI_OK;
     if (!unit_vectors_match()) return PMI_OK;          // never expected; the generic kernel uses the runtime table
-    if ((X & 7) || (x0 & 7) || (cx & 7) || cx < 16 || ((uintptr_t)d_movie & 15)) return PMI_OK;
+    if ((X & 7) || cx < 16 || ((uintptr_t)d_movie & 15)) return PMI_OK;      // rows must start 16-byte aligned; the crop may not
     if (cy > 65535 || cx > 65535 || X > 65535 || Y * X * 2 >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets
     const int RB = h == 1 ? 16 : (h == 2 ? 32 : 64);     // keeps the per-wave candidate list <= 8.5 KB of LDS
     FastParams p;
     p.movie = (const uint16_t *)d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;
     p.f_lo = f_lo; p.label_off = label_off; p.nframes = nframes; p.box = box; p.min_ng = min_ng;
     p.bands = (cy + RB - 1) / RB;
-    p.segs = (cx / 8 + 63) / 64;
+    p.segs = (((x0 & 7) + cx + 7) / 8 + 63) / 64;
     p.bpf = (p.bands * p.segs + FAST_WAVES - 1) / FAST_WAVES;
     // ng is a linear functional sum_p w(p) f(p) of the (2H+3)^2 neighbourhood with sum_p w(p) = 0 (a constant
     // image has no gradient), hence |ng| <= P_box * (max - min), P_box = sum of the positive weights

@@ -200,10 +200,15 @@ def test_identify_fast_path_vs_oracle(be, orc, shape, box):
         assert len(a[0]) == len(b[0]), (min_ng, len(a[0]), len(b[0]))
         assert all(np.array_equal(p, q) for p, q in zip(a, b))
     if X >= 32:
-        roi = ((3, 8), (Y - 2, X - 8))
-        a = be.identify_arrays(mov, 300.0, box, roi=roi)
-        b = orc.identify(mov, 300.0, box, roi=roi, threads=4)
-        assert all(np.array_equal(p, q) for p, q in zip(a, b))
+        # crops: aligned to 8 columns, and starting / ending anywhere (the fast path works on frame-aligned
+        # chunks and masks what lies outside the crop; the wrapped stencil column wraps inside the CROP)
+        for roi in (((3, 8), (Y - 2, X - 8)), ((0, 3), (Y, X - 5)), ((2, 1), (Y - 1, X)), ((5, 13), (Y - 3, X - 2)),
+                    ((1, 7), (Y - 4, 7 + 17))):
+            for min_ng in (-1e9, 300.0):
+                a = be.identify_arrays(mov, min_ng, box, roi=roi)
+                b = orc.identify(mov, min_ng, box, roi=roi, threads=4)
+                assert len(a[0]) == len(b[0]), (roi, min_ng)
+                assert all(np.array_equal(p, q) for p, q in zip(a, b)), (roi, min_ng)
 
 
 def test_identify_fast_path_all_zero_and_all_saturated(be, orc):

@@ -282,8 +282,13 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
     // vector address arithmetic at all (a 64-bit global address per lane would take two VALU adds).
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    // num_records bounds the descriptor at the end of the frames of this call: when the width is not a
+    // multiple of 8 the last chunk of a row reads into the next row (masked columns), and on the very last
+    // row it would read past the movie — the buffer unit returns 0 there instead
+    const long long remaining = ((long long)(p.nframes - fi) * p.Y * p.X - ((long long)p.y0 * p.X + p.x0 - xoff)) * 2;
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t *>(src - xoff), 0, 0x7fffffff, 0x00020000 /* raw 32-bit buffer, gfx94x/gfx950 */);
+        const_cast<uint16_t *>(src - xoff), 0, (int)(remaining < 0x7fffffffLL ? remaining : 0x7fffffffLL),
+        0x00020000 /* raw 32-bit buffer, gfx94x/gfx950 */);
     const unsigned pitch = (unsigned)p.X * 2u;         // Y * pitch < 2^31 on this path
     // interior bands never touch a row outside the crop: no clamping in their row loop
     const bool interior = rs0 >= 0 && rs0 + NRP + D <= p.cy;
@@ -607,7 +612,7 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     const int h = box / 2;
     if (h < 1 || h > 4) return PMI_OK;
     if (!unit_vectors_match()) return PMI_OK;          // never expected; the generic kernel uses the runtime table
-    if ((X & 7) || cx < 16 || ((uintptr_t)d_movie & 15)) return PMI_OK;      // rows must start 16-byte aligned; the crop may not
+    if ((X & 1) || cx < 16 || ((uintptr_t)d_movie & 3)) return PMI_OK;       // rows must start 4-byte aligned (buffer loads); the crop may not
     if (cy > 65535 || cx > 65535 || X > 65535 || Y * X * 2 >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets
     const int RB = h == 1 ? 16 : (h == 2 ? 32 : 64);     // keeps the per-wave candidate list <= 8.5 KB of LDS
     FastParams p;

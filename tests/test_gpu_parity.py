@@ -177,11 +177,12 @@ def test_localize_pipeline_on_resident_movie(be, orc, testdata_movie):
 
 
 @pytest.mark.parametrize("shape,box", [((3, 96, 128), 7), ((2, 200, 520), 7), ((2, 70, 1032), 5), ((1, 130, 64), 9),
-                                      ((4, 64, 16), 3), ((2, 137, 512), 7), ((2, 66, 1536), 9), ((3, 40, 24), 7)])
+                                      ((4, 64, 16), 3), ((2, 137, 512), 7), ((2, 66, 1536), 9), ((3, 40, 24), 7),
+                                      ((3, 90, 130), 7), ((2, 75, 518), 5), ((2, 64, 36), 7), ((1, 131, 1030), 9)])
 def test_identify_fast_path_vs_oracle(be, orc, shape, box):
-    """uint16 movies whose width is a multiple of 8 take the register-pipelined scan
-    (identify_fast.hip): multi-segment rows, partial bands, partial last segment, ties,
-    saturated plateaus, ROI crops aligned to 8 columns, low/high thresholds."""
+    """uint16 movies of even width take the register-pipelined scan (identify_fast.hip): multi-segment
+    rows, partial bands, partial last segment, widths that are not a multiple of 8 (the last chunk of a
+    row runs into the next row / past the movie), ties, saturated plateaus, ROI crops, low/high thresholds."""
     rng = np.random.default_rng(hash((shape, box)) % 2**32)
     mov = rng.poisson(30, size=shape).astype(np.uint16) + 100
     F, Y, X = shape

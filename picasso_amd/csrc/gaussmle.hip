@@ -411,7 +411,7 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         p.N = std::min<int64_t>(Ntotal, p.first + BATCH);
         p.queue = (unsigned long long *)ptr + bi;
         const int64_t count = p.N - p.first;
-        // boxes <= 7: eight spots per wavefront (gaussmle_g8.hip); larger boxes: one wavefront per spot
+        // boxes <= 15: eight or four spots per wavefront (gaussmle_g8.hip); boxes 17..21: one wavefront per spot
         if (!force_wave_per_spot && launch_fit_g8(p, method, from_movie, g_cu_count, state, s)) {
         } else {
             int64_t blocks = std::min<int64_t>((count + FIT_WAVES - 1) / FIT_WAVES, (int64_t)g_cu_count * 8);

@@ -1,5 +1,7 @@
-// gaussmle_g8.hip — MLE fit for boxes up to 7x7: eight lanes per spot, eight spots
-// per wavefront, one ROW of the spot per lane.
+// gaussmle_g8.hip — MLE fit for boxes up to 15x15, one ROW of the spot per lane: eight lanes
+// per spot and eight spots per wavefront for boxes up to 7x7, a 16-lane DPP row per spot and
+// four spots per wavefront for boxes 9..15 (GroupOf<B>::GS).  The text below says "eight" for
+// the group size throughout.
 //
 // Same algorithm and quirks as mle_fit_kernel (gaussmle.hip; picasso/gaussmle.py
 // :28-168, :268-383, :533-954); only the mapping to the machine differs:
@@ -48,6 +50,26 @@ __device__ __forceinline__ double sum8_d(double v)
     v += dpp_d<0xB1>(v);
     v += dpp_d<0x4E>(v);
     v += dpp_d<0x141>(v);
+    return v;
+}
+// group size: eight lanes per spot for boxes up to 7, a full 16-lane DPP row for boxes 9..15
+template <int B> struct GroupOf { static constexpr int GS = B <= 7 ? 8 : 16; };
+template <int GS> __device__ __forceinline__ float gsum(float v)
+{
+    v = sum8(v);
+    if (GS == 16) v += dpp_f<0x140>(v);      // row_mirror
+    return v;
+}
+template <int GS> __device__ __forceinline__ float gmin(float v)
+{
+    v = min8(v);
+    if (GS == 16) v = fminf(v, dpp_f<0x140>(v));
+    return v;
+}
+template <int GS> __device__ __forceinline__ double gsum_d(double v)
+{
+    v = sum8_d(v);
+    if (GS == 16) v += dpp_d<0x140>(v);
     return v;
 }
 // value of lane+1 / lane-1 (0 past the 16-lane DPP row; callers mask the group edges)
@@ -154,7 +176,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef G8_REFILL_K
 #define G8_REFILL_K 2
 #endif
-constexpr int G8_LDS = 8 * 12 + 8 * 12 + 8;
+template <int GS> struct GLds { static constexpr int N = GS * 12 + GS * 12 + 8; };
 
 struct LaneRole {          // what lane j does in the update stage: parameter j (j < NP)
     float ms;              // max_step of its parameter
@@ -167,7 +189,8 @@ template <int NP, int B>
 __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6], LaneRole &role, float *lds,
                                             int j, bool rowok, bool active, int &kk, double eps, int max_it)
 {
-    float *cols = lds, *red = lds + 96, *bc = lds + 192;
+    constexpr int GS = GroupOf<B>::GS;
+    float *cols = lds, *red = lds + GS * 12, *bc = lds + 2 * GS * 12;
     const float jf = (float)j;
     const float sgy = NP == 6 ? th[5] : th[4];
     const BTerms tx = boundary_terms(jf, th[0], th[4]);     // column j
@@ -240,7 +263,7 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
     const int l = j < 6 ? j : 5;
     f32x2 nd = {0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < 8; r++) {
+    for (int r = 0; r < GS; r++) {
         const float2 v = *reinterpret_cast<const float2 *>(red + r * 12 + 2 * l);
         nd = nd + (f32x2){v.x, v.y};
     }
@@ -254,11 +277,12 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
     nt = min_np(nt, role.cap);
     const bool conv_l = !role.conv_rel || ((double)fabsf(role.th - nt) < eps);
     const unsigned long long vote = __ballot(conv_l);
-    const bool conv = ((vote >> (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & ~7u)) & 0xffull) == 0xffull;
+    constexpr unsigned long long gmask = GS == 8 ? 0xffull : 0xffffull;
+    const bool conv = ((vote >> (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & ~(unsigned)(GS - 1))) & gmask) == gmask;
     // the previous-iteration values the reference compares with ARE th (old_x = theta after every pass);
     // finished groups keep their state
     role.th = active ? nt : role.th;
-    bc[j] = role.th;
+    if (j < 8) bc[j] = role.th;
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
     {
@@ -289,15 +313,16 @@ __device__ __forceinline__ LaneRole make_role(const float (&th)[6], const float 
 template <int NP, int B, bool FROM_MOVIE>
 __global__ __launch_bounds__(FIT_NT) void g8_init_kernel(FitParams p, float *__restrict__ state)
 {
+    constexpr int GS = GroupOf<B>::GS, NSPW = 64 / GS;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int g = lane >> 3, j = lane & 7;
+    const int g = lane / GS, j = lane & (GS - 1);
     const bool rowok = j < B;
     constexpr int H = B / 2;
     int64_t n = p.N;
     if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
-    const int64_t sidx = p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * 8 + g;
+    const int64_t sidx = p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW + g;
     const bool spot_ok = sidx < n;
-    if (__builtin_amdgcn_readfirstlane((int)(p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * 8 >= n))) return;
+    if (__builtin_amdgcn_readfirstlane((int)(p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW >= n))) return;
 
     float d[B];
     load_row<B, FROM_MOVIE>(p, sidx, j, spot_ok && rowok, d);
@@ -305,7 +330,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_init_kernel(FitParams p, float *__r
     double ps = 0.0, px = 0.0;
 #pragma unroll
     for (int i = 0; i < B; i++) { ps += (double)d[i]; px += (double)d[i] * (double)i; }
-    double sum = sum8_d(ps), sx_ = sum8_d(px), sy_ = sum8_d(ps * (double)j);
+    double sum = gsum_d<GS>(ps), sx_ = gsum_d<GS>(px), sy_ = gsum_d<GS>(ps * (double)j);
     // 3x3 edge-clipped mean filter: row-local 3-column sums, then the rows above / below
     float fmin_l = INFINITY;
     {
@@ -340,7 +365,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_init_kernel(FitParams p, float *__r
     }
     // np.min propagates NaN: a NaN pixel poisons the background (and through the sums everything else),
     // so the iteration kernel needs no per-pixel NaN guards
-    const float bg0 = (sum != sum) ? (float)sum : min8(fmin_l);
+    const float bg0 = (sum != sum) ? (float)sum : gmin<GS>(fmin_l);
     double com_y, com_x;
     if (sum <= 0.0) { sum = 0.01; com_y = (B - 1) / 2.0; com_x = (B - 1) / 2.0; }
     else { com_y = sy_ / sum; com_x = sx_ / sum; }
@@ -361,7 +386,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_init_kernel(FitParams p, float *__r
             }
         }
     }
-    a_sdy = sum8_d(a_sdy); a_sy = sum8_d(a_sy); a_sdx = sum8_d(a_sdx); a_sx = sum8_d(a_sx);
+    a_sdy = gsum_d<GS>(a_sdy); a_sy = gsum_d<GS>(a_sy); a_sdx = gsum_d<GS>(a_sdx); a_sx = gsum_d<GS>(a_sx);
     double isy = sqrt(a_sdy / a_sy), isx = sqrt(a_sdx / a_sx);
     if (!isfinite(isy)) isy = 0.01;
     if (!isfinite(isx)) isx = 0.01;
@@ -387,9 +412,11 @@ __global__ __launch_bounds__(FIT_NT) void g8_init_kernel(FitParams p, float *__r
 template <int NP, int B, bool FROM_MOVIE>
 __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const float *__restrict__ state)
 {
-    __shared__ __attribute__((aligned(16))) float s_x[FIT_WAVES][8][G8_LDS];       // per group: columns, reduction, broadcast
+    constexpr int GS = GroupOf<B>::GS, NSPW = 64 / GS;
+    constexpr int REFILL_K = GS == 8 ? G8_REFILL_K : 1;
+    __shared__ __attribute__((aligned(16))) float s_x[FIT_WAVES][NSPW][GLds<GS>::N];       // per group: columns, reduction, broadcast
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int g = lane >> 3, j = lane & 7;
+    const int g = lane / GS, j = lane & (GS - 1);
     const bool rowok = j < B;
     int64_t n = p.N;
     if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
@@ -413,7 +440,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
     int kk = 0;
     int64_t sidx = -1;
     bool active = false;
-    const unsigned long long below = (1ull << (lane & ~7)) - 1ull;     // lanes of lower groups
+    const unsigned long long below = (1ull << (lane & ~(GS - 1))) - 1ull;     // lanes of lower groups
 
     for (;;) {
         // Refills are batched: the refill block (publish theta, fetch state and pixels of the next spot)
@@ -423,7 +450,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
         const unsigned long long pend = __ballot(!active && sidx >= 0 && j == 0);      // finished, not yet published
         const unsigned long long empty = __ballot(!active && sidx < 0 && j == 0);      // no spot at all
         const bool any_active = __any(active);
-        if (__popcll(pend) >= G8_REFILL_K || (pend != 0 && !any_active) || (empty != 0 && next < end)) {
+        if (__popcll(pend) >= REFILL_K || (pend != 0 && !any_active) || (empty != 0 && next < end)) {
             // finished groups publish theta / iteration count, then take the next spots of the chunk
             if (!active && sidx >= 0 && j == 0) {
                 float *to = p.thetas + sidx * 6;
@@ -478,16 +505,17 @@ template <int NP, int B, bool FROM_MOVIE>
 __global__ __launch_bounds__(FIT_NT) void g8_final_kernel(FitParams p)
 {
     // per group: 8 columns x 12 floats (pair products), then reused as 8 lanes x 7 doubles per reduction round
-    __shared__ __attribute__((aligned(16))) double s_x[FIT_WAVES][8][8 * 7];
+    constexpr int GS = GroupOf<B>::GS, NSPW = 64 / GS;
+    __shared__ __attribute__((aligned(16))) double s_x[FIT_WAVES][NSPW][GS * 7];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const int g = lane >> 3, j = lane & 7;
+    const int g = lane / GS, j = lane & (GS - 1);
     const bool rowok = j < B;
     const float jf = (float)j;
     int64_t n = p.N;
     if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
-    const int64_t sidx = p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * 8 + g;
+    const int64_t sidx = p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW + g;
     const bool spot_ok = sidx < n;
-    if (__builtin_amdgcn_readfirstlane((int)(p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * 8 >= n))) return;
+    if (__builtin_amdgcn_readfirstlane((int)(p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW >= n))) return;
 
     float d[B], th[6];
     load_row<B, FROM_MOVIE>(p, sidx, j, spot_ok && rowok, d);
@@ -560,7 +588,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_final_kernel(FitParams p)
         Mloc[12] = T[7];             Mloc[13] = rNE * T[8] + rNS * T[5];
         Mloc[14] = rNE * rNE * T[9] + 2.0 * rNE * rNS * T[6] + rNS * rNS * T[4];
     }
-    // group sums through LDS, seven entries per round; lane j keeps entries j, j+8, j+16
+    // group sums through LDS, seven entries per round; lane j keeps entries j, j+GS, j+2GS
     constexpr int NE_ = NP * (NP + 1) / 2;
     double mine[3] = {0.0, 0.0, 0.0};
 #pragma unroll
@@ -572,11 +600,11 @@ __global__ __launch_bounds__(FIT_NT) void g8_final_kernel(FitParams p)
             __threadfence_block();
 #pragma unroll
             for (int t = 0; t < 3; t++) {
-                const int e = j + 8 * t - r0;                   // entry j + 8t lives in this round when 0 <= e < 7
+                const int e = j + GS * t - r0;                  // entry j + GS t lives in this round when 0 <= e < 7
                 if (e >= 0 && e < 7) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int r = 0; r < 8; r++) acc += red[r * 7 + e];
+                    for (int r = 0; r < GS; r++) acc += red[r * 7 + e];
                     mine[t] = acc;
                 }
             }
@@ -587,17 +615,18 @@ __global__ __launch_bounds__(FIT_NT) void g8_final_kernel(FitParams p)
     if (spot_ok) {
 #pragma unroll
         for (int t = 0; t < 3; t++)
-            if (j + 8 * t < NE_) fo[j + 8 * t] = mine[t];
+            if (j + GS * t < NE_) fo[j + GS * t] = mine[t];
     }
-    const float ll = sum8(ll_loc);
+    const float ll = gsum<GS>(ll_loc);
     if (spot_ok && j == 0) p.loglik[sidx] = ll;
 }
 
 template <int NP, int B, bool FROM_MOVIE>
 static void launch_g8(const FitParams &p, float *state, int cu_count, hipStream_t s)
 {
+    constexpr int NSPW = 64 / GroupOf<B>::GS;
     const int64_t count = p.N - p.first;
-    const int64_t waves = (count + 7) / 8;
+    const int64_t waves = (count + NSPW - 1) / NSPW;
     const dim3 flat((unsigned)((waves + FIT_WAVES - 1) / FIT_WAVES));
     // persistent iterate grid: 6 workgroups (24 waves, 73 VGPRs each) per CU, each wave owning >= 64 spots when possible
     const int64_t pw = std::max<int64_t>(1, std::min<int64_t>((int64_t)cu_count * 24, (count + 63) / 64));
@@ -613,7 +642,11 @@ static void launch_g8_box(const FitParams &p, float *state, int cu_count, hipStr
     switch (p.box) {
     case 3: launch_g8<NP, 3, FROM_MOVIE>(p, state, cu_count, s); break;
     case 5: launch_g8<NP, 5, FROM_MOVIE>(p, state, cu_count, s); break;
-    default: launch_g8<NP, 7, FROM_MOVIE>(p, state, cu_count, s); break;
+    case 7: launch_g8<NP, 7, FROM_MOVIE>(p, state, cu_count, s); break;
+    case 9: launch_g8<NP, 9, FROM_MOVIE>(p, state, cu_count, s); break;
+    case 11: launch_g8<NP, 11, FROM_MOVIE>(p, state, cu_count, s); break;
+    case 13: launch_g8<NP, 13, FROM_MOVIE>(p, state, cu_count, s); break;
+    default: launch_g8<NP, 15, FROM_MOVIE>(p, state, cu_count, s); break;
     }
 }
 
@@ -621,7 +654,7 @@ static void launch_g8_box(const FitParams &p, float *state, int cu_count, hipStr
 // Returns false when the box is not handled.
 bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, float *state, hipStream_t s)
 {
-    if (p.box > 7) return false;
+    if (p.box > 15) return false;
     if (method == PMI_MLE_SIGMAXY) {
         if (from_movie) launch_g8_box<6, true>(p, state, cu_count, s); else launch_g8_box<6, false>(p, state, cu_count, s);
     } else {

@@ -642,12 +642,10 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     static const int dbg = getenv("PMI_IDENTIFY_DBG") ? atoi(getenv("PMI_IDENTIFY_DBG")) : 0;
     p.dbg = dbg;
     int rc;
-    static const int deep = getenv("PMI_IDENTIFY_D6") ? 0 : 1;     // A/B switch for the prefetch depth (default 3 rows)
     switch (h) {
     case 1: rc = launch_fast<1, 16, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     case 2: rc = launch_fast<2, 32, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
-    case 3: rc = deep ? launch_fast<3, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s)
-                      : launch_fast<3, 64, 6>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 3: rc = launch_fast<3, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     default: rc = launch_fast<4, 64, 4>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     }
     if (rc == PMI_OK) *handled = true;

@@ -41,14 +41,20 @@ static __device__ __forceinline__ float mul_rn(float a, float b) { return a * b;
 static __device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
 static __device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
 
-// float32 sqrt of 0..32 (the squared lengths that occur for box <= 9), correctly rounded; the host
+// float32 sqrt of 0..72 (the squared lengths that occur for box <= 13), correctly rounded; the host
 // checks them against sqrtf before the first launch (unit_vectors_match).
-constexpr float SQRT_F32[33] = {
-    0x0.0p+0f, 0x1.000000p+0f, 0x1.6a09e6p+0f, 0x1.bb67aep+0f, 0x1.000000p+1f, 0x1.1e377ap+1f, 0x1.3988e2p+1f,
-    0x1.52a7fap+1f, 0x1.6a09e6p+1f, 0x1.800000p+1f, 0x1.94c584p+1f, 0x1.a8872ap+1f, 0x1.bb67aep+1f, 0x1.cd82b4p+1f,
-    0x1.deeea2p+1f, 0x1.efbdecp+1f, 0x1.000000p+2f, 0x1.07e0f6p+2f, 0x1.0f876cp+2f, 0x1.16f834p+2f, 0x1.1e377ap+2f,
-    0x1.2548ecp+2f, 0x1.2c2fc6p+2f, 0x1.32eee8p+2f, 0x1.3988e2p+2f, 0x1.400000p+2f, 0x1.465656p+2f, 0x1.4c8dc2p+2f,
-    0x1.52a7fap+2f, 0x1.58a68ap+2f, 0x1.5e8adep+2f, 0x1.645640p+2f, 0x1.6a09e6p+2f};
+constexpr float SQRT_F32[73] = {
+    0x0.0p+0f, 0x1.0p+0f, 0x1.6a09e6p+0f, 0x1.bb67aep+0f, 0x1.0p+1f, 0x1.1e377ap+1f, 0x1.3988e2p+1f,
+    0x1.52a7fap+1f, 0x1.6a09e6p+1f, 0x1.8p+1f, 0x1.94c584p+1f, 0x1.a8872ap+1f, 0x1.bb67aep+1f, 0x1.cd82b4p+1f,
+    0x1.deeea2p+1f, 0x1.efbdecp+1f, 0x1.0p+2f, 0x1.07e0f6p+2f, 0x1.0f876cp+2f, 0x1.16f834p+2f, 0x1.1e377ap+2f,
+    0x1.2548ecp+2f, 0x1.2c2fc6p+2f, 0x1.32eee8p+2f, 0x1.3988e2p+2f, 0x1.4p+2f, 0x1.465656p+2f, 0x1.4c8dc2p+2f,
+    0x1.52a7fap+2f, 0x1.58a68ap+2f, 0x1.5e8adep+2f, 0x1.64564p+2f, 0x1.6a09e6p+2f, 0x1.6fa6eap+2f, 0x1.752e5p+2f,
+    0x1.7aa10ep+2f, 0x1.8p+2f, 0x1.854bfcp+2f, 0x1.8a85c2p+2f, 0x1.8fae0cp+2f, 0x1.94c584p+2f, 0x1.99cccap+2f,
+    0x1.9ec474p+2f, 0x1.a3ad12p+2f, 0x1.a8872ap+2f, 0x1.ad5336p+2f, 0x1.b211b2p+2f, 0x1.b6c30cp+2f, 0x1.bb67aep+2f,
+    0x1.cp+2f, 0x1.c48c6p+2f, 0x1.c90d2ap+2f, 0x1.cd82b4p+2f, 0x1.d1ed52p+2f, 0x1.d64d52p+2f, 0x1.daa2fep+2f,
+    0x1.deeea2p+2f, 0x1.e3307cp+2f, 0x1.e768d4p+2f, 0x1.eb97e4p+2f, 0x1.efbdecp+2f, 0x1.f3db22p+2f, 0x1.f7efbep+2f,
+    0x1.fbfbf8p+2f, 0x1.0p+3f, 0x1.01fe04p+3f, 0x1.03f82p+3f, 0x1.05ee68p+3f, 0x1.07e0f6p+3f, 0x1.09cfdcp+3f,
+    0x1.0bbb3p+3f, 0x1.0da304p+3f, 0x1.0f876cp+3f};
 // unit vectors of picasso/localize.py:279-286 as compile-time float32 constants:
 // ux[k][l] = (H - l) / |(H - l, H - k)|, uy[k][l] = (H - k) / |...|  (float32 sqrt and divide)
 template <int H> constexpr float unit_x(int k, int l)
@@ -104,34 +110,37 @@ constexpr int FAST_WAVES = 4;
 #define FAST_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for
 #endif
 
-// pair `s` = pixels (s, s+1) relative to the lane's first pixel; A[k] holds (2k-4, 2k-3),
-// Bp[k] = (2k-5, 2k-4)
-template <int S>
-__device__ __forceinline__ u32 pair_at(const u32 (&A)[8], const u32 (&Bp)[8])
+// pair `s` = pixels (s, s+1) relative to the lane's first pixel.  A holds NA packed pairs: the lane's
+// own four in the middle, NB = NA - 4 neighbour pixels on either side (4 for boxes up to 9, 8 for
+// boxes 11 and 13): A[k] = pixels (2k - NB, 2k - NB + 1), Bp[k] = (2k - NB - 1, 2k - NB).
+template <int S, int NA>
+__device__ __forceinline__ u32 pair_at(const u32 (&A)[NA], const u32 (&Bp)[NA])
 {
-    if constexpr (((S + 4) & 1) == 0) return A[(S + 4) / 2];
-    else return Bp[(S + 5) / 2];
+    constexpr int NB = NA - 4;
+    if constexpr (((S + NB) & 1) == 0) return A[(S + NB) / 2];
+    else return Bp[(S + NB + 1) / 2];
 }
 
-template <int H, int K, int T>
+// Q = own pair 0..3 (pixels 2Q, 2Q+1)
+template <int H, int Q, int T, int NA>
 struct LR {
-    static __device__ __forceinline__ u32 left(const u32 (&A)[8], const u32 (&Bp)[8])
+    static __device__ __forceinline__ u32 left(const u32 (&A)[NA], const u32 (&Bp)[NA])
     {
-        constexpr int c0 = 2 * K - 4;
-        u32 v = pair_at<c0 - H + T>(A, Bp);
-        if constexpr (T + 1 < H) return pk_max(v, LR<H, K, T + 1>::left(A, Bp));
+        constexpr int c0 = 2 * Q;
+        u32 v = pair_at<c0 - H + T, NA>(A, Bp);
+        if constexpr (T + 1 < H) return pk_max(v, LR<H, Q, T + 1, NA>::left(A, Bp));
         else return v;
     }
-    static __device__ __forceinline__ u32 right(const u32 (&A)[8], const u32 (&Bp)[8])
+    static __device__ __forceinline__ u32 right(const u32 (&A)[NA], const u32 (&Bp)[NA])
     {
-        constexpr int c0 = 2 * K - 4;
-        u32 v = pair_at<c0 + 1 + T>(A, Bp);
-        if constexpr (T + 1 < H) return pk_max(v, LR<H, K, T + 1>::right(A, Bp));
+        constexpr int c0 = 2 * Q;
+        u32 v = pair_at<c0 + 1 + T, NA>(A, Bp);
+        if constexpr (T + 1 < H) return pk_max(v, LR<H, Q, T + 1, NA>::right(A, Bp));
         else return v;
     }
 };
 
-struct RowRegs { uint4 m; uint2 e; };   // 8 own pixels + (lanes 0 / 63 only) the 4 pixels beyond the wave's edge
+struct RowRegs { uint4 m; uint4 e; };   // 8 own pixels + (lanes 0 / 63 only) the 4 or 8 pixels beyond the wave's edge (e.z, e.w: boxes 11, 13)
 
 // value of lane-1 / lane+1 across the whole wavefront; `edge` is returned where no such lane exists
 __device__ __forceinline__ u32 from_lane_below(u32 v, u32 edge) { return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
@@ -195,16 +204,20 @@ __device__ __forceinline__ float exact_ng_noWrap(const uint16_t *__restrict__ sr
 }
 
 template <int H, int RB, int D>
-__global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan_u16_fast_kernel(
+__global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : 3)) void identify_scan_u16_fast_kernel(
     FastParams p, const float *__restrict__ uxy, Record *__restrict__ recs, long long cap,
     unsigned long long *__restrict__ shard_cnt, int *__restrict__ frame_count)
 {
     constexpr int BOX = 2 * H + 1;
-    constexpr int HR = H > 1 ? H - 1 : 1;                 // Hrow ring length (unused when H == 1)
-    constexpr int U_ = (H <= 2) ? 4 : H * (H - 1);         // unroll period: a multiple of both ring lengths
+    // Boxes 11 and 13 (H = 5, 6) need 8 neighbour pixels per side and keep an Hrow ring of H slots of which
+    // the slot about to be overwritten is skipped: both rings then share the period H.
+    constexpr bool WIDE = H >= 5;
+    constexpr int NB = WIDE ? 8 : 4, NA = 4 + NB, OWN = NB / 2;
+    constexpr int HR = WIDE ? H : (H > 1 ? H - 1 : 1);     // Hrow ring length (unused when H == 1)
+    constexpr int U_ = WIDE ? (H == 5 ? 10 : 2 * H) : ((H <= 2) ? 4 : H * (H - 1));   // unroll period: a multiple of both ring periods
     static_assert(U_ % D == 0, "prefetch depth must divide the unroll period");
     constexpr int GS = U_ >= 6 ? U_ : 8;                   // rows per MIN statistics group (cells of 8 columns)
-    constexpr int GM = H <= 2 ? 2 : H;                     // rows per MAX statistics group (cells of 4 columns)
+    constexpr int GM = H <= 2 ? 2 : H;                     // rows per MAX statistics group (cells of 4 columns); divides U_
     static_assert(U_ % GM == 0 && GS % GM == 0, "max groups close inside the unrolled body");
     static_assert(2 * H + 2 <= 3 * GM && 2 * H + 2 <= 2 * GS, "the stored windows (4 max groups, 3 min groups) must cover the stencil rows");
     constexpr int NR = RB + 2 * H + 2;                     // pipeline rows: band + H halo + 1 stats row each side
@@ -251,8 +264,8 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
     const int cm = min(c8, nch - 1);
     const uint16_t *src = p.movie + ((int64_t)(p.f_lo + fi) * p.Y + p.y0) * p.X + p.x0;
     const int col_m = cm * 8;
-    const int col_l = cm > 0 ? col_m - 4 : col_m;                 // clamped copies feed invalid pixels only
-    const int col_r = cm + 1 < nch ? col_m + 8 : col_m + 4;
+    const int col_l = cm > 0 ? col_m - NB : col_m;                // clamped copies feed invalid pixels only
+    const int col_r = cm + 1 < nch ? col_m + 8 : col_m + 8 - NB;
     const int band_lo = band * RB, band_hi = min(band_lo + RB, p.cy);
     const int row_lo = max(band_lo, H), row_hi = min(band_hi, p.cy - H - 1);   // rows that may hold a maximum
     const int rs0 = band_lo - H - 1;
@@ -298,10 +311,15 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
         RowRegs o;
         const u32x4_t m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_m, (int)soff, 0);
         o.m = make_uint4(m.x, m.y, m.z, m.w);
-        o.e = make_uint2(0u, 0u);
+        o.e = make_uint4(0u, 0u, 0u, 0u);
         if (edge_lane) {
-            const u32x2_t e = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off_e, (int)soff, 0);
-            o.e = make_uint2(e.x, e.y);
+            if constexpr (WIDE) {
+                const u32x4_t e = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_e, (int)soff, 0);
+                o.e = make_uint4(e.x, e.y, e.z, e.w);
+            } else {
+                const u32x2_t e = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off_e, (int)soff, 0);
+                o.e = make_uint4(e.x, e.y, 0u, 0u);
+            }
         }
         return o;
     };
@@ -332,30 +350,39 @@ __global__ __launch_bounds__(FAST_WAVES * 64, FAST_MIN_WAVES) void identify_scan
             const int st = sb + u;                    // pipeline step; row r = rs0 + st
             const RowRegs cur = pf[u % D];
             pf[u % D] = load_row(rs0 + st + D);
-            u32 A[8] = {from_lane_below(cur.m.z, cur.e.x), from_lane_below(cur.m.w, cur.e.y), cur.m.x, cur.m.y, cur.m.z, cur.m.w,
-                        from_lane_above(cur.m.x, cur.e.x), from_lane_above(cur.m.y, cur.e.y)};
-            u32 Bp[8];
+            u32 A[NA], Bp[NA];
+            if constexpr (WIDE) {
+                A[0] = from_lane_below(cur.m.x, cur.e.x); A[1] = from_lane_below(cur.m.y, cur.e.y);
+                A[2] = from_lane_below(cur.m.z, cur.e.z); A[3] = from_lane_below(cur.m.w, cur.e.w);
+                A[8] = from_lane_above(cur.m.x, cur.e.x); A[9] = from_lane_above(cur.m.y, cur.e.y);
+                A[10] = from_lane_above(cur.m.z, cur.e.z); A[11] = from_lane_above(cur.m.w, cur.e.w);
+            } else {
+                A[0] = from_lane_below(cur.m.z, cur.e.x); A[1] = from_lane_below(cur.m.w, cur.e.y);
+                A[6] = from_lane_above(cur.m.x, cur.e.x); A[7] = from_lane_above(cur.m.y, cur.e.y);
+            }
+            A[OWN] = cur.m.x; A[OWN + 1] = cur.m.y; A[OWN + 2] = cur.m.z; A[OWN + 3] = cur.m.w;
             Bp[0] = 0;
 #pragma unroll
-            for (int k = 1; k < 8; k++) Bp[k] = __builtin_amdgcn_alignbit(A[k], A[k - 1], 16);
-            mn = pk_min(pk_min(mn, pk_min(A[2], A[3])), pk_min(A[4], A[5]));
-            mxL = pk_max(mxL, pk_max(A[2], A[3]));
-            mxR = pk_max(mxR, pk_max(A[4], A[5]));
+            for (int k = 1; k < NA; k++) Bp[k] = __builtin_amdgcn_alignbit(A[k], A[k - 1], 16);
+            mn = pk_min(pk_min(mn, pk_min(A[OWN], A[OWN + 1])), pk_min(A[OWN + 2], A[OWN + 3]));
+            mxL = pk_max(mxL, pk_max(A[OWN], A[OWN + 1]));
+            mxR = pk_max(mxR, pk_max(A[OWN + 2], A[OWN + 3]));
 
             u32 L[4], R[4];
-            L[0] = LR<H, 2, 0>::left(A, Bp); R[0] = LR<H, 2, 0>::right(A, Bp);
-            L[1] = LR<H, 3, 0>::left(A, Bp); R[1] = LR<H, 3, 0>::right(A, Bp);
-            L[2] = LR<H, 4, 0>::left(A, Bp); R[2] = LR<H, 4, 0>::right(A, Bp);
-            L[3] = LR<H, 5, 0>::left(A, Bp); R[3] = LR<H, 5, 0>::right(A, Bp);
+            L[0] = LR<H, 0, 0, NA>::left(A, Bp); R[0] = LR<H, 0, 0, NA>::right(A, Bp);
+            L[1] = LR<H, 1, 0, NA>::left(A, Bp); R[1] = LR<H, 1, 0, NA>::right(A, Bp);
+            L[2] = LR<H, 2, 0, NA>::left(A, Bp); R[2] = LR<H, 2, 0, NA>::right(A, Bp);
+            L[3] = LR<H, 3, 0, NA>::left(A, Bp); R[3] = LR<H, 3, 0, NA>::right(A, Bp);
             u32 tq[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                const u32 v = A[q + 2];
+                const u32 v = A[q + OWN];
                 const u32 hrow = pk_max(pk_max(L[q], v), R[q]);
                 u32 Ucur = hrow;
                 if (H > 1) {
 #pragma unroll
-                    for (int t = 0; t < HR; t++) Ucur = pk_max(Ucur, Hring[t][q]);
+                    for (int t = 0; t < HR; t++)
+                        if (!WIDE || t != u % HR) Ucur = pk_max(Ucur, Hring[t][q]);     // WIDE: slot u % H holds the row H steps back
                 }
                 const u32 bef = pk_max(Uprev[q], L[q]);
                 const u32 pre = pk_max(pk_add_sat(bef, 0x00010001u), R[q]);
@@ -597,7 +624,8 @@ template <int H> static bool unit_vectors_match_h()
 }
 static bool unit_vectors_match()
 {
-    static const bool ok = unit_vectors_match_h<1>() && unit_vectors_match_h<2>() && unit_vectors_match_h<3>() && unit_vectors_match_h<4>();
+    static const bool ok = unit_vectors_match_h<1>() && unit_vectors_match_h<2>() && unit_vectors_match_h<3>() && unit_vectors_match_h<4>() &&
+                           unit_vectors_match_h<5>() && unit_vectors_match_h<6>();
     return ok;
 }
 
@@ -610,7 +638,7 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     static const bool force_generic = getenv("PMI_IDENTIFY_GENERIC") != nullptr;
     if (force_generic) return PMI_OK;
     const int h = box / 2;
-    if (h < 1 || h > 4) return PMI_OK;
+    if (h < 1 || h > 6) return PMI_OK;
     if (!unit_vectors_match()) return PMI_OK;          // never expected; the generic kernel uses the runtime table
     if ((X & 1) || cx < 16 || ((uintptr_t)d_movie & 3)) return PMI_OK;       // rows must start 4-byte aligned (buffer loads); the crop may not
     if (cy > 65535 || cx > 65535 || X > 65535 || Y * X * 2 >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets
@@ -646,7 +674,9 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     case 1: rc = launch_fast<1, 16, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     case 2: rc = launch_fast<2, 32, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     case 3: rc = launch_fast<3, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s); break;
-    default: rc = launch_fast<4, 64, 4>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 4: rc = launch_fast<4, 64, 4>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 5: rc = launch_fast<5, 64, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    default: rc = launch_fast<6, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     }
     if (rc == PMI_OK) *handled = true;
     return rc;

@@ -1,0 +1,118 @@
+"""The wire formats around the localization path: what `picasso localize` reads
+and writes, without h5py / PyTables.
+
+  raw movie  + .yaml   picasso/io.py:50-96 load_raw, :232-246 save_raw, :336-372 load_movie (".raw")
+  metadata   .yaml     picasso/io.py:375-415 load_info, :591-609 save_info (a list of YAML documents)
+  locs       .hdf5     picasso/io.py:2089-2110 save_locs, :2113-2164 load_locs
+  identifications      picasso/io.py:2167-2188 save_identifications
+  datasets             picasso/io.py save_datasets (several named tables in one file)
+
+The HDF5 side is picasso_amd._hdf5: the file structure h5py produces for these calls (one
+contiguous 1-D compound dataset in the root group), both directions interoperable with h5py.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+import pandas as pd
+import yaml
+
+from . import _hdf5, lib
+
+
+class NoMetadataFileError(FileNotFoundError):
+    pass
+
+
+def load_info(path: str, qt_parent=None) -> list[dict]:
+    path_base, _ = os.path.splitext(path)
+    filename = path_base + ".yaml"
+    try:
+        with open(filename, "r") as info_file:
+            info = list(yaml.load_all(info_file, Loader=yaml.UnsafeLoader))
+    except FileNotFoundError as e:
+        print(f"\nAn error occured. Could not find metadata file:\n{filename}")
+        raise NoMetadataFileError(e)
+    return info
+
+
+def save_info(path: str, info: list[dict], default_flow_style: bool = False) -> None:
+    with open(path, "w") as file:
+        yaml.dump_all(info, file, default_flow_style=default_flow_style)
+
+
+def load_raw(path: str, prompt_info=None, progress=None):
+    """-> (np.memmap movie (frames, height, width), info)."""
+    try:
+        info = load_info(path)
+    except FileNotFoundError as error:
+        if prompt_info is None:
+            raise error
+        result = prompt_info()
+        if result is None:
+            return
+        info, save = result
+        info = [info]
+        if save:
+            save_info(os.path.splitext(path)[0] + ".yaml", info)
+    dtype = np.dtype(info[0]["Data Type"])
+    shape = (info[0]["Frames"], info[0]["Height"], info[0]["Width"])
+    movie = np.memmap(path, dtype, "r", shape=shape)
+    if info[0]["Byte Order"] != "<":
+        movie = movie.byteswap()
+        info[0]["Byte Order"] = "<"
+    return movie, info
+
+
+def save_raw(path: str, movie, info) -> None:
+    movie.tofile(path)
+    save_info(os.path.splitext(path)[0] + ".yaml", info)
+
+
+def load_movie(path: str, prompt_info=None, progress=None):
+    ext = os.path.splitext(path)[1].lower()
+    if ext == ".raw":
+        return load_raw(path, prompt_info=prompt_info)
+    raise NotImplementedError(f"movie format {ext!r}: only .raw (+ .yaml) is read here; the reference's "
+                              "TIFF / ND2 / IMS readers are outside the localization path")
+
+
+def _to_records(table: pd.DataFrame) -> np.ndarray:
+    rec = table.to_records(index=False)
+    return np.ascontiguousarray(rec.astype([(n, rec.dtype[n].newbyteorder("<") if rec.dtype[n].byteorder == ">" else rec.dtype[n])
+                                            for n in rec.dtype.names]))
+
+
+def save_locs(path: str, locs: pd.DataFrame, info: list[dict]) -> None:
+    locs = lib.ensure_sanity(locs, info)
+    _hdf5.write(path, {"locs": _to_records(locs)})
+    save_info(os.path.splitext(path)[0] + ".yaml", info)
+
+
+def load_locs(path: str, qt_parent=None):
+    if path.endswith(".csv"):
+        raise ValueError("If you wish to load a ThunderSTORM .csv file, use picasso.io.import_ts instead.")
+    try:
+        locs = pd.DataFrame.from_records(_hdf5.read(path, "locs"))
+    except KeyError as e:
+        print(f"\nAn error occured. File: {path} does not contain a 'locs' dataset.")
+        raise KeyError(e)
+    info = load_info(path, qt_parent=qt_parent)
+    locs = lib.ensure_sanity(locs, info)
+    return locs, info
+
+
+def save_identifications(path: str, identifications: pd.DataFrame, info: list[dict]) -> None:
+    _hdf5.write(path, {"identifications": _to_records(identifications)})
+    save_info(os.path.splitext(path)[0] + ".yaml", info)
+
+
+def load_identifications(path: str):
+    return pd.DataFrame.from_records(_hdf5.read(path, "identifications")), load_info(path)
+
+
+def save_datasets(path: str, info: list[dict], **kwargs) -> None:
+    """Several named tables (DataFrames or record arrays) in one file."""
+    _hdf5.write(path, {k: (_to_records(v) if isinstance(v, pd.DataFrame) else np.asarray(v)) for k, v in kwargs.items()})
+    save_info(os.path.splitext(path)[0] + ".yaml", info)

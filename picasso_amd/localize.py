@@ -17,7 +17,7 @@ from typing import Callable, Literal
 import numpy as np
 import pandas as pd
 
-from . import __version__, avgroi, backend, gausslq, gaussmle
+from . import __version__, avgroi, backend, gausslq, gaussmle, lib
 
 _CHUNK_BYTES = 1 << 30      # movie bytes per device call = progress / abort granularity
 FITTING_METHODS = ["gausslq", "gausslq-gpu", "gaussmle", "avg"]
@@ -327,6 +327,37 @@ def localize_resident(movie: np.ndarray, camera_info: dict, parameters: dict, *,
     finally:
         dm.free()
     return pd.DataFrame(cols)
+
+
+def localize_file(path: str, camera_info: dict, parameters: dict, *, fitting_method: str = "gaussmle", roi=None,
+                  frame_bounds=None, eps: float = 0.001, max_it: int = 100, mle_method: str = "sigmaxy",
+                  drift: int = 0, suffix: str = "_locs") -> str:
+    """File to file, what `picasso localize movie.raw` does (picasso/__main__.py:1046-1156): read
+    <name>.raw + .yaml, localize on the GPU, optionally RCC-undrift with `drift` frames per segment,
+    write <name><suffix>.hdf5 + .yaml (and <name><suffix>_undrift.hdf5).  Returns the path written last."""
+    import os
+
+    from . import io, postprocess
+    movie, info = io.load_movie(path)
+    locs = localize_resident(np.asarray(movie), camera_info, parameters, roi=roi, frame_bounds=frame_bounds,
+                             fitting_method=fitting_method, eps=eps, max_it=max_it, mle_method=mle_method)
+    localize_info = {"Generated by": f"Picasso: v{__version__} Localize (picasso_amd HIP backend)",
+                     "ROI": roi, "Box Size": parameters["Box Size"],
+                     "Min. Net Gradient": parameters["Min. Net Gradient"], "Fit method": fitting_method}
+    if fitting_method == "gaussmle":
+        localize_info["Convergence criterion"] = eps
+        localize_info["Max iterations"] = max_it
+    info = info + [localize_info | camera_info]
+    base = os.path.splitext(path)[0]
+    out = base + suffix + ".hdf5"
+    io.save_locs(out, locs, info)
+    if drift and drift > 0:
+        pinfo = info if lib.get_from_metadata(info, "Pixelsize") is not None else info + [{"Pixelsize": 130}]
+        _, locs = postprocess.undrift(locs, pinfo, drift, display=False)
+        info = info + [{"Generated by": f"Picasso: v{__version__} Undrift (picasso_amd HIP backend)", "Segmentation": drift}]
+        out = base + suffix + "_undrift.hdf5"
+        io.save_locs(out, locs, info)
+    return out
 
 
 def install(picasso_localize=None, picasso_gaussmle=None, picasso_gausslq=None) -> None:

@@ -311,14 +311,16 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : 3)) voi
         RowRegs o;
         const u32x4_t m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_m, (int)soff, 0);
         o.m = make_uint4(m.x, m.y, m.z, m.w);
-        o.e = make_uint4(0u, 0u, 0u, 0u);
+        // only lanes 0 and 63 ever read `e` (as the DPP fill value): the other lanes leave it undefined
+        // instead of spending two or four v_mov per row on zeros
+        asm("" : "=v"(o.e.x), "=v"(o.e.y), "=v"(o.e.z), "=v"(o.e.w));
         if (edge_lane) {
             if constexpr (WIDE) {
                 const u32x4_t e = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_e, (int)soff, 0);
                 o.e = make_uint4(e.x, e.y, e.z, e.w);
             } else {
                 const u32x2_t e = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off_e, (int)soff, 0);
-                o.e = make_uint4(e.x, e.y, 0u, 0u);
+                o.e.x = e.x; o.e.y = e.y;
             }
         }
         return o;

@@ -208,7 +208,9 @@ int pmi_avgroi_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box,
  *   hist:     image[int(y'), int(x')] += 1                       (render.py:451-467)
  *   gaussian: separable Gaussian over +-3 sigma, sigma = oversampling *
  *             max(lp, min_blur_width), in TABLE ORDER per pixel   (render.py:494-575)
- * The image buffer is overwritten (zeroed first).                            */
+ * The image buffer is overwritten (zeroed first).  The Gaussian _dev form
+ * synchronises the stream once: the number of (tile, localization) pairs sizes
+ * its sort buffers.                                                          */
 int pmi_render_dims(double oversampling, double y_min, double x_min, double y_max, double x_max,
                     int64_t *ny, int64_t *nx);
 int pmi_render_hist(const float *x, const float *y, int64_t N, double oversampling,

@@ -133,6 +133,13 @@ __global__ __launch_bounds__(256) void peak_kernel(const double *__restrict__ r,
 }
 
 }  // namespace xc
+
+void release_fft_plans()
+{
+    for (auto &kv : xc::g_plans) { hipfftDestroy(kv.second.fwd); hipfftDestroy(kv.second.inv); }
+    xc::g_plans.clear();
+}
+
 }  // namespace pmi
 
 extern "C" {

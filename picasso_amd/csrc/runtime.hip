@@ -51,6 +51,8 @@ int scratch_release_all()
     return PMI_OK;
 }
 
+void release_fft_plans();   // xcorr.hip
+
 }  // namespace pmi
 
 extern "C" {
@@ -89,7 +91,6 @@ int pmi_free(void *dptr) { PMI_HIP(hipFree(dptr)); return PMI_OK; }
 int pmi_memcpy_h2d(void *d, const void *h, size_t bytes) { PMI_HIP(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return PMI_OK; }
 int pmi_memcpy_d2h(void *h, const void *d, size_t bytes) { PMI_HIP(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); return PMI_OK; }
 int pmi_stream_synchronize(void *stream) { PMI_HIP(hipStreamSynchronize((hipStream_t)stream)); return PMI_OK; }
-namespace pmi { void release_fft_plans(); }   // xcorr.hip
 int pmi_release_scratch(void) { pmi::release_fft_plans(); return pmi::scratch_release_all(); }
 
 int pmi_event_create(void **event)

@@ -207,7 +207,8 @@ int pmi_avgroi_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box,
  * viewport are drawn, *n_rendered receives their number.
  *   hist:     image[int(y'), int(x')] += 1                       (render.py:451-467)
  *   gaussian: separable Gaussian over +-3 sigma, sigma = oversampling *
- *             max(lp, min_blur_width), in TABLE ORDER per pixel   (render.py:494-575)
+ *             max(lp, min_blur_width), in TABLE ORDER per pixel   (render.py:494-575);
+ *             iso != 0: both widths = their mean ("gaussian_iso", :1148-1216)
  * The image buffer is overwritten (zeroed first).  The Gaussian _dev form
  * synchronises the stream once: the number of (tile, localization) pairs sizes
  * its sort buffers.                                                          */
@@ -221,11 +222,11 @@ int pmi_render_hist_dev(const float *d_x, const float *d_y, int64_t N, double ov
                         float *d_image, int64_t ny, int64_t nx, int64_t *d_n_rendered, void *stream);
 int pmi_render_gaussian(const float *x, const float *y, const float *lpx, const float *lpy, int64_t N,
                         double oversampling, double y_min, double x_min, double y_max, double x_max,
-                        double min_blur_width, float *image, int64_t ny, int64_t nx, int64_t *n_rendered);
+                        double min_blur_width, int iso, float *image, int64_t ny, int64_t nx, int64_t *n_rendered);
 int pmi_render_gaussian_dev(const float *d_x, const float *d_y, const float *d_lpx, const float *d_lpy,
                             int64_t N, double oversampling, double y_min, double x_min, double y_max,
-                            double x_max, double min_blur_width, float *d_image, int64_t ny, int64_t nx,
-                            int64_t *d_n_rendered, void *stream);
+                            double x_max, double min_blur_width, int iso, float *d_image, int64_t ny,
+                            int64_t nx, int64_t *d_n_rendered, void *stream);
 
 /* ---- cross-correlation for RCC undrift (picasso/imageprocess.py:27-217) ---- *
  * pmi_xcorr: out = fftshift(real(ifft2(fft2(A) * conj(fft2(B))))) / sqrt(Y*X),

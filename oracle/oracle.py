@@ -218,13 +218,13 @@ def render(x, y, oversampling, viewport, lpx=None, lpy=None, blur_method=None, m
         L.orc_render_hist.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64] + [f64] * 5 + [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
         n = L.orc_render_hist(_ptr(x), _ptr(y), len(x), float(oversampling), float(y_min), float(x_min), float(y_max),
                               float(x_max), _ptr(image), ny.value, nx.value)
-    elif blur_method == "gaussian":
+    elif blur_method in ("gaussian", "gaussian_iso"):
         lpx = np.ascontiguousarray(lpx, np.float32); lpy = np.ascontiguousarray(lpy, np.float32)
         L.orc_render_gaussian.restype = ctypes.c_int64
-        L.orc_render_gaussian.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [f64] * 6 + [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
+        L.orc_render_gaussian.argtypes = [ctypes.c_void_p] * 4 + [ctypes.c_int64] + [f64] * 6 + [ctypes.c_int, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64]
         n = L.orc_render_gaussian(_ptr(x), _ptr(y), _ptr(lpx), _ptr(lpy), len(x), float(oversampling), float(y_min),
-                                  float(x_min), float(y_max), float(x_max), float(min_blur_width), _ptr(image),
-                                  ny.value, nx.value)
+                                  float(x_min), float(y_max), float(x_max), float(min_blur_width),
+                                  int(blur_method == "gaussian_iso"), _ptr(image), ny.value, nx.value)
         if n < 0:
             raise ValueError("footprint too large for the oracle")
     else:

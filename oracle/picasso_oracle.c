@@ -1163,7 +1163,7 @@ int64_t orc_render_hist(const float *x, const float *y, int64_t N, double oversa
 
 int64_t orc_render_gaussian(const float *x, const float *y, const float *lpx, const float *lpy, int64_t N,
                             double oversampling, double y_min, double x_min, double y_max, double x_max,
-                            double min_blur_width, float *image, int64_t ny, int64_t nx)
+                            double min_blur_width, int iso, float *image, int64_t ny, int64_t nx)
 {
     const float osf = (float)oversampling, mbw = (float)min_blur_width;
     float gx[4096], gy[4096];
@@ -1173,7 +1173,8 @@ int64_t orc_render_gaussian(const float *x, const float *y, const float *lpx, co
         if (!(xd > x_min && yd > y_min && xd < x_max && yd < y_max)) continue;
         n++;
         const double x_ = oversampling * (xd - x_min), y_ = oversampling * (yd - y_min);
-        const float sx_ = osf * np_maxf(lpx[i], mbw), sy_ = osf * np_maxf(lpy[i], mbw);
+        float sx_ = osf * np_maxf(lpx[i], mbw), sy_ = osf * np_maxf(lpy[i], mbw);
+        if (iso) { sy_ = (sy_ + sx_) / 2.0f; sx_ = sy_; }          /* gaussian_iso, render.py:1196-1198 */
         const double max_y_off = 3.0 * (double)sy_, max_x_off = 3.0 * (double)sx_;
         int64_t i_min = to_int32(y_ - max_y_off);
         if (i_min < 0) i_min = 0;

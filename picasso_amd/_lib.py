@@ -68,8 +68,8 @@ SYMBOLS = {
     "pmi_render_dims": (_i32, [_f64, _f64, _f64, _f64, _f64, _p, _p]),
     "pmi_render_hist": (_i32, [_p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _p, _i64, _i64, _p]),
     "pmi_render_hist_dev": (_i32, [_p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _p, _i64, _i64, _p, _p]),
-    "pmi_render_gaussian": (_i32, [_p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _p, _i64, _i64, _p]),
-    "pmi_render_gaussian_dev": (_i32, [_p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _p, _i64, _i64, _p, _p]),
+    "pmi_render_gaussian": (_i32, [_p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _i32, _p, _i64, _i64, _p]),
+    "pmi_render_gaussian_dev": (_i32, [_p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _i32, _p, _i64, _i64, _p, _p]),
     "pmi_xcorr": (_i32, [_p, _p, _i64, _i64, _p]),
     "pmi_rcc_pairs": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p]),
     "pmi_rcc_pair_list": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _i64, _p, _p, _p, _p]),

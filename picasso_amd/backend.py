@@ -183,7 +183,7 @@ def zfit_arrays(sx, sy, cx, cy):
     return z, sq
 
 
-def render_arrays(x, y, oversampling, y_min, x_min, y_max, x_max, lpx=None, lpy=None, min_blur_width=0.0):
+def render_arrays(x, y, oversampling, y_min, x_min, y_max, x_max, lpx=None, lpy=None, min_blur_width=0.0, iso=False):
     """-> (n, image float32).  lpx/lpy None = histogram, else the Gaussian render."""
     _lib.require_gpu()
     L = _lib.load()
@@ -206,7 +206,7 @@ def render_arrays(x, y, oversampling, y_min, x_min, y_max, x_max, lpx=None, lpy=
             lpy = np.ascontiguousarray(lpy, np.float32)
             rc = L.pmi_render_gaussian(_lib.ptr(x), _lib.ptr(y), _lib.ptr(lpx), _lib.ptr(lpy), N, float(oversampling),
                                        float(y_min), float(x_min), float(y_max), float(x_max), float(min_blur_width),
-                                       _lib.ptr(image), ny.value, nx.value, ctypes.byref(n))
+                                       int(bool(iso)), _lib.ptr(image), ny.value, nx.value, ctypes.byref(n))
     _lib.check(rc, "pmi_render")
     return int(n.value), image
 

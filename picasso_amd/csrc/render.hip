@@ -39,6 +39,7 @@ constexpr int CHUNK = 32;          // localizations per LDS batch in the tile ke
 struct View {
     double oversampling, y_min, x_min, y_max, x_max;
     float os_f, min_blur_f;
+    int iso;                 // gaussian_iso: both widths = their mean (render.py:1148-1216)
     int64_t ny, nx;
     int tiles_x, tiles_y;
 };
@@ -95,6 +96,7 @@ __global__ void prep_kernel(const float *__restrict__ x, const float *__restrict
             L.y = v.oversampling * ((double)y[i] - v.y_min);
             L.sx = v.os_f * np_maxf(lpx[i], v.min_blur_f);
             L.sy = v.os_f * np_maxf(lpy[i], v.min_blur_f);
+            if (v.iso) { L.sy = (L.sy + L.sx) / 2.0f; L.sx = L.sy; }
             const double max_y_off = 3.0 * (double)L.sy, max_x_off = 3.0 * (double)L.sx;
             int64_t i_min = to_int32(L.y - max_y_off);
             if (i_min < 0) i_min = 0;
@@ -203,7 +205,7 @@ static int make_view(double oversampling, double y_min, double x_min, double y_m
     if (ny != ey || nx != ex) { set_error("render: image is %lld x %lld but the viewport needs %lld x %lld", (long long)ny, (long long)nx, (long long)ey, (long long)ex); return PMI_ERR_ARG; }
     if (ny <= 0 || nx <= 0 || ny > 0x7fffffff || nx > 0x7fffffff) { set_error("render: bad image size"); return PMI_ERR_ARG; }
     v->oversampling = oversampling; v->y_min = y_min; v->x_min = x_min; v->y_max = y_max; v->x_max = x_max;
-    v->os_f = (float)oversampling; v->min_blur_f = (float)min_blur;
+    v->os_f = (float)oversampling; v->min_blur_f = (float)min_blur; v->iso = 0;
     v->ny = ny; v->nx = nx;
     v->tiles_x = (int)((nx + TILE - 1) / TILE); v->tiles_y = (int)((ny + TILE - 1) / TILE);
     if ((int64_t)v->tiles_x * v->tiles_y > 0x7fffffffLL) { set_error("render: image too large"); return PMI_ERR_ARG; }
@@ -244,13 +246,14 @@ int pmi_render_hist_dev(const float *d_x, const float *d_y, int64_t N, double ov
 
 int pmi_render_gaussian_dev(const float *d_x, const float *d_y, const float *d_lpx, const float *d_lpy, int64_t N,
                             double oversampling, double y_min, double x_min, double y_max, double x_max,
-                            double min_blur_width, float *d_image, int64_t ny, int64_t nx, int64_t *d_n_rendered,
-                            void *stream)
+                            double min_blur_width, int iso, float *d_image, int64_t ny, int64_t nx,
+                            int64_t *d_n_rendered, void *stream)
 {
     using namespace pmi;
     rend::View v;
     int rc = rend::make_view(oversampling, y_min, x_min, y_max, x_max, min_blur_width, ny, nx, &v);
     if (rc != PMI_OK) return rc;
+    v.iso = iso ? 1 : 0;
     if (N > 0x7fffffffLL) { set_error("render: too many localizations"); return PMI_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
     PMI_HIP(hipMemsetAsync(d_n_rendered, 0, 8, s));
@@ -308,7 +311,7 @@ int pmi_render_gaussian_dev(const float *d_x, const float *d_y, const float *d_l
 }
 
 static int render_host(const float *x, const float *y, const float *lpx, const float *lpy, int64_t N, double oversampling,
-                       double y_min, double x_min, double y_max, double x_max, double min_blur_width, bool gaussian,
+                       double y_min, double x_min, double y_max, double x_max, double min_blur_width, int iso, bool gaussian,
                        float *image, int64_t ny, int64_t nx, int64_t *n_rendered)
 {
     using namespace pmi;
@@ -330,7 +333,7 @@ static int render_host(const float *x, const float *y, const float *lpx, const f
             PMI_HIP(hipMemcpy(dly, lpy, (size_t)N * 4, hipMemcpyHostToDevice));
         }
     }
-    rc = gaussian ? pmi_render_gaussian_dev(dx, dy, dlx, dly, N, oversampling, y_min, x_min, y_max, x_max, min_blur_width,
+    rc = gaussian ? pmi_render_gaussian_dev(dx, dy, dlx, dly, N, oversampling, y_min, x_min, y_max, x_max, min_blur_width, iso,
                                             (float *)d_img, ny, nx, dn, nullptr)
                   : pmi_render_hist_dev(dx, dy, N, oversampling, y_min, x_min, y_max, x_max, (float *)d_img, ny, nx, dn, nullptr);
     if (rc != PMI_OK) return rc;
@@ -342,14 +345,14 @@ static int render_host(const float *x, const float *y, const float *lpx, const f
 int pmi_render_hist(const float *x, const float *y, int64_t N, double oversampling, double y_min, double x_min,
                     double y_max, double x_max, float *image, int64_t ny, int64_t nx, int64_t *n_rendered)
 {
-    return render_host(x, y, nullptr, nullptr, N, oversampling, y_min, x_min, y_max, x_max, 0.0, false, image, ny, nx, n_rendered);
+    return render_host(x, y, nullptr, nullptr, N, oversampling, y_min, x_min, y_max, x_max, 0.0, 0, false, image, ny, nx, n_rendered);
 }
 
 int pmi_render_gaussian(const float *x, const float *y, const float *lpx, const float *lpy, int64_t N,
                         double oversampling, double y_min, double x_min, double y_max, double x_max,
-                        double min_blur_width, float *image, int64_t ny, int64_t nx, int64_t *n_rendered)
+                        double min_blur_width, int iso, float *image, int64_t ny, int64_t nx, int64_t *n_rendered)
 {
-    return render_host(x, y, lpx, lpy, N, oversampling, y_min, x_min, y_max, x_max, min_blur_width, true, image, ny, nx, n_rendered);
+    return render_host(x, y, lpx, lpy, N, oversampling, y_min, x_min, y_max, x_max, min_blur_width, iso, true, image, ny, nx, n_rendered);
 }
 
 }  // extern "C"

@@ -1,6 +1,6 @@
 """picasso.render surface for the two render modes on the drift-correction / display path:
-``blur_method=None`` (2-D histogram) and ``"gaussian"`` (one separable Gaussian per
-localization, width = localization precision).  picasso/render.py:37-175 ``render``,
+``blur_method=None`` (2-D histogram), ``"gaussian"`` (one separable Gaussian per localization,
+widths = localization precisions) and ``"gaussian_iso"`` (one width, their mean).  picasso/render.py:37-175 ``render``,
 :798-853 ``_render_hist``, :1020-1070 ``_render_gaussian``; the pixels are computed by
 csrc/render.hip.  Rotated views (``ang``) and the other blur methods are not built; they
 raise instead of falling back to a CPU path.
@@ -12,7 +12,7 @@ import pandas as pd
 
 from . import backend, lib
 
-_NOT_BUILT = ("gaussian_iso", "smooth", "convolve")
+_NOT_BUILT = ("smooth", "convolve")
 
 
 def _viewport(info, viewport):
@@ -40,6 +40,8 @@ def render(locs: pd.DataFrame, info, oversampling: float = 1.0, viewport=None, b
         return _render_hist(locs, oversampling, y_min, x_min, y_max, x_max)
     if blur_method == "gaussian":
         return _render_gaussian(locs, oversampling, y_min, x_min, y_max, x_max, min_blur_width)
+    if blur_method == "gaussian_iso":
+        return _render_gaussian_iso(locs, oversampling, y_min, x_min, y_max, x_max, min_blur_width)
     if blur_method in _NOT_BUILT:
         raise NotImplementedError(f"blur_method={blur_method!r} has no HIP kernel in picasso_amd; there is no CPU fallback")
     raise Exception("blur_method not understood.")
@@ -56,3 +58,12 @@ def _render_gaussian(locs, oversampling, y_min, x_min, y_max, x_max, min_blur_wi
         raise NotImplementedError("rotated rendering (ang) has no HIP kernel in picasso_amd")
     return backend.render_arrays(locs["x"].to_numpy(), locs["y"].to_numpy(), oversampling, y_min, x_min, y_max, x_max,
                                  lpx=locs["lpx"].to_numpy(), lpy=locs["lpy"].to_numpy(), min_blur_width=min_blur_width)
+
+
+def _render_gaussian_iso(locs, oversampling, y_min, x_min, y_max, x_max, min_blur_width, ang=None):
+    """picasso/render.py:1148-1216: one isotropic width per localization, the mean of the two."""
+    if ang is not None:
+        raise NotImplementedError("rotated rendering (ang) has no HIP kernel in picasso_amd")
+    return backend.render_arrays(locs["x"].to_numpy(), locs["y"].to_numpy(), oversampling, y_min, x_min, y_max, x_max,
+                                 lpx=locs["lpx"].to_numpy(), lpy=locs["lpy"].to_numpy(), min_blur_width=min_blur_width,
+                                 iso=True)

@@ -94,6 +94,14 @@ def main():
         bh = (osamp * np.maximum(lpy, mbw))[in_view]
         assert bw.dtype == np.float32
         render._fill_gaussian(image, xs, ys, bw.astype(np.float64), bh.astype(np.float64), nx, ny)
+        # gaussian_iso (render.py:1148-1216), NumPy execution and the float64-widened (numba) form
+        n_i, iso_np = render.render(locs, info, oversampling=osamp, viewport=vp, blur_method="gaussian_iso", min_blur_width=mbw)
+        image_iso, ny, nx, xs, ys, in_view = render._render_setup(x.astype(np.float64), y.astype(np.float64), osamp,
+                                                                  y_min, x_min, y_max, x_max)
+        s_iso = (bh + bw) / 2
+        assert s_iso.dtype == np.float32 and n_i == n_g
+        render._fill_gaussian(image_iso, xs, ys, s_iso.astype(np.float64), s_iso.astype(np.float64), nx, ny)
+        out.update({f"{key}_iso_numpy": iso_np, f"{key}_iso_numba": image_iso})
         out.update({f"{key}_oversampling": np.float64(osamp), f"{key}_min_blur": np.float64(mbw),
                     f"{key}_viewport": np.asarray(viewport, np.float64), f"{key}_n": np.int64(n_g),
                     f"{key}_hist": hist, f"{key}_gauss_numpy": gauss, f"{key}_gauss_numba": image})

@@ -351,6 +351,9 @@ def test_render_vs_goldens_and_oracle(be, orc, case):
     # same additions in the same order; only a 1-ulp float64 exp difference can survive the float32 rounding
     assert (img != ref).mean() < 1e-3
     assert np.max(np.abs(img - ref)) <= 4e-7 * float(ref.max())
+    n, iso = be.render_arrays(g["x"], g["y"], osamp, y_min, x_min, y_max, x_max, g["lpx"], g["lpy"], mbw, iso=True)
+    ref = g[case + "_iso_numba"]
+    assert n == int(g[case + "_n"]) and (iso != ref).mean() < 1e-3 and np.max(np.abs(iso - ref)) <= 4e-7 * float(ref.max())
 
 
 def test_render_large_random_vs_oracle(be, orc):

@@ -218,3 +218,6 @@ def test_render_against_goldens(case):
     ref = g[case + "_gauss_numpy"]
     assert np.max(np.abs(img - ref)) < 2e-4 * max(1.0, float(ref.max()))
     assert abs(float(img.sum()) - float(ref.sum())) < 1e-3 * float(ref.sum())
+    n, iso = orc.render(g["x"], g["y"], osamp, vp, g["lpx"], g["lpy"], "gaussian_iso", mbw)
+    assert n == int(g[case + "_n"]) and np.array_equal(iso, g[case + "_iso_numba"])
+    assert np.max(np.abs(iso - g[case + "_iso_numpy"])) < 2e-4 * max(1.0, float(g[case + "_iso_numpy"].max()))

@@ -42,7 +42,7 @@ for label, os_, mbw in (("gaussian os=%g" % osamp, osamp, 0.0), ("gaussian os=1 
             L.pmi_stream_synchronize(None)
             t0 = time.perf_counter()
             if kind == "gaussian":
-                rc = L.pmi_render_gaussian_dev(dx, dy, dlx, dly, N, os_, 0.0, 0.0, float(field), float(field), mbw, img, ny, nx, dn, None)
+                rc = L.pmi_render_gaussian_dev(dx, dy, dlx, dly, N, os_, 0.0, 0.0, float(field), float(field), mbw, 0, img, ny, nx, dn, None)
             else:
                 rc = L.pmi_render_hist_dev(dx, dy, N, os_, 0.0, 0.0, float(field), float(field), img, ny, nx, dn, None)
             _lib.check(rc, "render")

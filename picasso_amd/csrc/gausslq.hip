@@ -39,6 +39,7 @@ struct Params {
     int dtype;
     int64_t Y, X;
     float baseline, sensitivity, gain;
+    ConstDiv gdiv;
     int64_t N;
     const int64_t *d_n;
     int box;
@@ -481,7 +482,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
                 sp[e] = 0.f;
                 if (act[e]) {
                     const float raw = load_movie_px(p.movie, p.dtype, (fr * p.Y + (y0 + ri[e])) * p.X + (x0 + rj[e]));
-                    sp[e] = ((raw - p.baseline) * p.sensitivity) / p.gain;
+                    sp[e] = div_const((raw - p.baseline) * p.sensitivity, p.gdiv);
                 }
             }
         } else {
@@ -799,7 +800,7 @@ int pmi_gausslq_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, 
     if (N <= 0) return PMI_OK;
     lq::Params p = {};
     p.movie = d_movie; p.dtype = dtype; p.Y = Y; p.X = X; p.frame = d_frame; p.y = d_y; p.x = d_x;
-    p.baseline = (float)baseline; p.sensitivity = (float)sensitivity; p.gain = (float)gain;
+    p.baseline = (float)baseline; p.sensitivity = (float)sensitivity; p.gain = (float)gain; p.gdiv = make_const_div((float)gain);
     p.N = N; p.d_n = d_n; p.box = box; p.thetas = d_thetas; p.info = d_info; p.nfev = d_nfev;
     ScopedKernelTimer tm((hipStream_t)stream, &g_last_times.fit_ms);
     rc = lq::launch<true>(p, (hipStream_t)stream);

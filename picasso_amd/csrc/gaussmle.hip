@@ -64,7 +64,7 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p)
                     int64_t fr = p.frame[sidx], yy = p.y[sidx], xx = p.x[sidx];
                     float raw = load_movie_px(p.movie, p.dtype, (fr * p.Y + (yy - h + pj[s])) * p.X + (xx - h + pi[s]));
                     // localize.py:1112, float32, in this order (no contraction possible: sub, mul, div)
-                    v = ((raw - p.baseline) * p.sensitivity) / p.gain;
+                    v = div_const((raw - p.baseline) * p.sensitivity, p.gdiv);
                 } else {
                     v = p.spots[(int64_t)sidx * npix + lane + 64 * s];
                 }
@@ -438,7 +438,7 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
 __global__ void cut_spots_kernel(const void *__restrict__ movie, int dtype, int64_t Y, int64_t X,
                                  const int32_t *__restrict__ frame, const int32_t *__restrict__ y,
                                  const int32_t *__restrict__ x, int64_t N, const int64_t *__restrict__ d_n,
-                                 int box, float baseline, float sensitivity, float gain, float *__restrict__ spots)
+                                 int box, float baseline, float sensitivity, ConstDiv gdiv, float *__restrict__ spots)
 {
     int64_t n = N;
     if (d_n) { int64_t dn = *d_n; n = dn < n ? dn : n; }
@@ -449,7 +449,7 @@ __global__ void cut_spots_kernel(const void *__restrict__ movie, int dtype, int6
         int q = (int)(t - i * npix);
         int a = q / box, c = q - a * box;
         float raw = load_movie_px(movie, dtype, ((int64_t)frame[i] * Y + (y[i] - h + a)) * X + (x[i] - h + c));
-        spots[t] = ((raw - baseline) * sensitivity) / gain;
+        spots[t] = div_const((raw - baseline) * sensitivity, gdiv);
     }
 }
 
@@ -517,7 +517,7 @@ int pmi_gaussmle_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y,
     if (dtype < 0 || dtype > PMI_F32) { pmi::set_error("unknown dtype code %d", dtype); return PMI_ERR_ARG; }
     pmi::FitParams p = {};
     p.movie = d_movie; p.dtype = dtype; p.Y = Y; p.X = X; p.frame = d_frame; p.y = d_y; p.x = d_x;
-    p.baseline = (float)baseline; p.sensitivity = (float)sensitivity; p.gain = (float)gain;
+    p.baseline = (float)baseline; p.sensitivity = (float)sensitivity; p.gain = (float)gain; p.gdiv = pmi::make_const_div((float)gain);
     p.N = N; p.d_n = d_n; p.box = box; p.eps = eps; p.max_it = max_it;
     p.thetas = d_thetas; p.crlbs = d_crlbs; p.loglik = d_loglik; p.iterations = d_iterations;
     return pmi::fit_impl(p, method, true, (hipStream_t)stream);
@@ -560,7 +560,7 @@ int pmi_get_spots_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int6
     int64_t total = N * box * box;
     unsigned blocks = (unsigned)std::min<int64_t>((total + 255) / 256, 256 * 64);
     hipLaunchKernelGGL(cut_spots_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_movie, dtype, Y, X,
-                       d_frame, d_y, d_x, N, d_n, box, (float)baseline, (float)sensitivity, (float)gain, d_spots);
+                       d_frame, d_y, d_x, N, d_n, box, (float)baseline, (float)sensitivity, make_const_div((float)gain), d_spots);
     PMI_HIP(hipGetLastError());
     return PMI_OK;
 }

@@ -153,7 +153,7 @@ __device__ __forceinline__ void load_row(const FitParams &p, int64_t sidx, int j
             }
 #pragma unroll
             for (int i = 0; i < B; i++)      // localize.py:1112: float32 sub, mul, div in this order
-                d[i] = ((raw[i] - p.baseline) * p.sensitivity) / p.gain;
+                d[i] = div_const((raw[i] - p.baseline) * p.sensitivity, p.gdiv);
         } else {
             const float *sp = p.spots + sidx * (B * B) + j * B;
 #pragma unroll

@@ -437,3 +437,23 @@ def test_xcorr_and_peak_windows_vs_numpy(be, orc, shape, roi):
     pk2, va2, ro2, crop2 = be.rcc_pairs_arrays(segs, roi, 5, pairs=sub)
     assert crop2 == (Y_, X_) and np.array_equal(pk2, peak[1::3]) and np.array_equal(va2, valid[1::3])
     assert np.array_equal(ro2, rois[1::3])
+
+
+def test_photon_conversion_division_is_correctly_rounded(be, orc):
+    """The kernels divide by the (uniform) gain with a 3-instruction Markstein sequence instead of an IEEE
+    division; get_spots must stay bit-identical to float32 (x - baseline) * sensitivity / gain for any gain."""
+    rng = np.random.default_rng(99)
+    for dtype in (np.uint16, np.float32):
+        if dtype == np.uint16:
+            mov = rng.integers(0, 65535, size=(3, 40, 48)).astype(np.uint16)
+        else:
+            mov = (rng.uniform(-50, 70000, size=(3, 40, 48)) * rng.choice([1e-6, 1e-3, 1.0, 1e3], size=(3, 40, 48))).astype(np.float32)
+        n = 400
+        fr = rng.integers(0, 3, n).astype(np.int32); y = rng.integers(3, 37, n).astype(np.int32); x = rng.integers(3, 45, n).astype(np.int32)
+        for gain in (1.0, 2.0, 0.37, 3.3, 55.1, 300.0, 1e-3, 7.0 / 3.0, 1e20, float(np.float32(1.0000001))):
+            for sens in (1.0, 0.123, 4.7):
+                cam = {"Baseline": 99.5, "Sensitivity": sens, "Gain": gain}
+                a = be.get_spots_array(mov, fr, y, x, 7, cam["Baseline"], cam["Sensitivity"], cam["Gain"])
+                raw = np.stack([mov[f, yy - 3:yy + 4, xx - 3:xx + 4] for f, yy, xx in zip(fr, y, x)]).astype(np.float32)
+                want = (raw - np.float32(99.5)) * np.float32(sens) / np.float32(gain)
+                assert want.dtype == np.float32 and np.array_equal(a, want), (dtype, gain, sens)

@@ -59,11 +59,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local_rank)                # before the process group: RCCL binds to the current device
+    dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")      # "nccl" is RCCL on ROCm
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
     L = _lib.load()
     _lib.require_gpu()
     _lib.check(L.pmi_set_device(local_rank), "pmi_set_device")

@@ -31,6 +31,9 @@ constexpr double EPSMCH = 2.220446049250313e-16;
 constexpr double DWARF = 2.2250738585072014e-308;
 constexpr double RDWARF = 3.834e-20, RGIANT = 1.304e19;
 constexpr int LQ_WAVES = 4;
+#ifndef LQ_MIN_WAVES
+#define LQ_MIN_WAVES 2
+#endif
 
 struct Params {
     const float *spots;
@@ -445,7 +448,7 @@ __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], 
 }
 
 template <int GS, int E, bool FROM_MOVIE>
-__global__ __launch_bounds__(LQ_WAVES * 64) void lq_fit_kernel(Params p)
+__global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_fit_kernel(Params p)
 {
     constexpr int NGRP = 64 / GS;                              // spots per wavefront
     const int lane = (threadIdx.x & 63) % GS;                  // lane inside the group

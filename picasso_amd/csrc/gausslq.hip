@@ -228,16 +228,16 @@ __device__ __forceinline__ void residuals(const double (&th)[6], const float (&s
     }
 }
 
-// MINPACK qrsolv on the wave-uniform 6x6 factor R (R[row][col]).
-__device__ __forceinline__ void qrsolv(double (&R)[6][6], const int (&ipvt)[6], const double (&diag)[6],
+// MINPACK qrsolv on the wave-uniform 6x6 factor R (R[(row) * 6 + (col)]).
+__device__ __forceinline__ void qrsolv(double *R, const int (&ipvt)[6], const double (&diag)[6],
                                        const double (&qtb)[6], double (&x)[6], double (&sdiag)[6])
 {
     double wa[6];
 #pragma unroll
     for (int j = 0; j < 6; j++) {
 #pragma unroll
-        for (int i = j; i < 6; i++) R[i][j] = R[j][i];
-        x[j] = R[j][j];
+        for (int i = j; i < 6; i++) R[(i) * 6 + (j)] = R[(j) * 6 + (i)];
+        x[j] = R[(j) * 6 + (j)];
         wa[j] = qtb[j];
     }
 #pragma unroll
@@ -252,30 +252,30 @@ __device__ __forceinline__ void qrsolv(double (&R)[6][6], const int (&ipvt)[6], 
             for (int k = j; k < 6; k++) {
                 if (sdiag[k] != 0) {
                     double c, sn;
-                    if (fabs(R[k][k]) < fabs(sdiag[k])) {
-                        const double cotan = R[k][k] / sdiag[k];
+                    if (fabs(R[(k) * 6 + (k)]) < fabs(sdiag[k])) {
+                        const double cotan = R[(k) * 6 + (k)] / sdiag[k];
                         sn = 0.5 / sqrt(0.25 + 0.25 * (cotan * cotan));
                         c = sn * cotan;
                     } else {
-                        const double tn = sdiag[k] / R[k][k];
+                        const double tn = sdiag[k] / R[(k) * 6 + (k)];
                         c = 0.5 / sqrt(0.25 + 0.25 * (tn * tn));
                         sn = c * tn;
                     }
-                    R[k][k] = c * R[k][k] + sn * sdiag[k];
+                    R[(k) * 6 + (k)] = c * R[(k) * 6 + (k)] + sn * sdiag[k];
                     double temp = c * wa[k] + sn * qtbpj;
                     qtbpj = -sn * wa[k] + c * qtbpj;
                     wa[k] = temp;
 #pragma unroll
                     for (int i = k + 1; i < 6; i++) {
-                        temp = c * R[i][k] + sn * sdiag[i];
-                        sdiag[i] = -sn * R[i][k] + c * sdiag[i];
-                        R[i][k] = temp;
+                        temp = c * R[(i) * 6 + (k)] + sn * sdiag[i];
+                        sdiag[i] = -sn * R[(i) * 6 + (k)] + c * sdiag[i];
+                        R[(i) * 6 + (k)] = temp;
                     }
                 }
             }
         }
-        sdiag[j] = R[j][j];
-        R[j][j] = x[j];
+        sdiag[j] = R[(j) * 6 + (j)];
+        R[(j) * 6 + (j)] = x[j];
     }
     int nsing = 6;
 #pragma unroll
@@ -289,7 +289,7 @@ __device__ __forceinline__ void qrsolv(double (&R)[6][6], const int (&ipvt)[6], 
             double sum = 0;
 #pragma unroll
             for (int i = j + 1; i < 6; i++)
-                if (i < nsing) sum += R[i][j] * wa[i];
+                if (i < nsing) sum += R[(i) * 6 + (j)] * wa[i];
             wa[j] = (wa[j] - sum) / sdiag[j];
         }
     }
@@ -298,7 +298,7 @@ __device__ __forceinline__ void qrsolv(double (&R)[6][6], const int (&ipvt)[6], 
 }
 
 // MINPACK lmpar.
-__device__ __forceinline__ void lmpar(double (&R)[6][6], const int (&ipvt)[6], const double (&diag)[6],
+__device__ __forceinline__ void lmpar(double *R, const int (&ipvt)[6], const double (&diag)[6],
                                       const double (&qtb)[6], double delta, double &par, double (&x)[6],
                                       double (&sdiag)[6])
 {
@@ -307,16 +307,16 @@ __device__ __forceinline__ void lmpar(double (&R)[6][6], const int (&ipvt)[6], c
 #pragma unroll
     for (int j = 0; j < 6; j++) {
         wa1[j] = qtb[j];
-        if (R[j][j] == 0 && nsing == 6) nsing = j;
+        if (R[(j) * 6 + (j)] == 0 && nsing == 6) nsing = j;
         if (nsing < 6) wa1[j] = 0;
     }
 #pragma unroll
     for (int j = 5; j >= 0; j--) {
         if (j < nsing) {
-            wa1[j] /= R[j][j];
+            wa1[j] /= R[(j) * 6 + (j)];
             const double temp = wa1[j];
 #pragma unroll
-            for (int i = 0; i < j; i++) wa1[i] -= R[i][j] * temp;
+            for (int i = 0; i < j; i++) wa1[i] -= R[(i) * 6 + (j)] * temp;
         }
     }
 #pragma unroll
@@ -335,8 +335,8 @@ __device__ __forceinline__ void lmpar(double (&R)[6][6], const int (&ipvt)[6], c
         for (int j = 0; j < 6; j++) {
             double sum = 0;
 #pragma unroll
-            for (int i = 0; i < j; i++) sum += R[i][j] * wa1[i];
-            wa1[j] = (wa1[j] - sum) / R[j][j];
+            for (int i = 0; i < j; i++) sum += R[(i) * 6 + (j)] * wa1[i];
+            wa1[j] = (wa1[j] - sum) / R[(j) * 6 + (j)];
         }
         const double temp = enorm6(wa1);
         parl = ((fp / delta) / temp) / temp;
@@ -345,7 +345,7 @@ __device__ __forceinline__ void lmpar(double (&R)[6][6], const int (&ipvt)[6], c
     for (int j = 0; j < 6; j++) {
         double sum = 0;
 #pragma unroll
-        for (int i = 0; i <= j; i++) sum += R[i][j] * qtb[i];
+        for (int i = 0; i <= j; i++) sum += R[(i) * 6 + (j)] * qtb[i];
         wa1[j] = sum / get6(diag, ipvt[j]);
     }
     const double gnorm = enorm6(wa1);
@@ -374,7 +374,7 @@ __device__ __forceinline__ void lmpar(double (&R)[6][6], const int (&ipvt)[6], c
             wa1[j] /= sdiag[j];
             temp = wa1[j];
 #pragma unroll
-            for (int i = j + 1; i < 6; i++) wa1[i] -= R[i][j] * temp;
+            for (int i = j + 1; i < 6; i++) wa1[i] -= R[(i) * 6 + (j)] * temp;
         }
         temp = enorm6(wa1);
         const double parc = ((fp / delta) / temp) / temp;
@@ -451,6 +451,7 @@ template <int GS, int E, bool FROM_MOVIE>
 __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_fit_kernel(Params p)
 {
     constexpr int NGRP = 64 / GS;                              // spots per wavefront
+    __shared__ double s_R[GS == 16 ? LQ_WAVES * NGRP * 36 : 1];
     const int lane = (threadIdx.x & 63) % GS;                  // lane inside the group
     const int grp = (threadIdx.x & 63) / GS;
     const int64_t wave0 = (int64_t)blockIdx.x * LQ_WAVES + (threadIdx.x >> 6);
@@ -534,7 +535,10 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_fit_kernel(Par
 
         // ---- lmdif ----
         double a[6][E], fv[E], w4[E];
-        double R[6][6];
+        // the 6x6 factor: LDS for the 16-lane groups (frees 72 registers of a kernel capped at 256 for two
+        // waves per SIMD; every lane of the group writes the same values), registers for whole-wave groups
+        double R_regs[36];
+        double *R = GS == 16 ? s_R + (size_t)((threadIdx.x >> 6) * NGRP + grp) * 36 : R_regs;
         double diag[6], qtf[6], wa1[6], wa2[6], wa3[6];
         int ipvt[6];
         int info = 0, nfev = 1, iter = 1;
@@ -601,7 +605,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_fit_kernel(Par
 #pragma unroll
             for (int j = 0; j < 6; j++)
 #pragma unroll
-                for (int i = 0; i < 6; i++) R[i][j] = (i <= j) ? Grp<GS>::bcast_d(a[j][0], i) : 0.0;
+                for (int i = 0; i < 6; i++) R[(i) * 6 + (j)] = (i <= j) ? Grp<GS>::bcast_d(a[j][0], i) : 0.0;
             gnorm = 0;
             if (fnorm != 0) {
 #pragma unroll
@@ -610,7 +614,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_fit_kernel(Par
                     if (w2l != 0) {
                         double sum = 0;
 #pragma unroll
-                        for (int i = 0; i <= j; i++) sum += R[i][j] * (qtf[i] / fnorm);
+                        for (int i = 0; i <= j; i++) sum += R[(i) * 6 + (j)] * (qtf[i] / fnorm);
                         const double g = fabs(sum / w2l);
                         if (g > gnorm) gnorm = g;
                     }
@@ -637,7 +641,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_fit_kernel(Par
                 for (int j = 0; j < 6; j++) {
                     const double temp = get6(wa1, ipvt[j]);
 #pragma unroll
-                    for (int i = 0; i <= j; i++) wa3[i] += R[i][j] * temp;
+                    for (int i = 0; i <= j; i++) wa3[i] += R[(i) * 6 + (j)] * temp;
                 }
                 const double temp1 = enorm6(wa3) / fnorm, temp2 = (sqrt(par) * pnorm) / fnorm;
                 prered = temp1 * temp1 + temp2 * temp2 / 0.5;

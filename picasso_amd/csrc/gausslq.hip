@@ -17,7 +17,7 @@
 //
 // Sums over the m rows are tree reductions here and sequential loops in MINPACK;
 // the difference is in the last bits of float64 and disappears in the float32 theta
-// except when it flips a float32 rounding of the stored model (DESIGN.md section 5).
+// except when it flips a float32 rounding of the stored model (DESIGN.md section 2).
 #include <algorithm>
 
 #include "fit_common.h"

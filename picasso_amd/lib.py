@@ -44,25 +44,17 @@ def deprecation_warning(message: str) -> None:
 
 
 def minimize_shifts(shifts_x, shifts_y, shifts_z=None):
-    """Least-squares consistent shifts from all pairwise shifts (picasso/lib.py:2034-2078):
-    r_ij = sum of the segment-to-segment displacements D_i..D_{j-1}; D = pinv(A) r."""
+    """Least-squares consistent shifts from all pairwise shifts (picasso/lib.py:2034-2078).
+    The shift between segments i < j is the sum of the step displacements D_i .. D_{j-1}, so with one
+    row per pair (in the order i < j of the upper triangle) r = A D, A[row, i:j] = 1, and D = pinv(A) r.
+    -> (shift_y, shift_x[, shift_z]), cumulative from segment 0."""
     n = shifts_x.shape[0]
-    n_pairs = int(n * (n - 1) / 2)
-    n_dims = 2 if shifts_z is None else 3
-    rij = np.zeros((n_pairs, n_dims))
-    A = np.zeros((n_pairs, n - 1))
-    flag = 0
-    for i in range(n - 1):
-        for j in range(i + 1, n):
-            rij[flag, 0] = shifts_y[i, j]
-            rij[flag, 1] = shifts_x[i, j]
-            if n_dims == 3:
-                rij[flag, 2] = shifts_z[i, j]
-            A[flag, i:j] = 1
-            flag += 1
-    Dj = np.dot(np.linalg.pinv(A), rij)
-    shift_y = np.insert(np.cumsum(Dj[:, 0]), 0, 0)
-    shift_x = np.insert(np.cumsum(Dj[:, 1]), 0, 0)
-    if n_dims == 2:
-        return shift_y, shift_x
-    return shift_y, shift_x, np.insert(np.cumsum(Dj[:, 2]), 0, 0)
+    pairs = [(i, j) for i in range(n - 1) for j in range(i + 1, n)]
+    stacked = [shifts_y, shifts_x] + ([] if shifts_z is None else [shifts_z])
+    design = np.zeros((len(pairs), n - 1))
+    observed = np.zeros((len(pairs), len(stacked)))
+    for row, (i, j) in enumerate(pairs):
+        design[row, i:j] = 1
+        observed[row] = [m[i, j] for m in stacked]
+    steps = np.dot(np.linalg.pinv(design), observed)
+    return tuple(np.insert(np.cumsum(steps[:, d]), 0, 0) for d in range(len(stacked)))

@@ -4,76 +4,83 @@ the GPU render (csrc/render.hip) and cross-correlation (csrc/xcorr.hip).
 """
 from __future__ import annotations
 
+import warnings
+
 import numpy as np
 import pandas as pd
-from scipy import interpolate
+from scipy.interpolate import InterpolatedUnivariateSpline
 
 from . import imageprocess, lib, render
 
+_SEGMENT_RENDER = {"blur_method": "gaussian", "min_blur_width": 1}      # what undrift renders its segments with
+
 
 def n_segments(info, segmentation: int) -> int:
-    n_frames = lib.get_from_metadata(info, "Frames")
-    return int(np.round(n_frames / segmentation))
+    """Number of temporal segments: round(Frames / segmentation)."""
+    return int(np.round(lib.get_from_metadata(info, "Frames") / segmentation))
+
+
+def _segment_bounds(info, segmentation: int) -> np.ndarray:
+    count = n_segments(info, segmentation)
+    return np.linspace(0, info[0]["Frames"] - 1, count + 1, dtype=np.uint32)
 
 
 def segment(locs: pd.DataFrame, info, segmentation: int, kwargs: dict = {}, callback=None):
-    """Split the localizations into temporal segments and render each one (postprocess.py:2846-2897).
-    -> bounds (uint32 frame bounds), segments (n_seg, Y, X) float64."""
-    Y = info[0]["Height"]
-    X = info[0]["Width"]
-    n_frames = info[0]["Frames"]
-    n_seg = n_segments(info, segmentation)
-    bounds = np.linspace(0, n_frames - 1, n_seg + 1, dtype=np.uint32)
-    segments = np.zeros((n_seg, Y, X))
+    """Render the localizations of every temporal segment (postprocess.py:2846-2897).
+    -> (uint32 frame bounds, float64 stack of shape (n_segments, Height, Width)); segment i holds the
+    frames bounds[i] <= frame < bounds[i + 1]; the callback sees 0, 1, ..., n_segments."""
+    bounds = _segment_bounds(info, segmentation)
+    stack = np.zeros((len(bounds) - 1, info[0]["Height"], info[0]["Width"]))
+    frame = locs["frame"]
     if callback is not None:
         callback(0)
-    for i in range(n_seg):
-        segment_locs = locs[(locs["frame"] >= bounds[i]) & (locs["frame"] < bounds[i + 1])]
-        _, segments[i] = render.render(segment_locs, info, **kwargs)
+    for i, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
+        stack[i] = render.render(locs[(frame >= lo) & (frame < hi)], info, **kwargs)[1]
         if callback is not None:
             callback(i + 1)
-    return bounds, segments
+    return bounds, stack
 
 
 def _apply_drift(locs: pd.DataFrame, drift: pd.DataFrame) -> pd.DataFrame:
-    frames = locs["frame"]
-    locs["x"] -= drift["x"].iloc[frames].to_numpy()
-    locs["y"] -= drift["y"].iloc[frames].to_numpy()
-    if "z" in drift.columns and "z" in locs.columns:
-        locs["z"] -= drift["z"].iloc[frames].to_numpy()
+    """coordinate -= drift[frame]; the float64 drift turns the float32 columns into float64, as in
+    the reference (postprocess.py:3157-3168)."""
+    row = locs["frame"].to_numpy()
+    for axis in ("x", "y", "z"):
+        if axis in drift.columns and axis in locs.columns:
+            locs[axis] = locs[axis] - drift[axis].to_numpy()[row]
     return locs
 
 
 def apply_drift(locs: pd.DataFrame, info, *, drift):
+    """Checked form (postprocess.py:3171-3218): drift is a DataFrame with x, y (, z) per frame or an
+    array of shape (Frames, 2 | 3)."""
     assert isinstance(drift, (pd.DataFrame, np.ndarray)), "Drift must be a DataFrame or numpy array"
     n_frames = lib.get_from_metadata(info, "Frames", raise_error=True)
-    if isinstance(drift, pd.DataFrame):
-        required_columns = {"x", "y"}
-        if not required_columns.issubset(drift.columns):
-            raise ValueError(f"Drift DataFrame must contain columns {required_columns}")
-    elif isinstance(drift, np.ndarray):
-        if not (drift.shape[1] in [2, 3] and drift.shape[0] == n_frames):
+    if isinstance(drift, np.ndarray):
+        if drift.shape[0] != n_frames or drift.shape[1] not in (2, 3):
             raise ValueError("Drift array must have shape (n_frames, 2) for x and y drift, "
                              "or (n_frames, 3) for x, y, and z drift.")
-        drift = pd.DataFrame(drift, columns=["x", "y"] + (["z"] if drift.shape[1] == 3 else []))
+        drift = pd.DataFrame(drift, columns=["x", "y", "z"][:drift.shape[1]])
+    elif not {"x", "y"} <= set(drift.columns):
+        raise ValueError(f"Drift DataFrame must contain columns {{'x', 'y'}}")
     return _apply_drift(locs, drift)
+
+
+def _spline_over_frames(bounds, shift, n_frames):
+    centres = (bounds[1:] + bounds[:-1]) / 2
+    return InterpolatedUnivariateSpline(centres, shift, k=3)(np.arange(n_frames))
 
 
 def undrift(locs: pd.DataFrame, info, segmentation: int, display: bool = True, segmentation_callback=None,
             rcc_callback=None):
-    """RCC drift correction (postprocess.py:2900-2961) -> (drift DataFrame, undrifted locs).
+    """RCC drift correction (postprocess.py:2900-2961) -> (drift DataFrame, undrifted copy of locs).
     ``display`` (a matplotlib plot in the reference) is ignored."""
-    import warnings
     locs = locs.copy()
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", DeprecationWarning)       # render()'s oversampling notice, as in the reference call
-        bounds, segments = segment(locs, info, segmentation, {"blur_method": "gaussian", "min_blur_width": 1},
-                                   segmentation_callback)
-    shift_y, shift_x = imageprocess.rcc(segments, 32, rcc_callback)
-    t = (bounds[1:] + bounds[:-1]) / 2
-    drift_x_pol = interpolate.InterpolatedUnivariateSpline(t, shift_x, k=3)
-    drift_y_pol = interpolate.InterpolatedUnivariateSpline(t, shift_y, k=3)
-    t_inter = np.arange(info[0]["Frames"])
-    drift = pd.DataFrame({"x": drift_x_pol(t_inter), "y": drift_y_pol(t_inter)})
-    locs = apply_drift(locs, info, drift=drift)
-    return drift, locs
+        bounds, stack = segment(locs, info, segmentation, dict(_SEGMENT_RENDER), segmentation_callback)
+    shift_y, shift_x = imageprocess.rcc(stack, 32, rcc_callback)
+    n_frames = info[0]["Frames"]
+    drift = pd.DataFrame({"x": _spline_over_frames(bounds, shift_x, n_frames),
+                          "y": _spline_over_frames(bounds, shift_y, n_frames)})
+    return drift, apply_drift(locs, info, drift=drift)

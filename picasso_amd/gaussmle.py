@@ -100,47 +100,34 @@ def wait_async(current):
 
 
 def locs_from_fits(identifications: pd.DataFrame, theta, CRLBs, log_likelihoods, iterations, box: int) -> pd.DataFrame:
-    """Fit results -> localization table (picasso/gaussmle.py:957-1037): 17 columns
-    (+ n_id), x = theta_x + id.x - box//2, lp = sqrt(CRLB), sorted by frame."""
-    box_offset = int(box / 2)
-    x = theta[:, 0] + identifications["x"] - box_offset
-    y = theta[:, 1] + identifications["y"] - box_offset
+    """Fit results -> localization table (picasso/gaussmle.py:957-1037): 17 columns (+ n_id).
+    Positions are theta + identification - box // 2 (theta is in box-origin coordinates), precisions
+    and parameter uncertainties are the square roots of the CRLB columns, everything float32 except
+    frame / iterations / n_id (uint32); sorted by n_id if present, else by frame."""
+    f32, u32 = np.float32, np.uint32
+    half = int(box / 2)
     with np.errstate(invalid="ignore"):
-        lpx = np.sqrt(CRLBs[:, 0])
-        lpy = np.sqrt(CRLBs[:, 1])
-        a = np.maximum(theta[:, 4], theta[:, 5])
-        b = np.minimum(theta[:, 4], theta[:, 5])
-        ellipticity = (a - b) / a
-        photons_unc = np.sqrt(CRLBs[:, 2])
-        bg_unc = np.sqrt(CRLBs[:, 3])
-        sx_unc = np.sqrt(CRLBs[:, 4])
-        sy_unc = np.sqrt(CRLBs[:, 5])
-    locs = pd.DataFrame(
-        {
-            "frame": identifications["frame"].to_numpy(dtype=np.uint32),
-            "x": x.astype(np.float32),
-            "y": y.astype(np.float32),
-            "photons": theta[:, 2].astype(np.float32),
-            "sx": theta[:, 4].astype(np.float32),
-            "sy": theta[:, 5].astype(np.float32),
-            "bg": theta[:, 3].astype(np.float32),
-            "lpx": lpx.astype(np.float32),
-            "lpy": lpy.astype(np.float32),
-            "ellipticity": ellipticity.astype(np.float32),
-            "net_gradient": identifications["net_gradient"].astype(np.float32),
-            "log_likelihood": log_likelihoods.astype(np.float32),
-            "iterations": iterations.astype(np.uint32),
-            "photons_unc": photons_unc.astype(np.float32),
-            "bg_unc": bg_unc.astype(np.float32),
-            "sx_unc": sx_unc.astype(np.float32),
-            "sy_unc": sy_unc.astype(np.float32),
-        }
-    )
+        root = np.sqrt(CRLBs)                        # columns: x, y, photons, bg, sx, sy
+        wide, narrow = np.maximum(theta[:, 4], theta[:, 5]), np.minimum(theta[:, 4], theta[:, 5])
+        ellipticity = (wide - narrow) / wide
+    columns = [
+        ("frame", identifications["frame"].to_numpy(dtype=u32)),
+        ("x", (theta[:, 0] + identifications["x"] - half).astype(f32)),       # float32 + int64 -> float64, then cast
+        ("y", (theta[:, 1] + identifications["y"] - half).astype(f32)),
+        ("photons", theta[:, 2].astype(f32)), ("sx", theta[:, 4].astype(f32)), ("sy", theta[:, 5].astype(f32)),
+        ("bg", theta[:, 3].astype(f32)), ("lpx", root[:, 0].astype(f32)), ("lpy", root[:, 1].astype(f32)),
+        ("ellipticity", ellipticity.astype(f32)),
+        ("net_gradient", identifications["net_gradient"].astype(f32)),
+        ("log_likelihood", log_likelihoods.astype(f32)), ("iterations", iterations.astype(u32)),
+        ("photons_unc", root[:, 2].astype(f32)), ("bg_unc", root[:, 3].astype(f32)),
+        ("sx_unc", root[:, 4].astype(f32)), ("sy_unc", root[:, 5].astype(f32)),
+    ]
+    locs = pd.DataFrame(dict(columns))
+    key = "frame"
     if "n_id" in identifications.columns:
-        locs["n_id"] = identifications.n_id.astype(np.uint32)
-        locs.sort_values(by=["n_id"], kind="quicksort", inplace=True)
-    else:
-        locs.sort_values(by=["frame"], kind="quicksort", inplace=True)
+        locs["n_id"] = identifications.n_id.astype(u32)
+        key = "n_id"
+    locs.sort_values(by=[key], kind="quicksort", inplace=True)
     return locs
 
 

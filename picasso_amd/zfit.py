@@ -27,47 +27,44 @@ def _get_prime_calib_size(coeffs, z):
             + 2 * coeffs[4] * z + coeffs[5])
 
 
-def _axial_localization_precision_astig(locs: pd.DataFrame, cx, cy, magnification_factor: float, pixelsize: float,
-                                        fitting_method: Literal["gausslq", "gaussmle"] = "gausslq"):
-    """lpz in nm (picasso/zfit.py:805-889)."""
+def _sigma_standard_errors(locs: pd.DataFrame, fitting_method: str):
+    """(se_sx, se_sy) in camera pixels: Mortensen-style estimate for the least-squares fit, the CRLB columns
+    of the MLE table when present, else the Rieger-Stallinga estimate (picasso/zfit.py:844-871)."""
     if fitting_method == "gausslq":
-        se_sx = gausslq.sigma_uncertainty(locs["sx"], locs["sy"], locs["photons"], locs["bg"]) * pixelsize
-        se_sy = gausslq.sigma_uncertainty(locs["sy"], locs["sx"], locs["photons"], locs["bg"]) * pixelsize
+        estimate = gausslq.sigma_uncertainty
     elif fitting_method == "gaussmle":
-        if "sx_unc" not in locs.columns or "sy_unc" not in locs.columns:
-            se_sx = gaussmle.sigma_uncertainty(locs["sx"], locs["sy"], locs["photons"], locs["bg"]) * pixelsize
-            se_sy = gaussmle.sigma_uncertainty(locs["sy"], locs["sx"], locs["photons"], locs["bg"]) * pixelsize
-        else:
-            se_sx = locs["sx_unc"] * pixelsize
-            se_sy = locs["sy_unc"] * pixelsize
+        if {"sx_unc", "sy_unc"} <= set(locs.columns):
+            return locs["sx_unc"], locs["sy_unc"]
+        estimate = gaussmle.sigma_uncertainty
     else:
         raise ValueError("fitting_method must be 'gausslq' or 'gaussmle'.")
+    return (estimate(locs["sx"], locs["sy"], locs["photons"], locs["bg"]),
+            estimate(locs["sy"], locs["sx"], locs["photons"], locs["bg"]))
+
+
+def _axial_localization_precision_astig(locs: pd.DataFrame, cx, cy, magnification_factor: float, pixelsize: float,
+                                        fitting_method: Literal["gausslq", "gaussmle"] = "gausslq"):
+    """lpz in nm (picasso/zfit.py:805-889): error propagation through z = argmin of the calibration
+    residual in sqrt(width).  Per axis a, with w_a(z) the calibrated width in nm:
+        g_a = d sqrt(w_a) / dz = w_a'(z) / (2 sqrt(w_a(z))),   e_a = se(sigma_a) / (2 sqrt(sigma_a))  (nm units)
+        lpz = sqrt(g_x^2 e_x^2 + g_y^2 e_y^2) / (g_x^2 + g_y^2)"""
+    se = [v * pixelsize for v in _sigma_standard_errors(locs, fitting_method)]
     z = locs["z"] / magnification_factor       # the spot size actually measured
-    wx_calib = _get_calib_size(cx, z) * pixelsize
-    wy_calib = _get_calib_size(cy, z) * pixelsize
-    wx_calib_prime = _get_prime_calib_size(cx, z) * pixelsize
-    wy_calib_prime = _get_prime_calib_size(cy, z) * pixelsize
-    sqrt_wx_calib = np.sqrt(wx_calib)
-    sqrt_wx_calib_prime = wx_calib_prime / (2 * sqrt_wx_calib)
-    sqrt_wy_calib = np.sqrt(wy_calib)
-    sqrt_wy_calib_prime = wy_calib_prime / (2 * sqrt_wy_calib)
-    delta_sqrt_wx = (1 / (2 * np.sqrt(locs["sx"] * pixelsize))) * se_sx
-    delta_sqrt_wy = (1 / (2 * np.sqrt(locs["sy"] * pixelsize))) * se_sy
-    swxc2 = sqrt_wx_calib_prime**2
-    swyc2 = sqrt_wy_calib_prime**2
-    swx2 = delta_sqrt_wx**2
-    swy2 = delta_sqrt_wy**2
-    lpz = np.sqrt((swxc2 * swx2 + swyc2 * swy2) / (swxc2 + swyc2) ** 2)
+    slope_sq, err_sq = [], []
+    for coeffs, width, se_axis in ((cx, locs["sx"], se[0]), (cy, locs["sy"], se[1])):
+        w = _get_calib_size(coeffs, z) * pixelsize
+        w_prime = _get_prime_calib_size(coeffs, z) * pixelsize
+        slope_sq.append((w_prime / (2 * np.sqrt(w))) ** 2)
+        err_sq.append(((1 / (2 * np.sqrt(width * pixelsize))) * se_axis) ** 2)
+    lpz = np.sqrt((slope_sq[0] * err_sq[0] + slope_sq[1] * err_sq[1]) / (slope_sq[0] + slope_sq[1]) ** 2)
     return lpz * magnification_factor
 
 
 def filter_z_fits(locs: pd.DataFrame, range: int) -> pd.DataFrame:
-    """Drop fits whose calibration residual exceeds `range` x the RMS residual."""
-    if "d_zcalib" not in locs.columns:
-        return locs
-    if range > 0:
-        rmsd = np.sqrt(np.nanmean(locs["d_zcalib"] ** 2))
-        locs = locs[locs["d_zcalib"] <= range * rmsd]
+    """Keep fits whose calibration residual is at most `range` x the RMS residual (0 = keep all)."""
+    if range > 0 and "d_zcalib" in locs.columns:
+        residual = locs["d_zcalib"]
+        locs = locs[residual <= range * np.sqrt(np.nanmean(residual ** 2))]
     return locs
 
 

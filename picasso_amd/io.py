@@ -25,49 +25,51 @@ class NoMetadataFileError(FileNotFoundError):
     pass
 
 
+def _sidecar(path: str) -> str:
+    """<name>.yaml next to <name>.<ext>."""
+    return os.path.splitext(path)[0] + ".yaml"
+
+
 def load_info(path: str, qt_parent=None) -> list[dict]:
-    path_base, _ = os.path.splitext(path)
-    filename = path_base + ".yaml"
-    try:
-        with open(filename, "r") as info_file:
-            info = list(yaml.load_all(info_file, Loader=yaml.UnsafeLoader))
-    except FileNotFoundError as e:
+    """The YAML documents of the sidecar file, in order (picasso/io.py:375-415)."""
+    filename = _sidecar(path)
+    if not os.path.isfile(filename):
         print(f"\nAn error occured. Could not find metadata file:\n{filename}")
-        raise NoMetadataFileError(e)
-    return info
+        raise NoMetadataFileError(filename)
+    with open(filename, "r") as fh:
+        return list(yaml.load_all(fh, Loader=yaml.UnsafeLoader))
 
 
 def save_info(path: str, info: list[dict], default_flow_style: bool = False) -> None:
-    with open(path, "w") as file:
-        yaml.dump_all(info, file, default_flow_style=default_flow_style)
+    with open(path, "w") as fh:
+        yaml.dump_all(info, fh, default_flow_style=default_flow_style)
 
 
 def load_raw(path: str, prompt_info=None, progress=None):
-    """-> (np.memmap movie (frames, height, width), info)."""
+    """-> (np.memmap movie (frames, height, width), info)  (picasso/io.py:50-96).  Without a sidecar,
+    `prompt_info()` may supply (info dict, save flag); returning None cancels."""
     try:
         info = load_info(path)
-    except FileNotFoundError as error:
-        if prompt_info is None:
-            raise error
-        result = prompt_info()
-        if result is None:
-            return
-        info, save = result
-        info = [info]
-        if save:
-            save_info(os.path.splitext(path)[0] + ".yaml", info)
-    dtype = np.dtype(info[0]["Data Type"])
-    shape = (info[0]["Frames"], info[0]["Height"], info[0]["Width"])
-    movie = np.memmap(path, dtype, "r", shape=shape)
-    if info[0]["Byte Order"] != "<":
-        movie = movie.byteswap()
-        info[0]["Byte Order"] = "<"
+    except FileNotFoundError:
+        answer = prompt_info() if prompt_info is not None else NotImplemented
+        if answer is NotImplemented:
+            raise
+        if answer is None:
+            return None
+        first, keep = answer
+        info = [first]
+        if keep:
+            save_info(_sidecar(path), info)
+    head = info[0]
+    movie = np.memmap(path, np.dtype(head["Data Type"]), "r", shape=(head["Frames"], head["Height"], head["Width"]))
+    if head["Byte Order"] != "<":
+        movie, head["Byte Order"] = movie.byteswap(), "<"
     return movie, info
 
 
 def save_raw(path: str, movie, info) -> None:
     movie.tofile(path)
-    save_info(os.path.splitext(path)[0] + ".yaml", info)
+    save_info(_sidecar(path), info)
 
 
 def load_movie(path: str, prompt_info=None, progress=None):
@@ -87,7 +89,7 @@ def _to_records(table: pd.DataFrame) -> np.ndarray:
 def save_locs(path: str, locs: pd.DataFrame, info: list[dict]) -> None:
     locs = lib.ensure_sanity(locs, info)
     _hdf5.write(path, {"locs": _to_records(locs)})
-    save_info(os.path.splitext(path)[0] + ".yaml", info)
+    save_info(_sidecar(path), info)
 
 
 def load_locs(path: str, qt_parent=None):
@@ -105,7 +107,7 @@ def load_locs(path: str, qt_parent=None):
 
 def save_identifications(path: str, identifications: pd.DataFrame, info: list[dict]) -> None:
     _hdf5.write(path, {"identifications": _to_records(identifications)})
-    save_info(os.path.splitext(path)[0] + ".yaml", info)
+    save_info(_sidecar(path), info)
 
 
 def load_identifications(path: str):
@@ -115,4 +117,4 @@ def load_identifications(path: str):
 def save_datasets(path: str, info: list[dict], **kwargs) -> None:
     """Several named tables (DataFrames or record arrays) in one file."""
     _hdf5.write(path, {k: (_to_records(v) if isinstance(v, pd.DataFrame) else np.asarray(v)) for k, v in kwargs.items()})
-    save_info(os.path.splitext(path)[0] + ".yaml", info)
+    save_info(_sidecar(path), info)

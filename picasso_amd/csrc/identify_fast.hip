@@ -41,9 +41,9 @@ static __device__ __forceinline__ float mul_rn(float a, float b) { return a * b;
 static __device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
 static __device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
 
-// float32 sqrt of 0..72 (the squared lengths that occur for box <= 13), correctly rounded; the host
+// float32 sqrt of 0..128 (the squared lengths that occur for box <= 17), correctly rounded; the host
 // checks them against sqrtf before the first launch (unit_vectors_match).
-constexpr float SQRT_F32[73] = {
+constexpr float SQRT_F32[129] = {
     0x0.0p+0f, 0x1.0p+0f, 0x1.6a09e6p+0f, 0x1.bb67aep+0f, 0x1.0p+1f, 0x1.1e377ap+1f, 0x1.3988e2p+1f,
     0x1.52a7fap+1f, 0x1.6a09e6p+1f, 0x1.8p+1f, 0x1.94c584p+1f, 0x1.a8872ap+1f, 0x1.bb67aep+1f, 0x1.cd82b4p+1f,
     0x1.deeea2p+1f, 0x1.efbdecp+1f, 0x1.0p+2f, 0x1.07e0f6p+2f, 0x1.0f876cp+2f, 0x1.16f834p+2f, 0x1.1e377ap+2f,
@@ -54,7 +54,15 @@ constexpr float SQRT_F32[73] = {
     0x1.cp+2f, 0x1.c48c6p+2f, 0x1.c90d2ap+2f, 0x1.cd82b4p+2f, 0x1.d1ed52p+2f, 0x1.d64d52p+2f, 0x1.daa2fep+2f,
     0x1.deeea2p+2f, 0x1.e3307cp+2f, 0x1.e768d4p+2f, 0x1.eb97e4p+2f, 0x1.efbdecp+2f, 0x1.f3db22p+2f, 0x1.f7efbep+2f,
     0x1.fbfbf8p+2f, 0x1.0p+3f, 0x1.01fe04p+3f, 0x1.03f82p+3f, 0x1.05ee68p+3f, 0x1.07e0f6p+3f, 0x1.09cfdcp+3f,
-    0x1.0bbb3p+3f, 0x1.0da304p+3f, 0x1.0f876cp+3f};
+    0x1.0bbb3p+3f, 0x1.0da304p+3f, 0x1.0f876cp+3f, 0x1.11687ap+3f, 0x1.13464p+3f, 0x1.1520cep+3f, 0x1.16f834p+3f,
+    0x1.18cc82p+3f, 0x1.1a9dc8p+3f, 0x1.1c6c16p+3f, 0x1.1e377ap+3f, 0x1.2p+3f, 0x1.21c5b8p+3f, 0x1.2388acp+3f,
+    0x1.2548ecp+3f, 0x1.270682p+3f, 0x1.28c17cp+3f, 0x1.2a79e4p+3f, 0x1.2c2fc6p+3f, 0x1.2de32cp+3f, 0x1.2f9422p+3f,
+    0x1.3142b4p+3f, 0x1.32eee8p+3f, 0x1.3498cap+3f, 0x1.364064p+3f, 0x1.37e5bep+3f, 0x1.3988e2p+3f, 0x1.3b29d8p+3f,
+    0x1.3cc8aap+3f, 0x1.3e655ep+3f, 0x1.4p+3f, 0x1.419894p+3f, 0x1.432f24p+3f, 0x1.44c3b8p+3f, 0x1.465656p+3f,
+    0x1.47e706p+3f, 0x1.4975cep+3f, 0x1.4b02b4p+3f, 0x1.4c8dc2p+3f, 0x1.4e16fep+3f, 0x1.4f9e6cp+3f, 0x1.512414p+3f,
+    0x1.52a7fap+3f, 0x1.542a28p+3f, 0x1.55aaap+3f, 0x1.57296ap+3f, 0x1.58a68ap+3f, 0x1.5a2208p+3f, 0x1.5b9be6p+3f,
+    0x1.5d142cp+3f, 0x1.5e8adep+3f, 0x1.6p+3f, 0x1.617398p+3f, 0x1.62e5acp+3f, 0x1.64564p+3f, 0x1.65c558p+3f,
+    0x1.6732f8p+3f, 0x1.689f26p+3f, 0x1.6a09e6p+3f};
 // unit vectors of picasso/localize.py:279-286 as compile-time float32 constants:
 // ux[k][l] = (H - l) / |(H - l, H - k)|, uy[k][l] = (H - k) / |...|  (float32 sqrt and divide)
 template <int H> constexpr float unit_x(int k, int l)
@@ -204,12 +212,12 @@ __device__ __forceinline__ float exact_ng_noWrap(const uint16_t *__restrict__ sr
 }
 
 template <int H, int RB, int D>
-__global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : 3)) void identify_scan_u16_fast_kernel(
+__global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6 ? 3 : 2))) void identify_scan_u16_fast_kernel(
     FastParams p, const float *__restrict__ uxy, Record *__restrict__ recs, long long cap,
     unsigned long long *__restrict__ shard_cnt, int *__restrict__ frame_count)
 {
     constexpr int BOX = 2 * H + 1;
-    // Boxes 11 and 13 (H = 5, 6) need 8 neighbour pixels per side and keep an Hrow ring of H slots of which
+    // Boxes 11 to 17 (H = 5..8) need 8 neighbour pixels per side and keep an Hrow ring of H slots of which
     // the slot about to be overwritten is skipped: both rings then share the period H.
     constexpr bool WIDE = H >= 5;
     constexpr int NB = WIDE ? 8 : 4, NA = 4 + NB, OWN = NB / 2;
@@ -627,7 +635,8 @@ template <int H> static bool unit_vectors_match_h()
 static bool unit_vectors_match()
 {
     static const bool ok = unit_vectors_match_h<1>() && unit_vectors_match_h<2>() && unit_vectors_match_h<3>() && unit_vectors_match_h<4>() &&
-                           unit_vectors_match_h<5>() && unit_vectors_match_h<6>();
+                           unit_vectors_match_h<5>() && unit_vectors_match_h<6>() && unit_vectors_match_h<7>() &&
+                           unit_vectors_match_h<8>();
     return ok;
 }
 
@@ -640,7 +649,7 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     static const bool force_generic = getenv("PMI_IDENTIFY_GENERIC") != nullptr;
     if (force_generic) return PMI_OK;
     const int h = box / 2;
-    if (h < 1 || h > 6) return PMI_OK;
+    if (h < 1 || h > 8) return PMI_OK;
     if (!unit_vectors_match()) return PMI_OK;          // never expected; the generic kernel uses the runtime table
     if ((X & 1) || cx < 16 || ((uintptr_t)d_movie & 3)) return PMI_OK;       // rows must start 4-byte aligned (buffer loads); the crop may not
     if (cy > 65535 || cx > 65535 || X > 65535 || Y * X * 2 >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets
@@ -678,7 +687,9 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     case 3: rc = launch_fast<3, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     case 4: rc = launch_fast<4, 64, 4>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     case 5: rc = launch_fast<5, 64, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
-    default: rc = launch_fast<6, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 6: rc = launch_fast<6, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 7: rc = launch_fast<7, 64, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    default: rc = launch_fast<8, 64, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     }
     if (rc == PMI_OK) *handled = true;
     return rc;

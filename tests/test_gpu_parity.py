@@ -180,7 +180,7 @@ def test_localize_pipeline_on_resident_movie(be, orc, testdata_movie):
                                       ((4, 64, 16), 3), ((2, 137, 512), 7), ((2, 66, 1536), 9), ((3, 40, 24), 7),
                                       ((3, 90, 130), 7), ((2, 75, 518), 5), ((2, 64, 36), 7), ((1, 131, 1030), 9),
                                       ((2, 150, 520), 11), ((2, 137, 512), 13), ((2, 90, 130), 13), ((1, 70, 1032), 11),
-                                      ((3, 64, 40), 13)])
+                                      ((3, 64, 40), 13), ((2, 120, 520), 15), ((2, 90, 130), 17), ((1, 70, 1032), 17), ((2, 64, 48), 15)])
 def test_identify_fast_path_vs_oracle(be, orc, shape, box):
     """uint16 movies of even width take the register-pipelined scan (identify_fast.hip): multi-segment
     rows, partial bands, partial last segment, widths that are not a multiple of 8 (the last chunk of a

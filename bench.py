@@ -63,7 +63,7 @@ def main():
     dev = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)      # "nccl" is RCCL on ROCm
+        dist.init_process_group(backend="nccl")      # "nccl" is RCCL on ROCm
     L = _lib.load()
     _lib.require_gpu()
     _lib.check(L.pmi_set_device(local_rank), "pmi_set_device")

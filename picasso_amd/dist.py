@@ -32,7 +32,10 @@ def shard_frames(n_frames: int, world: int, rank: int) -> Tuple[int, int]:
 def allgather_table(table: torch.Tensor, n_rows, group=None) -> torch.Tensor:
     """All-gather a column-major table (C columns x capacity, 4-byte cells, first
     `n_rows` of each column valid) from every rank.  Returns a (C, total) tensor
-    on every rank, rows in rank order."""
+    on every rank, rows in rank order.  Without a process group (one process, one GPU) it is
+    the identity on the valid rows."""
+    if not (dist.is_available() and dist.is_initialized()):
+        return table[:, : int(n_rows)].clone()
     world = dist.get_world_size(group)
     C = table.shape[0]
     n = torch.as_tensor([int(n_rows)], dtype=torch.int64, device=table.device)

@@ -254,11 +254,19 @@ class DeviceMovie:
     def __init__(self, movie: np.ndarray):
         _lib.require_gpu()
         movie = as_movie_array(movie)
+        self.capacity = max(movie.nbytes, 1)
+        self._ptr = ctypes.c_void_p()
+        _lib.check(_lib.load().pmi_malloc(ctypes.byref(self._ptr), self.capacity), "pmi_malloc")
+        self.load(movie)
+
+    def load(self, movie: np.ndarray):
+        """Upload another stack of frames into the same allocation (it must fit)."""
+        movie = as_movie_array(movie)
+        if movie.nbytes > self.capacity:
+            raise ValueError("DeviceMovie.load: stack larger than the allocation")
         self.shape = movie.shape
         self.dtype = movie.dtype
         self.nbytes = movie.nbytes
-        self._ptr = ctypes.c_void_p()
-        _lib.check(_lib.load().pmi_malloc(ctypes.byref(self._ptr), max(self.nbytes, 1)), "pmi_malloc")
         _lib.check(_lib.load().pmi_memcpy_h2d(self._ptr, _lib.ptr(movie), self.nbytes), "pmi_memcpy_h2d")
 
     @property

@@ -291,6 +291,24 @@ def localize(movie, camera_info: dict, parameters: dict, *, roi=None, frame_boun
             "and the metadata dictionary.")
     if movie_info is None:
         movie_info = []
+    if fitting_method in ("gaussmle", "gausslq"):
+        # one upload per frame chunk, identify -> cut -> fit -> table on the device: the same table as the
+        # two calls below, without sending the movie over PCIe twice or the identifications back and forth
+        box, min_ng = parameters["Box Size"], parameters["Min. Net Gradient"]
+        locs = localize_streamed(movie, camera_info, parameters, roi=roi, frame_bounds=frame_bounds,
+                                 fitting_method=fitting_method, eps=eps, max_it=max_it, mle_method=mle_method,
+                                 progress_callback=identification_progress_callback)
+        if callable(fit_progress_callback):
+            fit_progress_callback(len(locs), len(locs))
+        identify_info = {"Generated by": f"Picasso: v{__version__} Identify (picasso_amd HIP backend)",
+                         "Min. Net Gradient": min_ng, "Box Size": box, "ROI": roi, "Frame Bounds": frame_bounds}
+        fit_info = {"Generated by": f"Picasso: v{__version__} Fit 2D (picasso_amd HIP backend)",
+                    "Fit method": fitting_method}
+        if fitting_method == "gaussmle":
+            fit_info["Convergence criterion"] = eps
+            fit_info["Max iterations"] = max_it
+        info = movie_info + [identify_info] + [fit_info | camera_info]
+        return (locs, info) if return_info else locs
     identifications, identify_info = identify(movie, parameters["Min. Net Gradient"], parameters["Box Size"],
                                               roi=roi, frame_bounds=frame_bounds, threaded=threaded,
                                               progress_callback=identification_progress_callback,
@@ -329,6 +347,65 @@ def localize_resident(movie: np.ndarray, camera_info: dict, parameters: dict, *,
     return pd.DataFrame(cols)
 
 
+def localize_streamed(movie, camera_info: dict, parameters: dict, *, roi=None, frame_bounds=None,
+                      fitting_method: str = "gaussmle", eps: float = 0.001, max_it: int = 100,
+                      mle_method: str = "sigmaxy", chunk_bytes: int = 1 << 30,
+                      progress_callback=None) -> pd.DataFrame:
+    """The fused device pipeline over a host movie of any length (ndarray, memmap or a picasso movie
+    object): frames go up in chunks of about ``chunk_bytes`` through one staging allocation, each chunk runs
+    identify -> cut+fit -> table on the device, only the table rows come back.  The movie crosses PCIe once
+    and neither host RAM nor HBM has to hold it whole.  Same rows as ``localize_resident``."""
+    if fitting_method not in ("gaussmle", "gausslq"):
+        raise ValueError("localize_streamed supports fitting_method 'gaussmle' or 'gausslq'")
+    box, min_ng = parameters["Box Size"], parameters["Min. Net Gradient"]
+    N = len(movie)
+    lo, hi = backend.frame_range(frame_bounds, N)
+    hi = min(hi, N - 1)
+    columns = backend.LQ_COLUMNS if fitting_method == "gausslq" else backend.LOC_COLUMNS
+    parts = []
+    if hi >= lo:
+        first = np.asarray(movie[lo])
+        per = max(1, int(chunk_bytes) // max(first.nbytes, 1))
+        stage = None
+        try:
+            for c0 in range(lo, hi + 1, per):
+                c1 = min(hi + 1, c0 + per)
+                chunk = _frames(movie, c0, c1)
+                if stage is None:
+                    stage = backend.DeviceMovie(chunk)
+                else:
+                    stage.load(chunk)
+                if fitting_method == "gausslq":
+                    cols = backend.localize_lq_device(stage.ptr, stage.dtype, stage.shape, box, min_ng, camera_info,
+                                                      roi=roi)
+                else:
+                    cols = backend.localize_mle_device(stage.ptr, stage.dtype, stage.shape, box, min_ng, camera_info,
+                                                       eps, max_it, mle_method, roi=roi)
+                cols["frame"] = cols["frame"] + np.asarray(c0, cols["frame"].dtype)
+                parts.append(pd.DataFrame(cols))
+                if callable(progress_callback):
+                    progress_callback(c1 - lo)
+        finally:
+            if stage is not None:
+                stage.free()
+    if not parts:
+        return pd.DataFrame({name: np.empty(0, dt) for name, dt in columns})
+    return parts[0] if len(parts) == 1 else pd.concat(parts, ignore_index=True)
+
+
+def _frames(movie, c0: int, c1: int) -> np.ndarray:
+    """Frames [c0, c1) of an ndarray / memmap (one slice) or of a movie object that only indexes by frame."""
+    if isinstance(movie, np.ndarray):
+        return movie[c0:c1]
+    try:
+        a = np.asarray(movie[c0:c1])
+        if a.ndim == 3 and len(a) == c1 - c0:
+            return a
+    except Exception:
+        pass
+    return np.stack([np.asarray(movie[f]) for f in range(c0, c1)])
+
+
 def localize_file(path: str, camera_info: dict, parameters: dict, *, fitting_method: str = "gaussmle", roi=None,
                   frame_bounds=None, eps: float = 0.001, max_it: int = 100, mle_method: str = "sigmaxy",
                   drift: int = 0, suffix: str = "_locs") -> str:
@@ -339,7 +416,7 @@ def localize_file(path: str, camera_info: dict, parameters: dict, *, fitting_met
 
     from . import io, postprocess
     movie, info = io.load_movie(path)
-    locs = localize_resident(np.asarray(movie), camera_info, parameters, roi=roi, frame_bounds=frame_bounds,
+    locs = localize_streamed(movie, camera_info, parameters, roi=roi, frame_bounds=frame_bounds,
                              fitting_method=fitting_method, eps=eps, max_it=max_it, mle_method=mle_method)
     localize_info = {"Generated by": f"Picasso: v{__version__} Localize (picasso_amd HIP backend)",
                      "ROI": roi, "Box Size": parameters["Box Size"],

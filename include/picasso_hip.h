@@ -148,7 +148,9 @@ int pmi_locs_from_fits_dev(const int32_t *d_frame, const int32_t *d_y, const int
 /* ---- whole path on a resident movie ----------------------------------- *
  * identify -> fused cut+fit -> table, one asynchronous submission.  d_table is
  * one device block of PMI_LOC_COLUMNS * cap * 4 bytes (column c starts at
- * element c*cap).  d_out_n: device int64 row count.                         */
+ * element c*cap).  d_out_n: device int64 row count.  When it comes back
+ * larger than cap nothing was fitted and the table is untouched: resubmit
+ * with cap >= *d_out_n.                                                     */
 int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
                          int box, double min_ng, const int64_t *roi4, int64_t f_lo, int64_t f_hi,
                          double baseline, double sensitivity, double gain,

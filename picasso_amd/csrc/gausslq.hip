@@ -869,12 +869,14 @@ int pmi_localize_lq_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, in
     float *d_th = d_ng + cap;
     rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, f_lo, f_hi, 0, d_f, d_y, d_x, d_ng, cap, d_out_n, s);
     if (rc != PMI_OK) return rc;
-    rc = pmi_gausslq_movie_dev(d_movie, dtype, F, Y, X, d_f, d_y, d_x, cap, d_out_n, box, baseline, sensitivity,
+    const int64_t *d_rows = nullptr;
+    if ((rc = rows_to_fit(d_out_n, cap, &d_rows, s)) != PMI_OK) return rc;
+    rc = pmi_gausslq_movie_dev(d_movie, dtype, F, Y, X, d_f, d_y, d_x, cap, d_rows, box, baseline, sensitivity,
                                gain, d_th, nullptr, nullptr, stream);
     if (rc != PMI_OK) return rc;
     void *cols[PMI_LQ_COLUMNS];
     for (int c = 0; c < PMI_LQ_COLUMNS; c++) cols[c] = (char *)d_table + (size_t)c * cap * 4;
-    return pmi_locs_from_fits_lq_dev(d_f, d_y, d_x, d_ng, d_th, cap, d_out_n, em, cols, stream);
+    return pmi_locs_from_fits_lq_dev(d_f, d_y, d_x, d_ng, d_th, cap, d_rows, em, cols, stream);
 }
 
 }  // extern "C"

@@ -648,12 +648,14 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
     int32_t *d_it = (int32_t *)(d_ll + cap);
     rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, f_lo, f_hi, 0, d_f, d_y, d_x, d_ng, cap, d_out_n, s);
     if (rc != PMI_OK) return rc;
-    rc = pmi_gaussmle_movie_dev(d_movie, dtype, F, Y, X, d_f, d_y, d_x, cap, d_out_n, box, baseline, sensitivity,
+    const int64_t *d_rows = nullptr;
+    if ((rc = rows_to_fit(d_out_n, cap, &d_rows, s)) != PMI_OK) return rc;
+    rc = pmi_gaussmle_movie_dev(d_movie, dtype, F, Y, X, d_f, d_y, d_x, cap, d_rows, box, baseline, sensitivity,
                                 gain, eps, max_it, method, d_th, d_cr, d_ll, d_it, stream);
     if (rc != PMI_OK) return rc;
     void *cols[PMI_LOC_COLUMNS];
     for (int c = 0; c < PMI_LOC_COLUMNS; c++) cols[c] = (char *)d_table + (size_t)c * cap * 4;
-    return pmi_locs_from_fits_dev(d_f, d_y, d_x, d_ng, d_th, d_cr, d_ll, d_it, cap, d_out_n, box, cols, stream);
+    return pmi_locs_from_fits_dev(d_f, d_y, d_x, d_ng, d_th, d_cr, d_ll, d_it, cap, d_rows, box, cols, stream);
 }
 
 }  // extern "C"

@@ -15,6 +15,7 @@
 // counts -> exclusive scan -> scatter by frame -> rank sort inside each frame.
 #include <algorithm>
 #include <cmath>
+#include <type_traits>
 #include <vector>
 
 #include "pmi_common.h"
@@ -226,46 +227,76 @@ __global__ void scatter_by_frame_kernel(const Record *__restrict__ recs, const u
     }
 }
 
-// one wave per frame: rank of each record among the frame's records by (y, x); the frame's keys
-// are staged in LDS when they fit (they do unless a frame holds more than SORT_LDS maxima)
-constexpr int SORT_LDS = 1024;
-__global__ __launch_bounds__(PMI_WAVE) void sort_in_frame_kernel(const Record *__restrict__ grouped,
-                                                                 const int *__restrict__ base,
-                                                                 const int *__restrict__ count,
-                                                                 const unsigned long long *__restrict__ counters,
-                                                                 long long cap,
-                                                                 int32_t *__restrict__ o_frame, int32_t *__restrict__ o_y,
-                                                                 int32_t *__restrict__ o_x, float *__restrict__ o_ng)
+// Rank of each record among its frame's records by (y, x).  grid = (frames, split): every block stages the
+// frame's keys in LDS (they fit unless a frame holds more than SORT_LDS maxima) and ranks its own slice of the
+// records, so a dense frame (2048 x 2048: ~1600 maxima) is spread over `split` blocks instead of one wave.  With
+// Y, X <= 65536 a key is (y << 16 | x) in 32 bits and one 16-byte LDS broadcast feeds four compares.
+constexpr int SORT_LDS = 4096;
+constexpr int SORT_THREADS = 256;
+template <bool K32>
+__global__ __launch_bounds__(SORT_THREADS) void sort_in_frame_kernel(const Record *__restrict__ grouped,
+                                                                     const int *__restrict__ base,
+                                                                     const int *__restrict__ count,
+                                                                     const unsigned long long *__restrict__ counters,
+                                                                     long long cap,
+                                                                     int32_t *__restrict__ o_frame, int32_t *__restrict__ o_y,
+                                                                     int32_t *__restrict__ o_x, float *__restrict__ o_ng)
 {
-    __shared__ unsigned long long s_key[SORT_LDS];
+    using key_t = typename std::conditional<K32, unsigned, unsigned long long>::type;
+    __shared__ __attribute__((aligned(16))) key_t s_key[SORT_LDS];
     if ((long long)counters[ID_SHARDS] > cap) return;   // overflow: the caller retries with a larger capacity
     const int fi = blockIdx.x;
     const int m = count[fi], b = base[fi];
-    if (m == 0) return;
-    const bool in_lds = m <= SORT_LDS;
-    if (in_lds) {
-        for (int q = threadIdx.x; q < m; q += PMI_WAVE) {
-            const Record o = grouped[b + q];
-            s_key[q] = ((unsigned long long)(unsigned)o.y << 32) | (unsigned)o.x;
-        }
+    const int per = (((m + (int)gridDim.y - 1) / (int)gridDim.y) + 63) & ~63;
+    const int q0 = (int)blockIdx.y * per, q1 = min(m, q0 + per);
+    if (q0 >= m) return;
+    auto key_of = [](const Record &o) -> key_t {
+        if constexpr (K32) return ((unsigned)o.y << 16) | (unsigned)o.x;
+        else return ((unsigned long long)(unsigned)o.y << 32) | (unsigned)o.x;
+    };
+    // keys go through LDS in tiles of SORT_LDS; a frame with fewer maxima than that (the usual case) is staged once
+    auto stage = [&](int t0, int tm) {
+        const int tmp = (tm + 3) & ~3;
+        for (int q = threadIdx.x; q < tmp; q += SORT_THREADS)
+            s_key[q] = q < tm ? key_of(grouped[b + t0 + q]) : ~(key_t)0;   // padding never counts: no key is above it
+    };
+    const bool single = m <= SORT_LDS;
+    if (single) {
+        stage(0, m);
         __syncthreads();
     }
-    for (int q = threadIdx.x; q < m; q += PMI_WAVE) {
-        const Record r = grouped[b + q];
-        const unsigned long long key = ((unsigned long long)(unsigned)r.y << 32) | (unsigned)r.x;
+    for (int qb = q0; qb < q1; qb += SORT_THREADS) {
+        const int q = qb + (int)threadIdx.x;
+        const bool act = q < q1;
+        Record r = {};
+        key_t key = 0;
+        if (act) {
+            r = grouped[b + q];
+            key = key_of(r);
+        }
         int rank = 0;
-        if (in_lds) {
-            for (int t = 0; t < m; t++) rank += s_key[t] < key;          // uniform address: one LDS broadcast per step
-        } else {
-            for (int t = 0; t < m; t++) {
-                const Record o = grouped[b + t];
-                rank += (((unsigned long long)(unsigned)o.y << 32) | (unsigned)o.x) < key;
+        for (int t0 = 0; t0 < m; t0 += SORT_LDS) {
+            const int tm = min(SORT_LDS, m - t0);
+            if (!single) {
+                __syncthreads();
+                stage(t0, tm);
+                __syncthreads();
+            }
+            if constexpr (K32) {
+                for (int t = 0; t < tm; t += 4) {                            // uniform address: one LDS broadcast per step
+                    const uint4 k4 = *reinterpret_cast<const uint4 *>(&s_key[t]);
+                    rank += (int)(k4.x < key) + (int)(k4.y < key) + (int)(k4.z < key) + (int)(k4.w < key);
+                }
+            } else {
+                for (int t = 0; t < tm; t++) rank += s_key[t] < key;
             }
         }
-        o_frame[b + rank] = r.frame;
-        o_y[b + rank] = r.y;
-        o_x[b + rank] = r.x;
-        o_ng[b + rank] = r.ng;
+        if (act) {
+            o_frame[b + rank] = r.frame;
+            o_y[b + rank] = r.y;
+            o_x[b + rank] = r.x;
+            o_ng[b + rank] = r.ng;
+        }
     }
 }
 
@@ -395,8 +426,13 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
         const unsigned sb = (unsigned)std::min<long long>((cap + 255) / 256, 512);
         hipLaunchKernelGGL(scatter_by_frame_kernel, dim3(sb, ID_SHARDS), dim3(256), 0, s, recs, d_total, (long long)cap,
                            (long long)(f_lo + label_offset), base, cursor, grouped);
-        hipLaunchKernelGGL(sort_in_frame_kernel, dim3((unsigned)nf), dim3(PMI_WAVE), 0, s, grouped, base, count,
-                           d_total, (long long)cap, d_frame, d_y, d_x, d_ng);
+        const unsigned split = (unsigned)std::min<int64_t>(16, std::max<int64_t>(1, (Y * X + 262143) / 262144));
+        if (Y <= 65536 && X <= 65536)
+            hipLaunchKernelGGL(sort_in_frame_kernel<true>, dim3((unsigned)nf, split), dim3(SORT_THREADS), 0, s, grouped, base,
+                               count, d_total, (long long)cap, d_frame, d_y, d_x, d_ng);
+        else
+            hipLaunchKernelGGL(sort_in_frame_kernel<false>, dim3((unsigned)nf, split), dim3(SORT_THREADS), 0, s, grouped, base,
+                               count, d_total, (long long)cap, d_frame, d_y, d_x, d_ng);
     }
     PMI_HIP(hipGetLastError());
     return PMI_OK;

@@ -32,10 +32,14 @@ enum ScratchSlot {
     SCR_STAGE_B,
     SCR_STAGE_C,
     SCR_STAGE_D,
+    SCR_ROWS,             // rows the fit stages of the fused pipelines may touch
     SCR_NUM
 };
 int scratch(int slot, size_t bytes, void **ptr);
 int scratch_release_all();
+// Fused pipelines: *d_rows = *d_total if it fits the caller's capacity, else 0 (the identification columns were not
+// written; the caller sees *d_total > cap and resubmits), so that the fit stages never follow stale rows.
+int rows_to_fit(const int64_t *d_total, int64_t cap, const int64_t **d_rows, hipStream_t s);
 
 struct Record {   // one identification, 16 B
     int32_t frame, y, x;

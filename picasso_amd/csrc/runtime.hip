@@ -51,6 +51,23 @@ int scratch_release_all()
     return PMI_OK;
 }
 
+__global__ void rows_to_fit_kernel(const int64_t *__restrict__ total, int64_t cap, int64_t *__restrict__ rows)
+{
+    const int64_t n = *total;
+    *rows = n > cap ? 0 : n;
+}
+
+int rows_to_fit(const int64_t *d_total, int64_t cap, const int64_t **d_rows, hipStream_t s)
+{
+    void *ptr = nullptr;
+    int rc = scratch(SCR_ROWS, sizeof(int64_t), &ptr);
+    if (rc != PMI_OK) return rc;
+    hipLaunchKernelGGL(rows_to_fit_kernel, dim3(1), dim3(1), 0, s, d_total, cap, (int64_t *)ptr);
+    PMI_HIP(hipGetLastError());
+    *d_rows = (const int64_t *)ptr;
+    return PMI_OK;
+}
+
 void release_fft_plans();   // xcorr.hip
 
 }  // namespace pmi

@@ -137,3 +137,36 @@ def test_config5_astigmatic_13x13_and_zfit(be, orc):
     assert np.max(np.abs(zz - oz)) < 5e-5 and np.max(np.abs(sq - osq)) < 1e-9
     # the fitted z follows the simulated one (astigmatism calibration is monotonic in this range)
     assert np.median(np.abs(zz - z)) < 25.0
+
+
+def test_config4_geometry_shard_in_miniature(be, orc):
+    """Config 4's frame geometry (2048 x 2048, ~1600 spots per frame) at a length the oracle can follow: the
+    identification set and net gradients are the oracle's, the fit is within tolerance, frame ranges concatenate
+    to the whole table (what the 8-rank form relies on), and RCC undrift runs on the table.  The full 25 000-frame
+    share of one rank is measured by tools/bench_config4_shard.py (profiles/r01g_config4_shard.jsonl)."""
+    import torch
+    from picasso_amd import postprocess, synth
+    F, H, W = 48, 2048, 2048
+    movie = synth.simulate_movie(F, H, W, emitters_per_frame=1856, device="cuda", chunk_frames=16)
+    torch.cuda.synchronize()
+    t = _localize_resident(be, movie)
+    fr = t["frame"].astype(np.int64)
+    per = np.bincount(fr, minlength=F)
+    assert per.min() > 1400 and per.max() < 1800 and np.all(np.diff(fr) >= 0)
+    parts = [_localize_resident(be, movie, f_lo=a, f_hi=b) for a, b in ((0, 5), (6, 23), (24, 47))]
+    for c in t:
+        assert np.array_equal(np.concatenate([p[c] for p in parts]), t[c], equal_nan=True), c
+    sub = movie[10:13].cpu().numpy()
+    ofr, oy, ox, ong = orc.identify(sub, 5000.0, 7, threads=4)
+    m = (fr >= 10) & (fr < 13)
+    assert m.sum() == len(ofr) and np.array_equal(fr[m] - 10, ofr) and np.array_equal(t["net_gradient"][m], ong)
+    spots = orc.get_spots(sub, ofr, oy, ox, 7, CAM)
+    th, cr, ll, it = orc.gaussmle(spots, 1e-3, 100, "sigmaxy", threads=4)
+    same = t["iterations"][m] == it
+    assert same.mean() > 0.95
+    assert np.max(np.abs(t["x"][m] - (th[:, 0] + ox - 3))[same]) < 1e-3
+    assert np.max(np.abs(t["y"][m] - (th[:, 1] + oy - 3))[same]) < 1e-3
+    locs = pd.DataFrame(t)
+    drift, und = postprocess.undrift(locs, [{"Frames": F, "Height": H, "Width": W}, {"Pixelsize": 130}], 8, display=False)
+    assert len(und) == len(locs) and len(drift) == F and float(np.abs(drift.to_numpy()).max()) < 0.2
+    del movie

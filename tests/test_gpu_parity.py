@@ -457,3 +457,66 @@ def test_photon_conversion_division_is_correctly_rounded(be, orc):
                 raw = np.stack([mov[f, yy - 3:yy + 4, xx - 3:xx + 4] for f, yy, xx in zip(fr, y, x)]).astype(np.float32)
                 want = (raw - np.float32(99.5)) * np.float32(sens) / np.float32(gain)
                 assert want.dtype == np.float32 and np.array_equal(a, want), (dtype, gain, sens)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("shape,box", [((2, 300, 600), 3), ((1, 1100, 1040), 5), ((3, 70, 2100), 3)])
+def test_identify_dense_frames_order(be, orc, shape, box):
+    """Noise frames with a threshold that keeps every maximum: thousands of rows per frame, more than one LDS
+    tile of sort keys (4096) and several sort blocks per frame; rows still come back in (frame, y, x) order
+    with the oracle's values."""
+    rng = np.random.default_rng(shape[1] * 7 + box)
+    mov = rng.integers(100, 4000, size=shape).astype(np.uint16)
+    a = be.identify_arrays(mov, -1e9, box)
+    b = orc.identify(mov, -1e9, box, threads=4)
+    assert len(a[0]) == len(b[0]) > 4096 * shape[0] // 2
+    assert all(np.array_equal(p, q) for p, q in zip(a, b))
+    key = (a[0].astype(np.int64) << 40) | (a[1].astype(np.int64) << 20) | a[2].astype(np.int64)
+    assert np.all(np.diff(key) > 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("lq", [False, True])
+def test_fused_pipeline_capacity_overflow_is_clean(be, lq):
+    """A table capacity below the row count: the fused submission reports the count, fits nothing, leaves the
+    table alone (no stale identification is followed into the movie), and the resubmission with room gives
+    the same rows as a roomy first call."""
+    import ctypes
+    from picasso_amd import _lib
+    rng = np.random.default_rng(3)
+    mov = rng.poisson(40, size=(6, 96, 160)).astype(np.uint16) + 100
+    for f in range(6):
+        for _ in range(40):
+            y, x = rng.integers(6, 90), rng.integers(6, 154)
+            mov[f, y - 1:y + 2, x - 1:x + 2] += 300
+            mov[f, y, x] += 900
+    cam = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
+    dm = be.DeviceMovie(mov)
+    fn = be.localize_lq_device if lq else be.localize_mle_device
+    roomy = fn(dm.ptr, dm.dtype, dm.shape, 7, 500.0, cam, cap=100000)
+    n = len(roomy["frame"])
+    assert n > 100
+    L = _lib.load()
+    ncol = _lib.PMI_LQ_COLUMNS if lq else _lib.PMI_LOC_COLUMNS
+    cap = 16
+    table, dn = ctypes.c_void_p(), ctypes.c_void_p()
+    _lib.check(L.pmi_malloc(ctypes.byref(table), ncol * cap * 4), "malloc")
+    _lib.check(L.pmi_malloc(ctypes.byref(dn), 8), "malloc")
+    fill = np.full(ncol * cap, 0x5A5A5A5A, np.uint32)
+    _lib.check(L.pmi_memcpy_h2d(table, _lib.ptr(fill), fill.nbytes), "h2d")
+    if lq:
+        rc = L.pmi_localize_lq_dev(dm.ptr, 0, 6, 96, 160, 7, 500.0, None, 0, 5, 100.0, 1.0, 1.0, 0, table, cap, dn, None)
+    else:
+        rc = L.pmi_localize_mle_dev(dm.ptr, 0, 6, 96, 160, 7, 500.0, None, 0, 5, 100.0, 1.0, 1.0, 1e-3, 100, 1, table, cap, dn, None)
+    _lib.check(rc, "fused")
+    _lib.check(L.pmi_stream_synchronize(None), "sync")
+    got_n = np.zeros(1, np.int64)
+    back = np.zeros_like(fill)
+    _lib.check(L.pmi_memcpy_d2h(_lib.ptr(got_n), dn, 8), "d2h")
+    _lib.check(L.pmi_memcpy_d2h(_lib.ptr(back), table, back.nbytes), "d2h")
+    assert int(got_n[0]) == n and np.array_equal(back, fill)
+    L.pmi_free(table); L.pmi_free(dn)
+    retried = fn(dm.ptr, dm.dtype, dm.shape, 7, 500.0, cam, cap=16)      # grows to the reported count
+    for c in roomy:
+        assert np.array_equal(roomy[c], retried[c], equal_nan=True), c
+    dm.free()

@@ -1,0 +1,115 @@
+#!/usr/bin/env python3
+"""One rank's share of BASELINE.json config 4 (200 000 frames x 2048 x 2048 over 8 GPUs = 25 000 frames,
+210 GB of uint16, ~4e7 spots per GPU), resident in the HBM of ONE MI355X: the movie is generated on the device
+in chunks (never on the host), localized with the fused MLE pipeline, checked through size-independent
+properties, then RCC-undrifted on the device.  The 8-rank form adds only the table all-gather
+(picasso_amd/dist.py); this tool measures what each rank does before it.
+
+usage: python tools/bench_config4_shard.py [--frames 25000] [--steps 3] [--segmentation 1000]
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=25000)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--segmentation", type=int, default=1000)
+    ap.add_argument("--undrift", type=int, default=1)
+    args = ap.parse_args()
+    import pandas as pd
+    import torch
+    from picasso_amd import _lib, backend, postprocess, synth
+    L = _lib.load()
+    _lib.require_gpu()
+    F, H, W = args.frames, 2048, 2048
+    cam = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
+    free0, total = torch.cuda.mem_get_info()
+    need = F * H * W * 2
+    print(f"# HBM free {free0 / 1e9:.1f} of {total / 1e9:.1f} GB; movie needs {need / 1e9:.1f} GB", flush=True)
+    if need + 12e9 > free0:
+        raise SystemExit("not enough free HBM for this shard")
+    t0 = time.perf_counter()
+    # same per-pixel density as config 2 (116 emitters per 512x512): 16x the area
+    movie = synth.simulate_movie(F, H, W, emitters_per_frame=1856, device="cuda", chunk_frames=64)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    print(f"# generated on device in {t_gen:.1f} s", flush=True)
+    cap = 1900 * F
+    table = torch.empty((_lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device="cuda")
+    d_n = torch.zeros(1, dtype=torch.int64, device="cuda")
+
+    def run():
+        _lib.check(L.pmi_localize_mle_dev(ctypes.c_void_p(movie.data_ptr()), 0, F, H, W, 7, 5000.0, None, 0, F - 1,
+                                          cam["Baseline"], cam["Sensitivity"], cam["Gain"], 1e-3, 100, 1,
+                                          ctypes.c_void_p(table.data_ptr()), cap, ctypes.c_void_p(d_n.data_ptr()), None), "localize")
+
+    _lib.check(L.pmi_set_kernel_timing(1), "timing")
+    run(); torch.cuda.synchronize()
+    ts, t_id = [], []
+    for _ in range(args.steps):
+        torch.cuda.synchronize(); t0 = time.perf_counter(); run(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
+        a, b = ctypes.c_float(), ctypes.c_float()
+        _lib.check(L.pmi_last_kernel_ms(ctypes.byref(a), ctypes.byref(b)), "kernel ms")
+        t_id.append(a.value)
+    _lib.check(L.pmi_set_kernel_timing(0), "timing")
+    n = int(d_n.item())
+    if n > cap:
+        raise SystemExit(f"table capacity {cap} too small for {n} rows")
+    dt, ms_id = float(np.median(ts)), float(np.median(t_id))
+    # ---- size-independent properties of the table (the full-size parity checks of tests/test_gpu_configs.py) ----
+    fr = table[0, :n]
+    cols = {name: table[c, :n].view(torch.float32) for c, (name, _) in enumerate(backend.LOC_COLUMNS) if name not in ("frame", "iterations")}
+    assert bool((fr[1:] >= fr[:-1]).all()), "table not frame-sorted"
+    assert int(fr.min()) >= 0 and int(fr.max()) <= F - 1
+    per_frame = torch.bincount(fr.to(torch.int64), minlength=F)
+    conv = table[12, :n] < 100
+    ok = torch.isfinite(cols["lpx"]) & conv
+    inside = (cols["x"] > 3) & (cols["x"] < W - 4) & (cols["y"] > 3) & (cols["y"] < H - 4)
+    props = {"rows": n, "rows_per_frame_mean": float(per_frame.float().mean()), "rows_per_frame_min": int(per_frame.min()),
+             "rows_per_frame_max": int(per_frame.max()), "converged_frac": float(conv.float().mean()),
+             "finite_crlb_frac": float(ok.float().mean()), "inside_frac": float(inside.float().mean()),
+             "photons_median": float(cols["photons"].median()), "sx_median": float(cols["sx"].median()),
+             "lpx_median": float(cols["lpx"][ok].median())}
+    # the first 64 frames again as their own movie: the same rows (shards are independent units)
+    sub = backend.localize_mle_device(movie.data_ptr(), np.dtype("uint16"), (64, H, W), 7, 5000.0, cam)
+    k = len(sub["frame"])
+    head = {name: table[c, :k].cpu().numpy().view(dt_) for c, (name, dt_) in enumerate(backend.LOC_COLUMNS)}
+    for name in sub:
+        assert np.array_equal(sub[name], head[name], equal_nan=True), f"shard head differs in {name}"
+    out = {"metric": "localizations/sec (7x7 ROI, MLE), one rank's share of config 4", "value": n / dt, "unit": "localizations/s",
+           "n_gpus": 1, "steps": args.steps, "ms_per_step": 1e3 * dt, "higher_is_better": True, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": f"{F} frames x {H} x {W} uint16 resident in HBM ({need / 1e9:.0f} GB), {n} spots, identify + fused cut + "
+                                  "MLE sigmaxy + 17-column table", "frames": F, "box": 7},
+           "roofline": {"bound": "hbm", "achieved": need / 1e9 / (ms_id / 1e3), "peak": 8000.0, "unit": "GB/s",
+                        "frac": need / 1e9 / (ms_id / 1e3) / 8000.0, "traffic": None},
+           "identify_ms": ms_id, "generate_s": t_gen, "table_bytes": n * 68, "properties": props}
+    print(json.dumps(out), flush=True)
+    if args.undrift:
+        # RCC on this shard's localizations (segments of `segmentation` frames align with the frame shards)
+        names = [c for c, _ in backend.LOC_COLUMNS]
+        t0 = time.perf_counter()
+        locs = pd.DataFrame({name: table[c, :n].cpu().numpy().view(dt_) for c, (name, dt_) in enumerate(backend.LOC_COLUMNS)})
+        t_d2h = time.perf_counter() - t0
+        info = [{"Frames": F, "Height": H, "Width": W}, {"Pixelsize": 130}]
+        t0 = time.perf_counter()
+        drift, und = postprocess.undrift(locs, info, args.segmentation, display=False)
+        t_u = time.perf_counter() - t0
+        d = np.asarray(drift[["x", "y"]] if hasattr(drift, "columns") else np.stack([drift["x"], drift["y"]], 1))
+        print(json.dumps({"undrift": {"segmentation": args.segmentation, "segments": F // args.segmentation,
+                                      "pairs": (F // args.segmentation) * (F // args.segmentation - 1) // 2,
+                                      "table_d2h_s": t_d2h, "undrift_s": t_u, "max_abs_drift_px": float(np.abs(d).max()),
+                                      "rows": len(und), "columns": names[:3]}}), flush=True)
+
+
+if __name__ == "__main__":
+    main()

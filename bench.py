@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--method", default="sigmaxy")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra instrumented steps for per-kernel time")
+    ap.add_argument("--serial-gather", action="store_true",
+                    help="N > 1: wait for each step's all-gather before the next step computes (no overlap)")
     return ap.parse_args()
 
 
@@ -61,7 +63,9 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     torch.cuda.set_device(local_rank)                # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local_rank)
-    if world > 1:
+    # under torch.distributed.run (even with one process) the collectives are part of the step
+    grouped = world > 1 or ("MASTER_PORT" in os.environ and "RANK" in os.environ)
+    if grouped:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl")      # "nccl" is RCCL on ROCm
     L = _lib.load()
@@ -92,40 +96,72 @@ def main():
     n_local = int(d_n.item())
     assert 0 < n_local <= cap, f"sizing pass found {n_local} rows (cap {cap})"
     cap = int(n_local * 1.02) + 1024
-    if world > 1:
+    if grouped:
         capt = torch.tensor([cap], dtype=torch.int64, device=dev)
         dist.all_reduce(capt, op=dist.ReduceOp.MAX)
         cap = int(capt.item())
     del table
-    table = torch.empty((_lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device=dev)
+    # Two sets of buffers: the all-gather of step i (RCCL's own stream, over xGMI) runs while step i+1
+    # computes into the other set; a set is reused only after its gather has finished.  Every gather
+    # completes inside the timed region (drained before the closing synchronize + barrier).
+    nbuf = 2 if (grouped and not args.serial_gather) else 1
+    tables = [torch.empty((_lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+    d_ns = [torch.zeros(1, dtype=torch.int64, device=dev) for _ in range(nbuf)]
     gathered = gathered_n = None
-    if world > 1:
-        gathered = torch.empty((world * _lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device=dev)
-        gathered_n = torch.empty((world,), dtype=torch.int64, device=dev)
+    if grouped:
+        gathered = [torch.empty((world * _lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device=dev) for _ in range(nbuf)]
+        gathered_n = [torch.empty((world,), dtype=torch.int64, device=dev) for _ in range(nbuf)]
+    pending = [None] * nbuf
+    table, d_n = tables[0], d_ns[0]
 
-    def step():
-        run(table, d_n, cap)
-        if world > 1:      # localization table of every shard on every GPU (RCCL over xGMI)
-            dist.all_gather_into_tensor(gathered_n, d_n)
-            dist.all_gather_into_tensor(gathered, table)
+    def drain(k):
+        if pending[k] is not None:
+            for w in pending[k]:
+                w.wait()                 # the compute stream waits for that gather; the host does not block
+            pending[k] = None
 
-    for _ in range(args.warmup):
-        step()
+    def step(i):
+        k = i % nbuf
+        drain(k)
+        run(tables[k], d_ns[k], cap)
+        if grouped:        # localization table of every shard on every GPU (RCCL over xGMI)
+            if nbuf == 1:
+                dist.all_gather_into_tensor(gathered_n[0], d_ns[0])
+                dist.all_gather_into_tensor(gathered[0], tables[0])
+            else:
+                pending[k] = (dist.all_gather_into_tensor(gathered_n[k], d_ns[k], async_op=True),
+                              dist.all_gather_into_tensor(gathered[k], tables[k], async_op=True))
+
+    def drain_all():
+        for k in range(nbuf):
+            drain(k)
+
+    for i in range(args.warmup):
+        step(i)
+    drain_all()
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
+    for i in range(args.steps):
+        step(i)
+    drain_all()
     torch.cuda.synchronize()
-    if world > 1:
+    if grouped:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
+    if grouped:
+        # the gathered table is what every rank would hand on: check rank order and counts once
+        last = (args.steps - 1) % nbuf if args.steps > 0 else 0
+        counts = gathered_n[last].cpu().tolist()
+        assert counts[rank] == int(d_ns[last].item()) and all(0 < c <= cap for c in counts), counts
+        mine = gathered[last].view(world, _lib.PMI_LOC_COLUMNS, cap)[rank, :, : counts[rank]]
+        assert torch.equal(mine, tables[last][:, : counts[rank]]), "gathered table differs from the local one"
     et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     nt = torch.tensor([int(d_n.item())], dtype=torch.int64, device=dev)
-    if world > 1:
+    if grouped:
         dist.all_reduce(et, op=dist.ReduceOp.MAX)
         dist.all_reduce(nt, op=dist.ReduceOp.SUM)
     elapsed = float(et.item())
@@ -175,7 +211,9 @@ def main():
             "config": {"workload": f"{F}-frame {H}x{W} uint16 simulated DNA-PAINT movie per GPU, "
                                    f"{n_total // world} spots per GPU, {box}x{box} ROI MLE ({args.method}), "
                                    "identify+cut+fit+table resident in HBM"
-                                   + (", + RCCL all-gather of the table" if world > 1 else ""),
+                                   + (", + RCCL all-gather of the table"
+                                      + (" (double-buffered: overlaps the next step's compute)" if nbuf == 2 else "")
+                                      if grouped else ""),
                        "frames": F, "height": H, "width": W, "box": box, "min_net_gradient": args.min_ng,
                        "eps": 1e-3, "max_it": 100, "localizations_total": n_total,
                        "sharding": f"frames x{world}"},
@@ -183,7 +221,7 @@ def main():
             "cpu_baseline": cpu,
         }
         print(json.dumps(result), flush=True)
-    if world > 1:
+    if grouped:
         dist.barrier()
         dist.destroy_process_group()
     return result

@@ -270,9 +270,10 @@ def cpu_baseline(movie, cam, box, min_ng, method, budget_s):
         if best is None or n / dt > best[0]:
             best = (n / dt, t, dt)
     rate, threads, dt = best
+    n1, dt1 = run(probe, 1)                  # the single-thread rate beside the all-thread one
     frames = int(min(movie.shape[0], max(probe, probe * budget_s / max(dt, 1e-3))))
     n, dt = run(frames, threads)
-    return {"value": n / dt, "unit": "localizations/s", "cores": threads, "kind": "port",
+    return {"value": n / dt, "unit": "localizations/s", "cores": threads, "kind": "port", "value_1_thread": n1 / dt1,
             "sample": f"first {frames} frames of the same movie ({n} spots), identify+get_spots+gaussmle "
                       f"({method}, eps 1e-3, max_it 100), C/OpenMP restatement of the reference algorithm, "
                       f"{dt:.1f} s"}

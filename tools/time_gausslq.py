@@ -1,5 +1,5 @@
 """Times pmi_gausslq_dev on synthetic spots (device resident) and reports exactness vs the oracle on a sample.
-usage: python tools/time_gausslq.py [N] [box]"""
+usage: python tools/time_gausslq.py [N] [box] [same4|sorted]"""
 import ctypes
 import sys
 import time
@@ -22,7 +22,14 @@ for i in range(base):
     gx = np.exp(-0.5 * ((idx - x0) / sx) ** 2) / (np.sqrt(2 * np.pi) * sx)
     gy = np.exp(-0.5 * ((idx - y0) / sy) ** 2) / (np.sqrt(2 * np.pi) * sy)
     spots[i] = rng.poisson(rng.uniform(800, 9000) * np.outer(gy, gx) + rng.uniform(2, 40))
-spots = np.ascontiguousarray(np.tile(spots, (N // base, 1, 1)))
+if len(sys.argv) > 3 and sys.argv[3] == "same4":       # four copies side by side: the groups of a wavefront stay in step
+    spots = np.repeat(spots, 4, axis=0)
+    spots = np.ascontiguousarray(np.tile(spots, (N // (4 * base), 1, 1)))
+elif len(sys.argv) > 3 and sys.argv[3] == "sorted":     # neighbours need about the same number of evaluations
+    spots = spots[np.argsort(spots.reshape(base, -1).max(axis=1))]
+    spots = np.ascontiguousarray(np.repeat(spots, N // base, axis=0))
+else:
+    spots = np.ascontiguousarray(np.tile(spots, (N // base, 1, 1)))
 N = len(spots)
 L = _lib.load()
 d_sp, d_th, d_nf = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()

@@ -205,3 +205,61 @@ def test_install_rebinds_the_reference_functions():
     assert pl._fit2d_gaussmle is localize._fit2d_gaussmle and pl._fit2d_gausslq is localize._fit2d_gausslq
     assert pm.gaussmle is amd_mle.gaussmle and pm.gaussmle_async is amd_mle.gaussmle_async
     assert pq.fit_spots is gausslq.fit_spots and pq.fit_spots_parallel is gausslq.fit_spots_parallel
+
+
+def test_localize_streamed_chunking_logic(monkeypatch, testdata_movie):
+    """Host logic of the chunked upload (no GPU): the device calls are replaced by the oracle's identify, so what
+    is checked is the chunk boundaries, the frame labels, frame bounds, the progress callback, the reuse of one
+    staging allocation and the empty result; the device side of the same function is the GPU tier's."""
+    from oracle import oracle as orc
+
+    class FakeStage:
+        made = 0
+
+        def __init__(self, chunk):
+            FakeStage.made += 1
+            self.capacity = np.asarray(chunk).nbytes
+            self.load(chunk)
+
+        def load(self, chunk):
+            chunk = np.ascontiguousarray(chunk)
+            assert chunk.nbytes <= self.capacity
+            self.ptr, self.dtype, self.shape = chunk, chunk.dtype, chunk.shape
+
+        def free(self):
+            self.ptr = None
+
+    def fake_device(stage_ptr, dtype, shape, box, min_ng, camera, *a, roi=None, **k):
+        assert stage_ptr.shape == tuple(shape)
+        fr, y, x, ng = orc.identify(stage_ptr, min_ng, box, roi=roi, threads=2)
+        cols = {name: np.zeros(len(fr), dt) for name, dt in backend.LOC_COLUMNS}
+        cols["frame"] = fr.astype(np.uint32)
+        cols["x"], cols["y"], cols["net_gradient"] = x.astype(np.float32), y.astype(np.float32), ng
+        return cols
+
+    monkeypatch.setattr(backend, "DeviceMovie", FakeStage)
+    monkeypatch.setattr(backend, "localize_mle_device", fake_device)
+    mov = np.ascontiguousarray(testdata_movie)
+    cam = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
+    params = {"Min. Net Gradient": 3000, "Box Size": 7}
+    whole = pd.DataFrame(fake_device(mov, mov.dtype, mov.shape, 7, 3000, cam))
+    seen = []
+    got = localize.localize_streamed(mov, cam, params, chunk_bytes=13 * mov[0].nbytes, progress_callback=seen.append)
+    assert FakeStage.made == 1 and seen == [13, 26, 39, 52, 65, 78, 91, 100]
+    assert len(got) == len(whole) > 20 and got.equals(whole)
+
+    class FrameOnly:
+        def __init__(self, a): self.a = a
+        def __len__(self): return len(self.a)
+        def __getitem__(self, i):
+            if not isinstance(i, (int, np.integer)):
+                raise TypeError
+            return self.a[i]
+
+    got = localize.localize_streamed(FrameOnly(mov), cam, params, chunk_bytes=40 * mov[0].nbytes, frame_bounds=(7, 61))
+    ref = whole[(whole.frame >= 7) & (whole.frame <= 61)].reset_index(drop=True)
+    assert got.equals(ref) and len(ref) > 5
+    none = localize.localize_streamed(mov, cam, params, frame_bounds=(50, 10))
+    assert len(none) == 0 and list(none.columns) == [n for n, _ in backend.LOC_COLUMNS]
+    with pytest.raises(ValueError):
+        localize.localize_streamed(mov, cam, params, fitting_method="avg")

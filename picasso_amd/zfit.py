@@ -103,6 +103,62 @@ def _fit_z(locs: pd.DataFrame, info, calibration: dict, magnification_factor: fl
     return filter_z_fits(locs, filter)
 
 
+def fit_z(locs: pd.DataFrame, info, calibration: dict, magnification_factor: float, pixelsize: float,
+          fitting_method: Literal["gausslq", "gaussmle"] = "gausslq", filter: int = 2, progress_callback=None):
+    """The older public name of ``_fit_z`` (picasso/zfit.py:294-324): same result, with the reference's notice."""
+    lib.deprecation_warning("Deprecation warning: `fit_z` will become a private function in v0.11.0. "
+                            "Please use `zfit` instead.")
+    return _fit_z(locs, info, calibration, magnification_factor, pixelsize, fitting_method, filter, progress_callback)
+
+
+def _fit_z_parallel(locs: pd.DataFrame, info, calibration: dict, magnification_factor: float, pixelsize: float,
+                    fitting_method: Literal["gausslq", "gaussmle"] = "gausslq", filter: int = 2, asynch: bool = False):
+    """picasso/zfit.py:414-462 without the process pool: the device call is the parallel form.  With ``asynch`` the
+    unfiltered result comes back as one finished future, which ``locs_from_futures`` filters like the reference."""
+    if asynch:
+        return [gausslq._DoneFuture(_fit_z(locs, info, calibration, magnification_factor, pixelsize,
+                                           fitting_method=fitting_method, filter=0))]
+    return locs_from_futures(_fit_z_parallel(locs, info, calibration, magnification_factor, pixelsize,
+                                             fitting_method, filter, asynch=True), filter=filter)
+
+
+def fit_z_parallel(locs: pd.DataFrame, info, calibration: dict, magnification_factor: float, pixelsize: float,
+                   fitting_method: Literal["gausslq", "gaussmle"] = "gausslq", filter: int = 2, asynch: bool = False):
+    """The older public name of ``_fit_z_parallel`` (picasso/zfit.py:385-411)."""
+    lib.deprecation_warning("Deprecation warning: `fit_z_parallel` will become a private function in v0.11.0. "
+                            "Please use `zfit` instead.")
+    return _fit_z_parallel(locs, info, calibration, magnification_factor, pixelsize, fitting_method, filter, asynch)
+
+
+def locs_from_futures(futures, filter: int = 2) -> pd.DataFrame:
+    """Concatenate per-task z fits and apply the residual filter once (picasso/zfit.py:648-671)."""
+    return filter_z_fits(pd.concat([f.result() for f in futures], ignore_index=True), filter)
+
+
+def axial_localization_precision_astig(locs, info, calibration: dict,
+                                       fitting_method: Literal["gausslq", "gaussmle"] = "gausslq"):
+    """lpz (nm) of already z-fitted localizations from a calibration dictionary (picasso/zfit.py:747-803)."""
+    assert fitting_method in ["gausslq", "gaussmle"], "fitting_method must be 'gausslq' or 'gaussmle'."
+    assert ("X Coefficients" in calibration and "Y Coefficients" in calibration
+            and "Magnification factor" in calibration), (
+        "Calibration dictionary must contain 'X Coefficients', 'Y Coefficients', and 'Magnification factor'.")
+    pixelsize = lib.get_from_metadata(info, "Pixelsize")
+    if pixelsize is None:
+        raise ValueError("Pixelsize not found in info.")
+    return _axial_localization_precision_astig(locs, np.array(calibration["X Coefficients"]),
+                                               np.array(calibration["Y Coefficients"]),
+                                               calibration["Magnification factor"], pixelsize, fitting_method)
+
+
+def axial_localization_precision(locs, info, calibration: dict,
+                                 fitting_method: Literal["gausslq", "gaussmle"] = "gausslq",
+                                 modality: Literal["astigmatic"] = "astigmatic"):
+    """picasso/zfit.py:706-744: dispatch on the 3D modality (astigmatism is the only one)."""
+    if modality != "astigmatic":
+        raise NotImplementedError("Currently only 'astigmatic' modality is supported.")
+    return axial_localization_precision_astig(locs, info, calibration, fitting_method)
+
+
 def zfit(locs: pd.DataFrame, info, *, calibration: dict, magnification_factor: float | None = None,
          pixelsize: int | float | None = None, fitting_method: Literal["gausslq", "gaussmle"] = "gausslq",
          filter: int = 2, multiprocess: bool = False,

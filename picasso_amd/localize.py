@@ -3,9 +3,12 @@
 Drop-in for the hot-path functions of picasso/localize.py: ``identify``
 (:639-749), ``identify_by_frame_number`` (:340-421), ``identify_in_frame``
 (:295-337), ``identify_in_image`` (:247-292), ``get_spots`` (:1115-1145),
-``fit2D`` (:1344-1506) and ``localize`` (:1682-1815) — same signatures,
+``fit2D`` (:1344-1506), ``localize`` (:1682-1815) and ``localize_3D`` (:1818-2031) — same signatures,
 defaults, return types, metadata dictionaries, assertion messages and
-abort/progress contracts.  The work is done by libpicasso_hip.so; there is no
+abort/progress contracts — plus the older names the module still exports (``fit``, ``fit_async``,
+``identify_async``, ``identifications_from_futures``, ``locs_from_fits``, ``local_maxima``) and the
+identification constructors the GUI feeds into ``get_spots`` (``picks_to_identifications``,
+``locs_to_identifications``).  The work is done by libpicasso_hip.so; there is no
 CPU path.  ``install()`` rebinds the reference package's functions to these.
 """
 from __future__ import annotations
@@ -321,6 +324,165 @@ def localize(movie, camera_info: dict, parameters: dict, *, roi=None, frame_boun
     if return_info:
         return locs, info
     return locs
+
+
+# ---------------------------------------------------------------------------
+# the remaining public names of picasso/localize.py on the path
+# ---------------------------------------------------------------------------
+def _local_maxima(frame, box: int):
+    """y, x of the pixels that are the first maximum of their box x box window (picasso/localize.py:97-134),
+    in np.where order."""
+    img = np.ascontiguousarray(frame, dtype=np.float32)[None]
+    _, y, x, _ = backend.identify_arrays(img, -np.inf, box)
+    return y.astype(np.int64), x.astype(np.int64)
+
+
+def local_maxima(frame, box: int):
+    """Older public name of ``_local_maxima`` (picasso/localize.py:84-94)."""
+    _deprecation_warning("Deprecation warning: This function will become private in v0.11.0. "
+                         "Use _local_maxima instead.")
+    return _local_maxima(frame, box)
+
+
+def identify_async(movie, minimum_ng: float, box: int, *, roi=None, frame_bounds=None):
+    """picasso/localize.py:482-560 returns a frame counter and one future per worker thread; here the device
+    call has finished when this returns: the counter stands at the last frame and the single future holds the
+    per-chunk identification frames ``identifications_from_futures`` expects."""
+    ids = identify(movie, minimum_ng, box, roi=roi, frame_bounds=frame_bounds, threaded=True, return_info=False)
+    return [len(movie)], [gausslq._DoneFuture([ids])]
+
+
+def identifications_from_futures(futures) -> pd.DataFrame:
+    """Concatenate the workers' lists of per-frame identifications, ordered by frame (picasso/localize.py:457-479)."""
+    frames = [df for f in futures for df in f.result()]
+    ids = pd.concat(frames, ignore_index=True) if frames else _empty_identifications()
+    return ids.sort_values(by="frame", kind="stable")
+
+
+def locs_from_fits(identifications: pd.DataFrame, theta, CRLBs, likelihoods, iterations, box: int) -> pd.DataFrame:
+    """The older 12-column table of picasso/localize.py:1281-1341 (columns ``likelihood`` and int32
+    ``iterations``; theta is read as (y, x, photons, bg, sy, sx) and no box offset is subtracted).  The
+    current builder is ``gaussmle.locs_from_fits``."""
+    idf = identifications
+    y = theta[:, 0] + idf["y"].to_numpy()
+    x = theta[:, 1] + idf["x"].to_numpy()
+    locs = pd.DataFrame({
+        "frame": idf["frame"].to_numpy().astype(np.uint32), "x": x.astype(np.float32), "y": y.astype(np.float32),
+        "photons": theta[:, 2].astype(np.float32), "sx": theta[:, 5].astype(np.float32),
+        "sy": theta[:, 4].astype(np.float32), "bg": theta[:, 3].astype(np.float32),
+        "lpx": np.sqrt(CRLBs[:, 1]).astype(np.float32), "lpy": np.sqrt(CRLBs[:, 0]).astype(np.float32),
+        "net_gradient": idf["net_gradient"].to_numpy().astype(np.float32),
+        "likelihood": np.asarray(likelihoods).astype(np.float32), "iterations": np.asarray(iterations).astype(np.int32)})
+    return locs.sort_values(by="frame", kind="stable")
+
+
+def fit(movie, camera_info: dict, identifications: pd.DataFrame, box: int, eps: float = 0.001, max_it: int = 100,
+        method: Literal["sigma", "sigmaxy"] = "sigmaxy") -> pd.DataFrame:
+    """Older MLE entry point (picasso/localize.py:1148-1211): spots -> gaussmle -> ``locs_from_fits``.  (At the
+    reference's HEAD the call into ``locs_from_fits`` drops the CRLB argument and raises; this passes all six.)"""
+    _deprecation_warning("Deprecation warning: this function will be removed in v0.11.0. Use localize.fit2D instead.")
+    spots = get_spots(movie, identifications, box, camera_info)
+    theta, CRLBs, likelihoods, iterations = gaussmle.gaussmle(spots, eps, max_it, method=method)
+    return locs_from_fits(identifications, theta, CRLBs, likelihoods, iterations, box)
+
+
+def fit_async(movie, camera_info: dict, identifications: pd.DataFrame, box: int, eps: float = 0.001,
+              max_it: int = 100, method: Literal["sigma", "sigmaxy"] = "sigmaxy"):
+    """picasso/localize.py:1214-1278: the counter and result arrays of ``gaussmle.gaussmle_async``."""
+    _deprecation_warning("Deprecation warning: this function will be removed in v0.11.0. Use localize.fit2D instead.")
+    spots = get_spots(movie, identifications, box, camera_info)
+    return gaussmle.gaussmle_async(spots, eps, max_it, method=method)
+
+
+def _ids_around(frames, xs, ys, n_ids) -> pd.DataFrame:
+    """frame / x / y / net_gradient (the dummy 101) / n_id, all float64 as the reference builds them from a
+    float array, ordered by frame."""
+    ids = pd.DataFrame({"frame": np.asarray(frames, float), "x": np.asarray(xs, float), "y": np.asarray(ys, float),
+                        "net_gradient": np.full(len(frames), 101.0), "n_id": np.asarray(n_ids, float)})
+    return ids.sort_values(by="frame", kind="stable")
+
+
+def picks_to_identifications(picks, *, n_frames: int | None = None, drift: pd.DataFrame | None = None) -> pd.DataFrame:
+    """Circular picks -> one identification per pick and frame, following the drift when given
+    (picasso/localize.py:752-854); n_id counts picks from 1."""
+    assert isinstance(picks, (list, tuple)), "picks must be a list or a tuple."
+    assert all([len(_) == 2 for _ in picks]), (
+        "Circular picks are required. Each element in 'picks' must contain two numbers (x and y coordinates).")
+    if isinstance(drift, pd.DataFrame):
+        assert all(col in drift.columns for col in ["x", "y"]), "Drift data frame must contain 'x' and 'y' columns."
+    if n_frames is None:
+        if drift is None:
+            raise ValueError("n_frames must be given if no drift file is provided")
+        n_frames = len(drift)
+    else:
+        assert isinstance(n_frames, int), "n_frames must be an integer."
+        if drift is not None:
+            assert n_frames == len(drift), (
+                f"{n_frames} frames were provided but the drift suggests {len(drift)} frames.")
+    n_picks = len(picks)
+    centres = np.asarray(picks, float).reshape(n_picks, 2)
+    dx = drift["x"].to_numpy() if drift is not None else np.zeros(n_frames)
+    dy = drift["y"].to_numpy() if drift is not None else np.zeros(n_frames)
+    frames = np.tile(np.arange(n_frames), n_picks)
+    xs = (centres[:, :1] + dx[None, :]).ravel()
+    ys = (centres[:, 1:] + dy[None, :]).ravel()
+    return _ids_around(frames, xs, ys, np.repeat(np.arange(n_picks) + 1.0, n_frames))
+
+
+def locs_to_identifications(locs: pd.DataFrame, movie_info, n_frames: int) -> pd.DataFrame:
+    """Each localization -> identifications at its position over the 2 n_frames + 1 frames around it
+    (picasso/localize.py:857-913); localizations closer than n_frames to either end are skipped but still
+    counted in n_id."""
+    assert isinstance(locs, pd.DataFrame), "Localizations must be a pandas data frame"
+    assert isinstance(n_frames, int) and n_frames >= 0, "n_frames must be a non-negative integer"
+    max_frames = lib.get_from_metadata(movie_info, "Frames", raise_error=True)
+    f = locs["frame"].to_numpy().astype(float)
+    keep = np.nonzero((f > n_frames) & (f < max_frames - n_frames))[0]
+    span = np.arange(-n_frames, n_frames + 1, dtype=float)
+    frames = (f[keep, None] + span[None, :]).ravel()
+    k = len(span)
+    return _ids_around(frames, np.repeat(locs["x"].to_numpy().astype(float)[keep], k),
+                       np.repeat(locs["y"].to_numpy().astype(float)[keep], k), np.repeat(keep + 1.0, k))
+
+
+def localize_3D(movie, *, movie_info, camera_info: dict, box: int, minimum_ng: float, calibration_3d,
+                roi=None, frame_bounds=None, fitting_method: Literal["gausslq", "gausslq-gpu", "gaussmle"] = "gausslq",
+                eps: float = 0.001, max_it: int = 100, mle_method: Literal["sigma", "sigmaxy"] = "sigmaxy",
+                multiprocess: bool = True, identification_progress_callback=None, fit_progress_callback=None,
+                fit_z_progress_callback=None):
+    """2D localization followed by the astigmatic z fit (picasso/localize.py:1818-1975) -> (locs, info)."""
+    assert isinstance(movie, np.ndarray) or _accepted_movie(movie), "movie must be a numpy array or ND2Movie"
+    assert isinstance(movie_info, list), "movie_info must be a list"
+    assert isinstance(camera_info, dict), "camera_info must be a dict"
+    assert isinstance(box, int) and box > 0 and box % 2 == 1, "box must be a positive odd integer"
+    assert isinstance(minimum_ng, (int, float)), "minimum_ng must be a number"
+    assert isinstance(calibration_3d, (dict, str)), "calibration_3d must be a dict or a path to a YAML file"
+    assert fitting_method in ["gausslq", "gausslq-gpu", "gaussmle"], (
+        "fitting_method must be one of 'gausslq', 'gausslq-gpu', or 'gaussmle'")
+    assert isinstance(eps, (int, float)) and eps > 0, "eps must be a positive number"
+    assert isinstance(max_it, int) and max_it > 0, "max_it must be a positive integer"
+    assert mle_method in ["sigma", "sigmaxy"], "mle_method must be 'sigma' or 'sigmaxy'"
+    assert isinstance(multiprocess, bool), "multiprocess must be a boolean"
+    return _localize_3D(movie, movie_info=movie_info, camera_info=camera_info, box=box, minimum_ng=minimum_ng,
+                        calibration_3d=calibration_3d, roi=roi, frame_bounds=frame_bounds,
+                        fitting_method=fitting_method, eps=eps, max_it=max_it, mle_method=mle_method,
+                        multiprocess=multiprocess, identification_progress_callback=identification_progress_callback,
+                        fit_progress_callback=fit_progress_callback, fit_z_progress_callback=fit_z_progress_callback)
+
+
+def _localize_3D(movie, *, movie_info, camera_info, box, minimum_ng, calibration_3d, roi=None, frame_bounds=None,
+                 fitting_method="gausslq", eps=0.001, max_it=100, mle_method="sigmaxy", multiprocess=True,
+                 identification_progress_callback=None, fit_progress_callback=None, fit_z_progress_callback=None):
+    """picasso/localize.py:1977-2031."""
+    from . import zfit
+    locs, info = localize(movie, camera_info, {"Min. Net Gradient": minimum_ng, "Box Size": box}, roi=roi,
+                          frame_bounds=frame_bounds, movie_info=movie_info, fitting_method=fitting_method, eps=eps,
+                          max_it=max_it, mle_method=mle_method, threaded=multiprocess,
+                          identification_progress_callback=identification_progress_callback,
+                          fit_progress_callback=fit_progress_callback, return_info=True)
+    method_3d = "gausslq" if fitting_method in ["gausslq", "gausslq-gpu"] else "gaussmle"
+    return zfit.zfit(locs=locs, info=info, calibration=calibration_3d, fitting_method=method_3d, filter=0,
+                     multiprocess=multiprocess, progress_callback=fit_z_progress_callback)
 
 
 def localize_resident(movie: np.ndarray, camera_info: dict, parameters: dict, *, roi=None, frame_bounds=None,

@@ -263,3 +263,49 @@ def test_localize_streamed_chunking_logic(monkeypatch, testdata_movie):
     assert len(none) == 0 and list(none.columns) == [n for n, _ in backend.LOC_COLUMNS]
     with pytest.raises(ValueError):
         localize.localize_streamed(mov, cam, params, fitting_method="avg")
+
+
+def test_picks_and_locs_to_identifications_match_reference():
+    """Host-side table constructors (picasso/localize.py:752-913) against the reference's output
+    (tests/golden/make_goldens_surface.py); rows of one frame are compared as a set (the reference's
+    sort is not stable)."""
+    g = golden("surface_cases")
+    picks = [tuple(p) for p in g["picks"]]
+    drift = pd.DataFrame({"x": g["drift_x"], "y": g["drift_y"]})
+    cols = ["frame", "x", "y", "net_gradient", "n_id"]
+
+    def same(df, tag):
+        assert list(df.columns) == cols and all(df[c].dtype == np.float64 for c in cols)
+        a = np.stack([df[c].to_numpy() for c in cols], 1)
+        b = np.stack([g[f"{tag}_{c}"] for c in cols], 1)
+        assert a.shape == b.shape and np.all(np.diff(a[:, 0]) >= 0)
+        assert np.array_equal(a[np.lexsort(a.T[::-1])], b[np.lexsort(b.T[::-1])])
+
+    same(localize.picks_to_identifications(picks, n_frames=9), "picks_plain")
+    same(localize.picks_to_identifications(picks, drift=drift), "picks_drift")
+    same(localize.picks_to_identifications(picks, n_frames=17, drift=drift), "picks_drift")
+    with pytest.raises(ValueError):
+        localize.picks_to_identifications(picks)
+    with pytest.raises(AssertionError):
+        localize.picks_to_identifications(picks, n_frames=5, drift=drift)
+    with pytest.raises(AssertionError):
+        localize.picks_to_identifications([(1, 2, 3)], n_frames=5)
+    locs = pd.DataFrame({c: g[f"l2i_in_{c}"] for c in ("frame", "x", "y")})
+    same(localize.locs_to_identifications(locs, [{"Frames": 60}], 4), "l2i")
+    with pytest.raises(AssertionError):
+        localize.locs_to_identifications(locs, [{"Frames": 60}], -1)
+
+
+def test_older_locs_from_fits_and_futures_collation():
+    g = golden("surface_cases")
+    ids = pd.DataFrame({c: g[f"lff_ids_{c}"] for c in ("frame", "x", "y", "net_gradient")})
+    t = localize.locs_from_fits(ids, g["lff_theta"], g["lff_crlb"], g["lff_ll"], g["lff_it"], 7)
+    assert list(t.columns) == list(g["lff_columns"]) and t["iterations"].dtype == np.int32 and t["frame"].dtype == np.uint32
+    order = np.argsort(g["lff_frame"], kind="stable")          # input frames were sorted: the table is in input order
+    for c in t.columns:
+        assert t[c].dtype == g[f"lff_{c}"].dtype
+        assert np.array_equal(t[c].to_numpy(), g[f"lff_{c}"][order]), c
+    parts = [ids.iloc[20:], ids.iloc[:20]]
+    got = localize.identifications_from_futures([localize.gausslq._DoneFuture(parts[:1]), localize.gausslq._DoneFuture(parts[1:])])
+    assert np.all(np.diff(got["frame"].to_numpy()) >= 0) and len(got) == len(ids)
+    assert sorted(map(tuple, got.to_numpy().tolist())) == sorted(map(tuple, ids.to_numpy().tolist()))

@@ -67,3 +67,27 @@ def _render_gaussian_iso(locs, oversampling, y_min, x_min, y_max, x_max, min_blu
     return backend.render_arrays(locs["x"].to_numpy(), locs["y"].to_numpy(), oversampling, y_min, x_min, y_max, x_max,
                                  lpx=locs["lpx"].to_numpy(), lpy=locs["lpy"].to_numpy(), min_blur_width=min_blur_width,
                                  iso=True)
+
+
+def _older_name(name: str) -> None:
+    lib.deprecation_warning(f"Deprecation warning: the '{name}' function is deprecated and will be removed in "
+                            f"v0.11.0. Use _{name} instead if necessary.")
+
+
+def render_hist(locs, oversampling, y_min, x_min, y_max, x_max, ang=None):
+    """Older public name of ``_render_hist`` (picasso/render.py:776-795)."""
+    _older_name("render_hist")
+    return _render_hist(locs, oversampling, y_min, x_min, y_max, x_max, ang=ang)
+
+
+def render_gaussian(locs, oversampling, y_min, x_min, y_max, x_max, min_blur_width, ang=None):
+    """Older public name of ``_render_gaussian`` (picasso/render.py:990-1017) — the call BASELINE.json's
+    config 3 is quoted on."""
+    _older_name("render_gaussian")
+    return _render_gaussian(locs, oversampling, y_min, x_min, y_max, x_max, min_blur_width, ang=ang)
+
+
+def render_gaussian_iso(locs, oversampling, y_min, x_min, y_max, x_max, min_blur_width, ang=None):
+    """Older public name of ``_render_gaussian_iso`` (picasso/render.py:1118-1145)."""
+    _older_name("render_gaussian_iso")
+    return _render_gaussian_iso(locs, oversampling, y_min, x_min, y_max, x_max, min_blur_width, ang=ang)

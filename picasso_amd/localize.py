@@ -599,9 +599,22 @@ def localize_file(path: str, camera_info: dict, parameters: dict, *, fitting_met
     return out
 
 
-def install(picasso_localize=None, picasso_gaussmle=None, picasso_gausslq=None) -> None:
+def _reference_module(given, name: str):
+    if given is not None:
+        return given
+    try:
+        import importlib
+        return importlib.import_module("picasso." + name)
+    except ImportError:
+        return None
+
+
+def install(picasso_localize=None, picasso_gaussmle=None, picasso_gausslq=None, picasso_zfit=None,
+            picasso_render=None, picasso_imageprocess=None, picasso_postprocess=None) -> None:
     """Rebind the reference package's hot-path functions to this backend, so that
-    picasso.__main__ and the GUI run on the GPU unchanged."""
+    picasso.__main__ and the GUI run on the GPU unchanged.  Modules not given are taken
+    from the installed ``picasso`` package; the rows next to the path (z fit, render, RCC undrift) are rebound
+    when their module is available.  Rotated renders keep going to the reference's own functions."""
     if picasso_localize is None:
         import picasso.localize as picasso_localize       # the installed reference
     if picasso_gaussmle is None:
@@ -622,3 +635,34 @@ def install(picasso_localize=None, picasso_gaussmle=None, picasso_gausslq=None) 
     if picasso_gausslq is not None:
         for name in ("fit_spot", "fit_spots", "fit_spots_parallel", "fits_from_futures"):
             setattr(picasso_gausslq, name, getattr(gausslq, name))
+    picasso_zfit = _reference_module(picasso_zfit, "zfit")
+    if picasso_zfit is not None:
+        from . import zfit as amd_zfit
+        for name in ("_fit_z", "_fit_z_parallel", "locs_from_futures"):
+            setattr(picasso_zfit, name, getattr(amd_zfit, name))
+    picasso_render = _reference_module(picasso_render, "render")
+    if picasso_render is not None:
+        from . import render as amd_render
+
+        def unrotated(mine, theirs):
+            def call(locs, oversampling, y_min, x_min, y_max, x_max, *rest, **kw):
+                n_blur = 1 if mine is not amd_render._render_hist else 0
+                ang = kw.get("ang", rest[n_blur] if len(rest) > n_blur else None)
+                if ang is not None and theirs is not None:
+                    return theirs(locs, oversampling, y_min, x_min, y_max, x_max, *rest, **kw)
+                return mine(locs, oversampling, y_min, x_min, y_max, x_max, *rest, **kw)
+            call.__name__ = mine.__name__
+            return call
+
+        for name in ("_render_hist", "_render_gaussian", "_render_gaussian_iso"):
+            setattr(picasso_render, name, unrotated(getattr(amd_render, name), getattr(picasso_render, name, None)))
+    picasso_imageprocess = _reference_module(picasso_imageprocess, "imageprocess")
+    if picasso_imageprocess is not None:
+        from . import imageprocess as amd_ip
+        for name in ("xcorr", "get_image_shift", "rcc"):
+            setattr(picasso_imageprocess, name, getattr(amd_ip, name))
+    picasso_postprocess = _reference_module(picasso_postprocess, "postprocess")
+    if picasso_postprocess is not None:
+        from . import postprocess as amd_pp
+        for name in ("segment", "undrift"):
+            setattr(picasso_postprocess, name, getattr(amd_pp, name))

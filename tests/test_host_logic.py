@@ -205,6 +205,20 @@ def test_install_rebinds_the_reference_functions():
     assert pl._fit2d_gaussmle is localize._fit2d_gaussmle and pl._fit2d_gausslq is localize._fit2d_gausslq
     assert pm.gaussmle is amd_mle.gaussmle and pm.gaussmle_async is amd_mle.gaussmle_async
     assert pq.fit_spots is gausslq.fit_spots and pq.fit_spots_parallel is gausslq.fit_spots_parallel
+    # the rows next to the path: z fit, render (rotated views stay with the reference), RCC undrift
+    from picasso_amd import imageprocess, postprocess, render, zfit
+    calls = []
+    pz, pi, pp = types.SimpleNamespace(), types.SimpleNamespace(), types.SimpleNamespace()
+    pr = types.SimpleNamespace(_render_gaussian=lambda *a, **k: calls.append(("theirs", a, k)) or (0, None),
+                               _render_hist=lambda *a, **k: calls.append(("theirs_hist", a, k)) or (0, None))
+    localize.install(pl, pm, pq, pz, pr, pi, pp)
+    assert pz._fit_z is zfit._fit_z and pi.rcc is imageprocess.rcc and pp.undrift is postprocess.undrift
+    assert pr._render_gaussian("L", 1, 0, 0, 8, 8, 0.0, ang=(0.1, 0, 0))[0] == 0 and calls[-1][0] == "theirs"
+    assert pr._render_gaussian("L", 1, 0, 0, 8, 8, 0.0, (0.1, 0, 0))[0] == 0 and len(calls) == 2
+    assert pr._render_hist("L", 1, 0, 0, 8, 8, (0.1, 0, 0))[0] == 0 and calls[-1][0] == "theirs_hist"
+    with pytest.raises(Exception):          # unrotated: ours, which needs the device (and a DataFrame)
+        pr._render_gaussian("L", 1, 0, 0, 8, 8, 0.0)
+    assert len(calls) == 3
 
 
 def test_localize_streamed_chunking_logic(monkeypatch, testdata_movie):

@@ -5,8 +5,8 @@
 // the residual vector is float32), gtol = 0, factor = 100, maxfev = 1400, on the
 // residuals of a point-sampled elliptical Gaussian whose model is stored in
 // float32 (gausslq.py:151-203).  This file restates that algorithm for one group of lanes
-// per spot — a 16-lane DPP row for boxes up to 7x7 (four spots per wavefront), the whole
-// wavefront for larger boxes:
+// per spot — a 16-lane DPP row for boxes up to 7x7 (four spots per wavefront), half a wavefront
+// for boxes 9..15 (two spots), the whole wavefront for larger boxes:
 //
 //   - residual row r = i*size + j lives in lane r % GS, element r / GS, so the
 //     m x 6 Jacobian is six register columns per lane; column norms and the
@@ -19,6 +19,7 @@
 // the difference is in the last bits of float64 and disappears in the float32 theta
 // except when it flips a float32 rounding of the stored model.
 #include <algorithm>
+#include <cstdlib>
 
 #include "fit_common.h"
 
@@ -102,6 +103,32 @@ template <> struct Grp<16> {
     {
         const unsigned long long b = __builtin_amdgcn_ballot_w64(c);
         return ((b >> ((threadIdx.x & 63u) & ~15u)) & 0xffffull) != 0;
+    }
+};
+template <> struct Grp<32> {          // half a wavefront: two DPP rows, the partner row through bpermute
+    static __device__ __forceinline__ double sum_d(double v)
+    {
+        v = Grp<16>::sum_d(v);
+        return v + __shfl_xor(v, 16);
+    }
+    static __device__ __forceinline__ double max_d(double v)
+    {
+        for (int off = 16; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+        return v;
+    }
+    static __device__ __forceinline__ float min_f(float v)
+    {
+        for (int off = 16; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+        return v;
+    }
+    static __device__ __forceinline__ double bcast_d(double v, int k)
+    {
+        return __shfl(v, (int)((threadIdx.x & 63u) & ~31u) + k);
+    }
+    static __device__ __forceinline__ bool any(bool c)
+    {
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(c);
+        return ((b >> ((threadIdx.x & 63u) & ~31u)) & 0xffffffffull) != 0;
     }
 };
 // Indexing a 6-vector by a run-time (wave-uniform) index without leaving registers.
@@ -219,7 +246,7 @@ __device__ __forceinline__ void residuals(const double (&th)[6], const float (&s
     const float prof = (float)(nrm * exp(-0.5 * (t * t)));
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int gbase = GS == 64 ? 0 : (int)((threadIdx.x & 63u) & ~15u);     // first lane of this group
+        const int gbase = GS == 64 ? 0 : (int)((threadIdx.x & 63u) & ~(unsigned)(GS - 1));     // first lane of this group
         const float mxv = __shfl(prof, gbase + rj[e]);
         const float myv = __shfl(prof, gbase + size + ri[e]);
         const float model = (float)(th[2] * (double)myv * (double)mxv + th[3]);
@@ -451,7 +478,7 @@ template <int GS, int E, bool FROM_MOVIE>
 __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_fit_kernel(Params p)
 {
     constexpr int NGRP = 64 / GS;                              // spots per wavefront
-    __shared__ double s_R[GS == 16 ? LQ_WAVES * NGRP * 36 : 1];
+    __shared__ double s_R[GS < 64 ? LQ_WAVES * NGRP * 36 : 1];
     const int lane = (threadIdx.x & 63) % GS;                  // lane inside the group
     const int grp = (threadIdx.x & 63) / GS;
     const int64_t wave0 = (int64_t)blockIdx.x * LQ_WAVES + (threadIdx.x >> 6);
@@ -538,7 +565,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_fit_kernel(Par
         // the 6x6 factor: LDS for the 16-lane groups (frees 72 registers of a kernel capped at 256 for two
         // waves per SIMD; every lane of the group writes the same values), registers for whole-wave groups
         double R_regs[36];
-        double *R = GS == 16 ? s_R + (size_t)((threadIdx.x >> 6) * NGRP + grp) * 36 : R_regs;
+        double *R = GS < 64 ? s_R + (size_t)((threadIdx.x >> 6) * NGRP + grp) * 36 : R_regs;
         double diag[6], qtf[6], wa1[6], wa2[6], wa3[6];
         int ipvt[6];
         int info = 0, nfev = 1, iter = 1;
@@ -704,6 +731,15 @@ static int launch(const Params &p, hipStream_t s)
         if (m <= 16) hipLaunchKernelGGL((lq_fit_kernel<16, 1, FROM_MOVIE>), grid, block, 0, s, p);
         else if (m <= 32) hipLaunchKernelGGL((lq_fit_kernel<16, 2, FROM_MOVIE>), grid, block, 0, s, p);
         else hipLaunchKernelGGL((lq_fit_kernel<16, 4, FROM_MOVIE>), grid, block, 0, s, p);
+    } else if (p.box <= 15 && !getenv("PMI_LQ_WAVE_PER_SPOT")) {
+        // two spots per wavefront (2 * box <= 32 profile lanes): the 6x6 stage, which costs a wavefront the same
+        // whatever the group size, is shared by two fits
+        const int64_t waves = (p.N + 1) / 2;
+        dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
+        if (m <= 96) hipLaunchKernelGGL((lq_fit_kernel<32, 3, FROM_MOVIE>), grid, block, 0, s, p);
+        else if (m <= 128) hipLaunchKernelGGL((lq_fit_kernel<32, 4, FROM_MOVIE>), grid, block, 0, s, p);
+        else if (m <= 192) hipLaunchKernelGGL((lq_fit_kernel<32, 6, FROM_MOVIE>), grid, block, 0, s, p);
+        else hipLaunchKernelGGL((lq_fit_kernel<32, 8, FROM_MOVIE>), grid, block, 0, s, p);
     } else {
         const int e = (m + 63) / 64;
         dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((p.N + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));

@@ -269,7 +269,7 @@ def test_gausslq_vs_oracle_and_goldens(be, orc, name):
 @pytest.mark.parametrize("box", [3, 5, 7, 9, 11, 13, 15, 17, 19, 21])
 def test_gausslq_all_boxes_vs_oracle(be, orc, box):
     rng = np.random.default_rng(100 + box)
-    n, c = 128, box // 2
+    n, c = 127, box // 2          # odd: the last wavefront has an unpaired group
     idx = np.arange(box) - c
     spots = np.empty((n, box, box), np.float32)
     for i in range(n):

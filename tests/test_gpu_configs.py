@@ -1,10 +1,10 @@
 """GPU tier: the workloads BASELINE.json names, end to end.
 
-config 2 at FULL size (10k frames, 512x512, ~1e6 spots) through size-independent properties:
-ordering, determinism, shard consistency (frames shard without a halo), first-argmax property on a
-sample, agreement with the simulated ground truth; config 3 (gausslq + Gaussian render at
-oversampling 10) and config 5 (13x13 astigmatic MLE + zfit) against the oracle composition at sizes
-the oracle finishes in seconds.
+config 2 at FULL size (10k frames, 512x512, ~1e6 spots): every identification and every fit against the
+oracle (its C restatement runs on all host threads of the GPU box in seconds), plus size-independent
+properties — ordering, determinism, shard consistency (frames shard without a halo), agreement with the
+simulated ground truth; config 3 (gausslq + Gaussian render at oversampling 10, 2000 frames), config 4's
+geometry in miniature and config 5 (13x13 astigmatic MLE + zfit) against the oracle composition.
 """
 import ctypes
 
@@ -108,15 +108,15 @@ def test_config3_gausslq_and_render(be, orc):
     """gausslq path + Gaussian render at oversampling 10 (BASELINE.json configs[2]) vs the oracle composition."""
     import torch
     from picasso_amd import gausslq, synth
-    F = 300
+    F = 2000
     movie = synth.simulate_movie(F, 512, 512, emitters_per_frame=116, device="cuda", seed=77)
     torch.cuda.synchronize()
     t = _localize_resident(be, movie, lq=True)
     sub = movie.cpu().numpy()
-    fr, y, x, ng = orc.identify(sub, 5000.0, 7)
-    assert len(t["frame"]) == len(fr) and np.array_equal(t["net_gradient"], ng)
+    fr, y, x, ng = orc.identify(sub, 5000.0, 7, threads=orc.max_threads())
+    assert len(t["frame"]) == len(fr) > 150000 and np.array_equal(t["net_gradient"], ng)
     spots = orc.get_spots(sub, fr, y, x, 7, CAM)
-    oth = orc.gausslq(spots, threads=4)
+    oth = orc.gausslq(spots, threads=orc.max_threads())
     ref = gausslq.locs_from_fits(pd.DataFrame({"frame": fr, "x": x, "y": y, "net_gradient": ng}), oth, 7, em=False)
     ref = ref.sort_index()          # the reference's quicksort by frame is not stable; undo it (identification order)
     same = t["x"] == ref["x"].to_numpy()

@@ -20,6 +20,8 @@
  *   pmi_identify*      picasso/localize.py:639-749 identify (-> :247-292
  *                      identify_in_image, :97-134 _local_maxima, :202-244
  *                      _net_gradient, :295-337 ROI crop, :395-401 frame bounds)
+ *   pmi_net_gradient   picasso/localize.py:202-244 _net_gradient (+ :153-181
+ *                      _gradient_at) on one frame with the caller's unit vectors
  *   pmi_get_spots*     picasso/localize.py:1115-1145 get_spots (-> :917-931
  *                      _cut_spots_numba, :1101-1112 _to_photons)
  *   pmi_gaussmle*      picasso/gaussmle.py:409-475 gaussmle / :478-530
@@ -156,6 +158,16 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
                          double baseline, double sensitivity, double gain,
                          double eps, int max_it, int method,
                          void *d_table, int64_t cap, int64_t *d_out_n, void *stream);
+
+/* ---- net gradient at given pixels (picasso/localize.py:202-244 _net_gradient) ---- *
+ * image: one (Y, X) float32 frame; y, x: n pixel positions; uy, ux: (box, box)
+ * float32 unit-vector tables (the centre entry is not read).  out_ng[i] = sum over
+ * the box x box window around (y, x), centre excluded, of gy*uy + gx*ux with
+ * central differences, accumulated in float32 in the reference's order.  Index -1
+ * wraps to the last row / column as the reference's unchecked indexing does;
+ * positions whose window reaches past the far edge are refused.                   */
+int pmi_net_gradient(const float *image, int64_t Y, int64_t X, const int32_t *y, const int32_t *x,
+                     int64_t n, int box, const float *uy, const float *ux, float *out_ng);
 
 /* ---- gausslq (picasso/gausslq.py:206-300) ------------------------------- *
  * spots: (N, box, box) float32 photons, box odd in [3, 21].  thetas (N,6) =

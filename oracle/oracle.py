@@ -55,6 +55,8 @@ def lib():
         L.orc_gausslq_initial.argtypes = [p, i64, i32, p]
         L.orc_gausslq_from.argtypes = [p, i64, i32, p, p, i32]
         L.orc_zfit.argtypes = [p, p, i64, p, p, p, p, i32]
+        L.orc_net_gradient.argtypes = [p, i64, i64, p, p, i64, i32, p, p, p]
+        L.orc_net_gradient.restype = i32
         L.orc_max_threads.restype = i32
         _lib = L
     return _lib
@@ -155,6 +157,19 @@ def unit_vectors(box):
     ux = np.zeros((box, box), np.float32); uy = np.zeros((box, box), np.float32)
     lib().orc_unit_vectors(int(box), _ptr(ux), _ptr(uy))
     return ux, uy
+
+
+def net_gradient(frame, y, x, box, uy, ux):
+    """picasso/localize.py:202-244 on one float32 frame -> float32 (len(y),)."""
+    img = np.ascontiguousarray(frame, np.float32)
+    y = np.ascontiguousarray(y, np.int32); x = np.ascontiguousarray(x, np.int32)
+    uy = np.ascontiguousarray(uy, np.float32); ux = np.ascontiguousarray(ux, np.float32)
+    out = np.zeros(len(y), np.float32)
+    rc = lib().orc_net_gradient(_ptr(img), img.shape[0], img.shape[1], _ptr(y), _ptr(x), len(y), int(box),
+                                _ptr(uy), _ptr(ux), _ptr(out))
+    if rc:
+        raise ValueError("net_gradient: a window reaches past the far edge of the image")
+    return out
 
 
 def avgroi(spots):

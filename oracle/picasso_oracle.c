@@ -136,6 +136,37 @@ static int64_t identify_image(const float *img, int Y, int X, int box, double mi
     return n;
 }
 
+/* _net_gradient as a function of its own (picasso/localize.py:202-244): n pixels of one float32 image,
+ * caller-supplied unit vectors; every index expression wraps on its own when negative, like numba's
+ * unchecked indexing.  Returns 1 if a window would reach past the far edge (undefined in the reference). */
+int orc_net_gradient(const float *img, int64_t Y, int64_t X, const int32_t *py, const int32_t *px, int64_t n, int box,
+                     const float *uy, const float *ux, float *out)
+{
+    int h = box / 2;
+    for (int64_t i = 0; i < n; i++) {
+        int yi = py[i], xi = px[i];
+        if (yi + h + 1 >= Y || xi + h + 1 >= X || yi - h - 1 < -Y || xi - h - 1 < -X) return 1;
+        float ng = 0.0f;
+        for (int kk = 0; kk < box; kk++) {
+            int k = yi - h + kk;
+            for (int ll = 0; ll < box; ll++) {
+                int m = xi - h + ll;
+                if (k == yi && m == xi) continue;
+#define ORC_WRAP(v, N) ((v) < 0 ? (v) + (N) : (v))
+                float gy = img[ORC_WRAP(k + 1, Y) * X + ORC_WRAP(m, X)] - img[ORC_WRAP(k - 1, Y) * X + ORC_WRAP(m, X)];
+                float gx = img[ORC_WRAP(k, Y) * X + ORC_WRAP(m + 1, X)] - img[ORC_WRAP(k, Y) * X + ORC_WRAP(m - 1, X)];
+#undef ORC_WRAP
+                float t1 = gy * uy[kk * box + ll];
+                float t2 = gx * ux[kk * box + ll];
+                float s = t1 + t2;
+                ng = ng + s;
+            }
+        }
+        out[i] = ng;
+    }
+    return 0;
+}
+
 /* Whole movie.  roi = {y0, x0, y1, x1} (already normalised to the frame) or
  * NULL.  Frames outside [f_lo, f_hi] (inclusive, localize.py:401) are
  * skipped.  Output is ordered by frame, then y, then x.  Returns 0, or 1 if

@@ -45,6 +45,7 @@ SYMBOLS = {
     "pmi_release_scratch": (_i32, []),
     "pmi_identify": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
     "pmi_identify_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _p]),
+    "pmi_net_gradient": (_i32, [_p, _i64, _i64, _p, _p, _i64, _i32, _p, _p, _p]),
     "pmi_get_spots": (_i32, [_p, _i32, _i64, _i64, _i64, _p, _p, _p, _i64, _i32, _f64, _f64, _f64, _p]),
     "pmi_get_spots_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _p, _p, _p, _i64, _p, _i32, _f64, _f64, _f64, _p, _p]),
     "pmi_gaussmle": (_i32, [_p, _i64, _i32, _f64, _i32, _i32, _p, _p, _p, _p]),

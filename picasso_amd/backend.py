@@ -96,6 +96,26 @@ def identify_arrays(movie: np.ndarray, min_ng: float, box: int, roi=None, frame_
         return fr[:k].copy(), yy[:k].copy(), xx[:k].copy(), ng[:k].copy()
 
 
+def net_gradient_array(image, y, x, box: int, uy, ux) -> np.ndarray:
+    """float32 net gradient at the given pixels of one image (pmi_net_gradient)."""
+    _lib.require_gpu()
+    img = np.ascontiguousarray(image, np.float32)
+    if img.ndim != 2:
+        raise ValueError("image must be 2-D")
+    y = np.ascontiguousarray(y, np.int32)
+    x = np.ascontiguousarray(x, np.int32)
+    uy = np.ascontiguousarray(uy, np.float32)
+    ux = np.ascontiguousarray(ux, np.float32)
+    if uy.shape != (box, box) or ux.shape != (box, box) or len(y) != len(x):
+        raise ValueError("uy, ux must have shape (box, box) and y, x the same length")
+    out = np.zeros(len(y), np.float32)
+    with _lib.lock():
+        rc = _lib.load().pmi_net_gradient(_lib.ptr(img), img.shape[0], img.shape[1], _lib.ptr(y), _lib.ptr(x), len(y),
+                                          int(box), _lib.ptr(uy), _lib.ptr(ux), _lib.ptr(out))
+    _lib.check(rc, "pmi_net_gradient")
+    return out
+
+
 def get_spots_array(movie: np.ndarray, frame, y, x, box: int, baseline, sensitivity, gain) -> np.ndarray:
     _lib.require_gpu()
     movie = as_movie_array(movie)

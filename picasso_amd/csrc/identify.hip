@@ -438,6 +438,36 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
     return PMI_OK;
 }
 
+// Net gradient at given pixels of one float32 image with caller-supplied unit vectors
+// (picasso/localize.py:202-244 _net_gradient, :153-181 _gradient_at): float32 accumulator, window rows
+// then columns, centre skipped, one rounding per operation; row / column -1 wraps to the last one.
+__global__ __launch_bounds__(256) void net_gradient_kernel(const float *__restrict__ img, int Y, int X,
+                                                           const int32_t *__restrict__ py, const int32_t *__restrict__ px,
+                                                           int64_t n, int box, const float *__restrict__ uy,
+                                                           const float *__restrict__ ux, float *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const int h = box / 2, yi = py[i], xi = px[i];
+    float ng = 0.0f;
+    for (int kk = 0; kk < box; kk++) {
+        const int k = yi - h + kk;
+        for (int ll = 0; ll < box; ll++) {
+            const int m = xi - h + ll;
+            if (k == yi && m == xi) continue;
+            auto wrap = [](int v, int N) { return v < 0 ? v + N : v; };      // each index wraps on its own
+            const int kw = wrap(k, Y), mw = wrap(m, X);
+            const float gy = img[(int64_t)wrap(k + 1, Y) * X + mw] - img[(int64_t)wrap(k - 1, Y) * X + mw];
+            const float gx = img[(int64_t)kw * X + wrap(m + 1, X)] - img[(int64_t)kw * X + wrap(m - 1, X)];
+            const float t1 = gy * uy[kk * box + ll];
+            const float t2 = gx * ux[kk * box + ll];
+            const float sum = t1 + t2;
+            ng = ng + sum;
+        }
+    }
+    out[i] = ng;
+}
+
 }  // namespace pmi
 
 extern "C" {
@@ -504,6 +534,42 @@ int pmi_identify(const void *movie, int dtype, int64_t F, int64_t Y, int64_t X, 
     }
     *out_n = total;
     if (overflow) { set_error("identify: capacity %lld too small, %lld rows needed", (long long)cap, (long long)total); return PMI_ERR_CAPACITY; }
+    return PMI_OK;
+}
+
+
+int pmi_net_gradient(const float *image, int64_t Y, int64_t X, const int32_t *y, const int32_t *x, int64_t n, int box,
+                     const float *uy, const float *ux, float *out_ng)
+{
+    using namespace pmi;
+    if (pmi_device_count() < 1) { set_error("no HIP device"); return PMI_ERR_NODEVICE; }
+    if (n < 0 || (n > 0 && (!image || !y || !x || !uy || !ux || !out_ng))) { set_error("null pointer"); return PMI_ERR_ARG; }
+    if (box < 1 || box > PMI_MAX_BOX || (box & 1) == 0) { set_error("box must be odd in [1, %d], got %d", PMI_MAX_BOX, box); return PMI_ERR_ARG; }
+    if (n == 0) return PMI_OK;
+    const int h = box / 2;
+    // what the reference's unchecked indexing can reach without leaving the array: y + h + 1 and x + h + 1 inside,
+    // y - h - 1 and x - h - 1 not below -1 ... -Y (negative indices wrap once)
+    for (int64_t i = 0; i < n; i++)
+        if (y[i] + h + 1 >= Y || x[i] + h + 1 >= X || y[i] - h - 1 < -Y || x[i] - h - 1 < -X) {
+            set_error("net_gradient: position %lld (%d, %d) reaches outside the %lld x %lld image", (long long)i, y[i], x[i], (long long)Y, (long long)X);
+            return PMI_ERR_ARG;
+        }
+    void *pa = nullptr, *pb = nullptr;
+    int rc;
+    const size_t img_bytes = (size_t)Y * X * 4, tab = (size_t)box * box * 4;
+    if ((rc = scratch(SCR_STAGE_A, img_bytes, &pa)) != PMI_OK) return rc;
+    if ((rc = scratch(SCR_STAGE_B, (size_t)n * 12 + 2 * tab + 64, &pb)) != PMI_OK) return rc;
+    int32_t *d_y = (int32_t *)pb, *d_x = d_y + n;
+    float *d_out = (float *)(d_x + n), *d_uy = d_out + n, *d_ux = d_uy + box * box;
+    PMI_HIP(hipMemcpy(pa, image, img_bytes, hipMemcpyHostToDevice));
+    PMI_HIP(hipMemcpy(d_y, y, (size_t)n * 4, hipMemcpyHostToDevice));
+    PMI_HIP(hipMemcpy(d_x, x, (size_t)n * 4, hipMemcpyHostToDevice));
+    PMI_HIP(hipMemcpy(d_uy, uy, tab, hipMemcpyHostToDevice));
+    PMI_HIP(hipMemcpy(d_ux, ux, tab, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(net_gradient_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, (const float *)pa, (int)Y,
+                       (int)X, d_y, d_x, n, box, d_uy, d_ux, d_out);
+    PMI_HIP(hipGetLastError());
+    PMI_HIP(hipMemcpy(out_ng, d_out, (size_t)n * 4, hipMemcpyDeviceToHost));
     return PMI_OK;
 }
 

@@ -6,7 +6,7 @@ Drop-in for the hot-path functions of picasso/localize.py: ``identify``
 ``fit2D`` (:1344-1506), ``localize`` (:1682-1815) and ``localize_3D`` (:1818-2031) — same signatures,
 defaults, return types, metadata dictionaries, assertion messages and
 abort/progress contracts — plus the older names the module still exports (``fit``, ``fit_async``,
-``identify_async``, ``identifications_from_futures``, ``locs_from_fits``, ``local_maxima``) and the
+``identify_async``, ``identifications_from_futures``, ``locs_from_fits``, ``local_maxima``, ``net_gradient``, ``gradient_at``) and the
 identification constructors the GUI feeds into ``get_spots`` (``picks_to_identifications``,
 ``locs_to_identifications``).  The work is done by libpicasso_hip.so; there is no
 CPU path.  ``install()`` rebinds the reference package's functions to these.
@@ -342,6 +342,32 @@ def local_maxima(frame, box: int):
     _deprecation_warning("Deprecation warning: This function will become private in v0.11.0. "
                          "Use _local_maxima instead.")
     return _local_maxima(frame, box)
+
+
+def _net_gradient(frame, y, x, box: int, uy, ux):
+    """Net gradient (float32) at pixels (y, x) of one frame with the given unit-vector tables
+    (picasso/localize.py:202-244).  The frame is taken as float32, as ``identify_in_frame`` hands it over."""
+    return backend.net_gradient_array(frame, y, x, box, uy, ux)
+
+
+def net_gradient(frame, y, x, box: int, uy, ux):
+    """Older public name of ``_net_gradient`` (picasso/localize.py:184-199)."""
+    _deprecation_warning("Deprecation warning: This function will become private in v0.11.0. "
+                         "Use _net_gradient instead.")
+    return _net_gradient(frame, y, x, box, uy, ux)
+
+
+def _gradient_at(frame, y: int, x: int, i: int = 0):
+    """Central differences (gy, gx) at one pixel (picasso/localize.py:153-181) — two subtractions in the frame's
+    own dtype, as indexing arithmetic on the host."""
+    return frame[y + 1, x] - frame[y - 1, x], frame[y, x + 1] - frame[y, x - 1]
+
+
+def gradient_at(frame, y: int, x: int, i: int = 0):
+    """Older public name of ``_gradient_at`` (picasso/localize.py:137-150)."""
+    _deprecation_warning("Deprecation warning: This function will become private in v0.11.0. "
+                         "Use _gradient_at instead.")
+    return _gradient_at(frame, y, x, i)
 
 
 def identify_async(movie, minimum_ng: float, box: int, *, roi=None, frame_bounds=None):

@@ -58,6 +58,33 @@ out["lff_columns"] = np.array(list(df.columns))
 for c in df.columns:
     out[f"lff_{c}"] = df[c].to_numpy()
 
+# _local_maxima / _net_gradient / _gradient_at on single frames, including positions whose window touches
+# row / column -1 (wraps to the last one) and a non-standard unit-vector table
+tm = np.fromfile(os.path.join(_refshim.REF, "tests", "data", "testdata.raw"), dtype="<u2").reshape(100, 32, 32)
+for tag, fidx, box in (("ng7", 12, 7), ("ng5", 40, 5), ("ng9", 77, 9)):
+    frame = np.float32(tm[fidx])
+    h = box // 2
+    my, mx = loc._local_maxima(frame, box)
+    yy = np.concatenate([my, [h, h, 20, 31 - h - 1]]).astype(np.int64)
+    xx = np.concatenate([mx, [h, 18, h, 31 - h - 1]]).astype(np.int64)
+    ux = np.zeros((box, box), np.float32); uy = np.zeros((box, box), np.float32)
+    for i in range(box):
+        val = h - i
+        ux[:, i] = val
+        uy[i, :] = val
+    with np.errstate(invalid="ignore"):
+        norm = np.sqrt(ux ** 2 + uy ** 2)
+        ux /= norm
+        uy /= norm
+    out[f"{tag}_frame"], out[f"{tag}_y"], out[f"{tag}_x"] = frame, yy, xx
+    out[f"{tag}_n_maxima"] = np.asarray(len(my))
+    out[f"{tag}_ux"], out[f"{tag}_uy"] = ux, uy
+    out[f"{tag}_ng"] = loc._net_gradient(frame, yy, xx, box, uy, ux)
+    ruy = rng.normal(0, 1, (box, box)).astype(np.float32); rux = rng.normal(0, 1, (box, box)).astype(np.float32)
+    out[f"{tag}_ruy"], out[f"{tag}_rux"] = ruy, rux
+    out[f"{tag}_rng"] = loc._net_gradient(frame, yy, xx, box, ruy, rux)
+    out[f"{tag}_grad"] = np.array([loc._gradient_at(frame, int(a), int(b), 0) for a, b in zip(yy, xx)], np.float32)
+
 # localize_3D end to end (identify + gaussmle + zfit) on the reference's test movie
 movie = np.memmap(os.path.join(_refshim.REF, "tests", "data", "testdata.raw"), dtype="<u2", mode="r", shape=(100, 32, 32))
 info = [{"Frames": 100, "Height": 32, "Width": 32, "Data Type": "uint16", "Byte Order": "<"}]

@@ -221,3 +221,20 @@ def test_render_against_goldens(case):
     n, iso = orc.render(g["x"], g["y"], osamp, vp, g["lpx"], g["lpy"], "gaussian_iso", mbw)
     assert n == int(g[case + "_n"]) and np.array_equal(iso, g[case + "_iso_numba"])
     assert np.max(np.abs(iso - g[case + "_iso_numpy"])) < 2e-4 * max(1.0, float(g[case + "_iso_numpy"].max()))
+
+
+@pytest.mark.parametrize("tag,box", [("ng7", 7), ("ng5", 5), ("ng9", 9)])
+def test_oracle_net_gradient_standalone(tag, box):
+    """orc_net_gradient against the reference's _net_gradient on single frames (local maxima plus positions whose
+    window wraps through row / column -1), with the standard and with an arbitrary unit-vector table: bit for bit."""
+    from oracle import oracle as orc
+    g = golden("surface_cases")
+    frame, y, x = g[f"{tag}_frame"], g[f"{tag}_y"], g[f"{tag}_x"]
+    assert np.array_equal(orc.net_gradient(frame, y, x, box, g[f"{tag}_uy"], g[f"{tag}_ux"]), g[f"{tag}_ng"])
+    assert np.array_equal(orc.net_gradient(frame, y, x, box, g[f"{tag}_ruy"], g[f"{tag}_rux"]), g[f"{tag}_rng"])
+    ux, uy = orc.unit_vectors(box)
+    c = box // 2
+    keep = np.ones((box, box), bool); keep[c, c] = False
+    assert np.array_equal(ux[keep], g[f"{tag}_ux"][keep]) and np.array_equal(uy[keep], g[f"{tag}_uy"][keep])
+    with pytest.raises(ValueError):
+        orc.net_gradient(frame, [31 - box // 2], [10], box, uy, ux)

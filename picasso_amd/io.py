@@ -118,3 +118,60 @@ def save_datasets(path: str, info: list[dict], **kwargs) -> None:
     """Several named tables (DataFrames or record arrays) in one file."""
     _hdf5.write(path, {k: (_to_records(v) if isinstance(v, pd.DataFrame) else np.asarray(v)) for k, v in kwargs.items()})
     save_info(_sidecar(path), info)
+
+
+# ---------------------------------------------------------------------------
+# small text / YAML formats next to the path
+# ---------------------------------------------------------------------------
+def save_drift(path: str, drift: pd.DataFrame) -> None:
+    """One line per frame, ``x y`` in camera pixels, CRLF line ends (picasso/io.py save_drift; what
+    ``picasso undrift`` writes beside the undrifted table)."""
+    np.savetxt(path, drift, newline="\r\n")
+
+
+def load_drift(path: str) -> pd.DataFrame:
+    """The table ``save_drift`` wrote -> columns x, y (and z when there is a third column)."""
+    if not path.endswith(".txt"):
+        raise ValueError("Drift file must end with .txt")
+    values = np.loadtxt(path, delimiter=" ")
+    assert values.ndim == 2 and values.shape[1] in [2, 3], (
+        "Drift must be a 2D array with 2 or 3 columns (x, y, (z)). " f"Loaded array has shape {values.shape}.")
+    return pd.DataFrame({name: values[:, i] for i, name in enumerate(["x", "y", "z"][: values.shape[1]])})
+
+
+def load_calibration(path: str) -> dict:
+    """The astigmatism calibration YAML (X / Y Coefficients, Magnification factor ...) that ``zfit.zfit`` and
+    ``localize.localize_3D`` take as a dict."""
+    with open(path, "r") as fh:
+        return yaml.full_load(fh)
+
+
+_PICK_LAYOUT = {            # shape -> (key of the positions, size key in nm, older size key in camera pixels)
+    "Circle": ("Centers", "Diameter (nm)", "Diameter"),
+    "Rectangle": ("Center-Axis-Points", "Width (nm)", "Width"),
+    "Polygon": ("Vertices", None, None),
+    "Square": ("Centers", "Side Length (nm)", None),
+}
+
+
+def load_picks(path: str, pixelsize: float | None = None):
+    """Pick regions saved by the Render GUI -> (picks, shape, size); size in camera pixels when ``pixelsize`` (nm)
+    is given and the file states nm, None for polygons.  Circular picks feed ``localize.picks_to_identifications``."""
+    assert path.endswith(".yaml"), "Picks should be stored in a .yaml file."
+    with open(path, "r") as fh:
+        regions = yaml.full_load(fh)
+    if "Shape" in regions:
+        shape = regions["Shape"]
+    elif "Centers" in regions and "Diameter" in regions:
+        shape = "Circle"                      # files from before the Shape key existed
+    else:
+        raise ValueError("Unrecognized picks file")
+    if shape not in _PICK_LAYOUT:
+        raise ValueError("Unrecognized pick shape")
+    positions, nm_key, px_key = _PICK_LAYOUT[shape]
+    size = None
+    if nm_key is not None and (nm_key in regions or px_key is None):
+        size = regions[nm_key] / (1 if pixelsize is None else pixelsize)
+    elif px_key is not None and px_key in regions:
+        size = regions[px_key]
+    return regions[positions], shape, size

@@ -599,7 +599,7 @@ def localize_file(path: str, camera_info: dict, parameters: dict, *, fitting_met
                   drift: int = 0, suffix: str = "_locs") -> str:
     """File to file, what `picasso localize movie.raw` does (picasso/__main__.py:1046-1156): read
     <name>.raw + .yaml, localize on the GPU, optionally RCC-undrift with `drift` frames per segment,
-    write <name><suffix>.hdf5 + .yaml (and <name><suffix>_undrift.hdf5).  Returns the path written last."""
+    write <name><suffix>.hdf5 + .yaml (and <name><suffix>_undrift.hdf5 + .yaml, <name><suffix>_drift.txt).  Returns the path written last."""
     import os
 
     from . import io, postprocess
@@ -618,10 +618,12 @@ def localize_file(path: str, camera_info: dict, parameters: dict, *, fitting_met
     io.save_locs(out, locs, info)
     if drift and drift > 0:
         pinfo = info if lib.get_from_metadata(info, "Pixelsize") is not None else info + [{"Pixelsize": 130}]
-        _, locs = postprocess.undrift(locs, pinfo, drift, display=False)
-        info = info + [{"Generated by": f"Picasso: v{__version__} Undrift (picasso_amd HIP backend)", "Segmentation": drift}]
+        drift_table, locs = postprocess.undrift(locs, pinfo, drift, display=False)
+        info = info + [{"Generated by": f"Picasso: v{__version__} Undrift (picasso_amd HIP backend)", "Segmentation": drift,
+                        "Drift X": float(drift_table["x"].mean()), "Drift Y": float(drift_table["y"].mean())}]
         out = base + suffix + "_undrift.hdf5"
         io.save_locs(out, locs, info)
+        io.save_drift(base + suffix + "_drift.txt", drift_table)       # as `picasso undrift` does (__main__.py:476-482)
     return out
 
 

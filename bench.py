@@ -61,6 +61,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    ndev = torch.cuda.device_count()
+    if ndev < 1:
+        raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
+    if local_rank >= ndev:
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but only {ndev} GPU(s) visible — one process per GPU")
     torch.cuda.set_device(local_rank)                # before the process group: RCCL binds to the current device
     dev = torch.device("cuda", local_rank)
     # under torch.distributed.run (even with one process) the collectives are part of the step

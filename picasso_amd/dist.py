@@ -65,17 +65,73 @@ def columns_to_table(cols: Dict[str, np.ndarray], device="cpu") -> torch.Tensor:
     return torch.from_numpy(out).to(device)
 
 
+class PipelinedTableGather:
+    """All-gather of a rank's table in pieces while the next piece is still being computed.
+
+    ``submit(table, d_n)`` is called after each frame chunk has been queued on the current stream: the padded
+    (C, cap) table and its device-side row count go out as asynchronous collectives (RCCL's own stream, ordered
+    after the kernels queued so far), so the host never waits and the next chunk's kernels overlap the transfer.
+    Every rank must submit the same number of pieces with the same capacities.  ``finish()`` waits for the
+    collectives and returns the (C, total) table ordered by rank, then piece — i.e. by frame for contiguous frame
+    shards — or None when some piece overflowed its capacity anywhere (the caller then falls back to the plain
+    path).  Without a process group it concatenates the local pieces."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.on = dist.is_available() and dist.is_initialized()
+        self.world = dist.get_world_size(group) if self.on else 1
+        self.pieces = []          # (table or gathered, counts tensor, cap, work handles)
+
+    def submit(self, table: torch.Tensor, d_n: torch.Tensor):
+        C, cap = table.shape
+        if not self.on:
+            self.pieces.append((table.view(1, C, cap), d_n.view(1), cap, ()))
+            return
+        recv = torch.empty((self.world * C, cap), dtype=table.dtype, device=table.device)
+        counts = torch.empty((self.world,), dtype=d_n.dtype, device=d_n.device)
+        works = (dist.all_gather_into_tensor(counts, d_n.view(1), group=self.group, async_op=True),
+                 dist.all_gather_into_tensor(recv, table, group=self.group, async_op=True))
+        self.pieces.append((recv.view(self.world, C, cap), counts, cap, works))
+
+    def finish(self):
+        for _, _, _, works in self.pieces:
+            for w in works:
+                w.wait()
+        if not self.pieces:
+            return None
+        counts = torch.stack([c for _, c, _, _ in self.pieces]).cpu()          # (pieces, world): the one host sync
+        if any(int(counts[i].max()) > self.pieces[i][2] for i in range(len(self.pieces))):
+            return None
+        parts = [self.pieces[i][0][r, :, : int(counts[i, r])] for r in range(self.world) for i in range(len(self.pieces))]
+        return torch.cat(parts, dim=1)
+
+
+def _all_reduce_max_int(value: int, device, group=None) -> int:
+    if not (dist.is_available() and dist.is_initialized()):
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return int(t.item())
+
+
 def localize_sharded(movie_shard: torch.Tensor, first_frame: int, camera_info: dict, parameters: dict, *,
-                     eps: float = 1e-3, max_it: int = 100, mle_method: str = "sigmaxy", group=None):
+                     eps: float = 1e-3, max_it: int = 100, mle_method: str = "sigmaxy", group=None, chunks: int = 1):
     """Each rank localizes its resident shard (uint16 CUDA tensor of its frames),
     then all ranks receive the whole table.  `first_frame` is the label of the
-    shard's first frame (from shard_frames)."""
+    shard's first frame (from shard_frames).  With ``chunks`` > 1 the shard is processed in that many frame
+    ranges and the all-gather of each range overlaps the kernels of the next (a large shard's table is
+    gigabytes: config 4 moves 2.7 GB per rank); the result is the same table."""
     import ctypes
 
     from . import _lib
     L = _lib.load()
     _lib.require_gpu()
     F, H, W = movie_shard.shape
+    if chunks > 1 and F >= 2 * chunks:
+        out = _localize_sharded_pipelined(L, movie_shard, first_frame, camera_info, parameters, eps, max_it,
+                                          mle_method, group, chunks)
+        if out is not None:
+            return table_to_columns(out)
     cap = max(4096, 400 * F)
     dev = movie_shard.device
     stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
@@ -95,6 +151,55 @@ def localize_sharded(movie_shard: torch.Tensor, first_frame: int, camera_info: d
         cap = n
     table[0, :n] += int(first_frame)        # shard-local frame index -> movie frame label
     return table_to_columns(allgather_table(table, n, group))
+
+
+def _localize_sharded_pipelined(L, movie_shard, first_frame, camera_info, parameters, eps, max_it, mle_method, group, chunks):
+    """Frame ranges of the shard, each followed by its asynchronous gather.  The first range is timed to learn the
+    density of localizations (one host sync, maximum over the ranks) so that the later tables are tight; if a
+    later range overflows its capacity anywhere the whole call returns None and the caller takes the plain path."""
+    import ctypes
+
+    from . import _lib
+    F, H, W = movie_shard.shape
+    dev = movie_shard.device
+    stream = ctypes.c_void_p(torch.cuda.current_stream(dev).cuda_stream)
+    frames = _all_reduce_max_int(F, dev, group)                 # shards differ by at most one frame: same ranges everywhere
+    cuts = [(frames * i + chunks - 1) // chunks for i in range(chunks + 1)]      # identical on every rank
+    bounds = [min(F, c) for c in cuts]                                          # this rank's (a shorter shard ends early)
+    C = len(LOC_COLUMNS)
+    frame_bytes = H * W * movie_shard.element_size()
+
+    def run(lo, hi, cap):
+        table = torch.empty((C, cap), dtype=torch.int32, device=dev)
+        d_n = torch.zeros(1, dtype=torch.int64, device=dev)
+        nf = hi - lo
+        if nf > 0:
+            rc = L.pmi_localize_mle_dev(ctypes.c_void_p(movie_shard.data_ptr() + lo * frame_bytes), 0, nf, H, W,
+                                        int(parameters["Box Size"]), float(parameters["Min. Net Gradient"]), None,
+                                        0, nf - 1, float(camera_info["Baseline"]), float(camera_info["Sensitivity"]),
+                                        float(camera_info["Gain"]), float(eps), int(max_it),
+                                        _lib.MLE_METHODS[mle_method], ctypes.c_void_p(table.data_ptr()), cap,
+                                        ctypes.c_void_p(d_n.data_ptr()), stream)
+            _lib.check(rc, "pmi_localize_mle_dev")
+            table[0] += int(first_frame) + lo              # frame labels; the padding beyond the count is never read
+        return table, d_n
+
+    width = max(1, cuts[1] - cuts[0])
+    cap0 = _all_reduce_max_int(max(4096, 400 * width), dev, group)
+    t0, n0 = run(bounds[0], bounds[1], cap0)
+    found = int(n0.item())                                      # the one sync on the compute stream: density of this movie
+    per_frame = _all_reduce_max_int(-(-found // width), dev, group)
+    if _all_reduce_max_int(found, dev, group) > cap0:
+        return None
+    gather = PipelinedTableGather(group)
+    tight = found if not gather.on else _all_reduce_max_int(found, dev, group)
+    gather.submit(t0[:, : max(tight, 1)].contiguous(), n0)
+    for i in range(1, chunks):
+        lo, hi = bounds[i], bounds[i + 1]
+        cap = int(per_frame * max(1, cuts[i + 1] - cuts[i]) * 1.15) + 1024          # the same on every rank
+        table, d_n = run(lo, hi, cap)
+        gather.submit(table, d_n)
+    return gather.finish()
 
 
 # ---------------------------------------------------------------------------

@@ -156,3 +156,59 @@ def test_undrift_sharded_world2_matches_reference_goldens():
     # single process == sharded, with the same stand-in functions
     d1, u1 = pdist.undrift_sharded(locs, info, int(g["segmentation"]), render_fn=_cpu_render, pair_shift_fn=_cpu_pair_shifts)
     assert np.max(np.abs(d1["x"].to_numpy() - np.array(results[0][1]))) < 1e-9
+
+
+def _pipelined_worker(rank, world, port, piece_counts, caps, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = pdist.PipelinedTableGather()
+        for i, cap in enumerate(caps):
+            n = piece_counts[rank][i]
+            _, table = _fake_table(10 * rank + i, min(n, cap), cap)
+            g.submit(table, torch.tensor([n], dtype=torch.int64))
+        out = g.finish()
+        q.put((rank, None if out is None else out.tolist()))
+    except Exception as exc:
+        q.put((rank, repr(exc)))
+        raise
+    finally:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("piece_counts,caps,overflow", [(((4, 0, 7), (2, 5, 1)), (8, 6, 9), False),
+                                                        (((4, 3, 7), (2, 9, 1)), (8, 6, 9), True)])
+def test_pipelined_table_gather_world2(piece_counts, caps, overflow):
+    """Pieces gathered one by one (asynchronous collectives, as after each frame chunk of a shard) come back
+    ordered by rank, then piece; a piece that overflowed its capacity on any rank makes every rank return None."""
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_pipelined_worker, args=(r, 2, port, piece_counts, caps, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=60) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    if overflow:
+        assert results[0] is None and results[1] is None
+        return
+    want = torch.cat([_fake_table(10 * r + i, piece_counts[r][i], caps[i])[1][:, : piece_counts[r][i]]
+                      for r in range(2) for i in range(len(caps))], dim=1)
+    for r in range(2):
+        assert isinstance(results[r], list), results[r]
+        assert torch.equal(torch.tensor(results[r], dtype=torch.int32), want)
+
+
+def test_pipelined_table_gather_single_process():
+    g = pdist.PipelinedTableGather()
+    pieces = [(_fake_table(i, n, 10)[1], n) for i, n in enumerate((3, 0, 10))]
+    for t, n in pieces:
+        g.submit(t, torch.tensor([n], dtype=torch.int64))
+    assert torch.equal(g.finish(), torch.cat([t[:, :n] for t, n in pieces], dim=1))
+    g = pdist.PipelinedTableGather()
+    g.submit(pieces[0][0], torch.tensor([11], dtype=torch.int64))
+    assert g.finish() is None

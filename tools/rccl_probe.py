@@ -21,6 +21,14 @@ a = pdist._all_reduce_sum(np.ones((3, 4)), dev)
 assert np.array_equal(a, np.ones((3, 4)))
 g = torch.empty((1,), dtype=torch.int64, device=dev)
 dist.all_gather_into_tensor(g, torch.tensor([5], dtype=torch.int64, device=dev))
+# the pipelined shard path (frame ranges, asynchronous gathers) on a synthetic movie, against the plain one
+from picasso_amd import synth  # noqa: E402
+cam = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
+params = {"Box Size": 7, "Min. Net Gradient": 5000}
+mov = synth.simulate_movie(300, 256, 256, emitters_per_frame=30, device=dev)
+plain = pdist.localize_sharded(mov, 50, cam, params)
+piped = pdist.localize_sharded(mov, 50, cam, params, chunks=4)
+assert len(plain["frame"]) > 1000 and all(np.array_equal(plain[c], piped[c], equal_nan=True) for c in plain)
 dist.barrier()
 print("rccl probe ok: world", dist.get_world_size(), "gathered", int(g.item()))
 dist.destroy_process_group()

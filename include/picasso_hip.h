@@ -82,6 +82,13 @@ int pmi_free(void *dptr);
 int pmi_memcpy_h2d(void *dst_dev, const void *src_host, size_t bytes);
 int pmi_memcpy_d2h(void *dst_host, const void *src_dev, size_t bytes);
 int pmi_stream_synchronize(void *stream);
+/* A non-blocking HIP stream of the library's own (for callers without torch): the *_dev entry points queued on
+ * it do not order against default-stream copies, so the upload of the next frame chunk (pmi_memcpy_h2d from
+ * another host thread) overlaps them.  pmi_memcpy_d2h_async queues a copy on a stream; the host buffer is valid
+ * after pmi_stream_synchronize.                                                                              */
+int pmi_stream_create(void **stream);
+int pmi_stream_destroy(void *stream);
+int pmi_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int pmi_release_scratch(void);               /* frees the library's cached scratch buffers */
 
 /* ---- identify --------------------------------------------------------- *

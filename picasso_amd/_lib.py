@@ -42,6 +42,9 @@ SYMBOLS = {
     "pmi_memcpy_h2d": (_i32, [_p, _p, _sz]),
     "pmi_memcpy_d2h": (_i32, [_p, _p, _sz]),
     "pmi_stream_synchronize": (_i32, [_p]),
+    "pmi_stream_create": (_i32, [_p]),
+    "pmi_stream_destroy": (_i32, [_p]),
+    "pmi_memcpy_d2h_async": (_i32, [_p, _p, _sz, _p]),
     "pmi_release_scratch": (_i32, []),
     "pmi_identify": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
     "pmi_identify_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _p]),

@@ -305,9 +305,57 @@ class DeviceMovie:
             pass
 
 
-def _localize_device(call, columns, d_movie_ptr, dtype, shape, roi, frame_bounds, cap, stream, f_lo, f_hi):
-    """Shared driver of the fused pipelines: allocate the table, submit, grow on
-    overflow, copy the columns back."""
+class DeviceWorkspace:
+    """Grow-only device buffers of the fused pipelines (table + row count), kept across submissions so that a
+    chunked run does not allocate and free per chunk (hipFree waits for the whole device, uploads included)."""
+
+    def __init__(self):
+        self._table = ctypes.c_void_p()
+        self._bytes = 0
+        self._dn = ctypes.c_void_p()
+
+    def table(self, nbytes: int):
+        L = _lib.load()
+        if nbytes > self._bytes:
+            if self._table:
+                L.pmi_free(self._table)
+                self._table, self._bytes = ctypes.c_void_p(), 0
+            want = nbytes + nbytes // 4
+            _lib.check(L.pmi_malloc(ctypes.byref(self._table), want), "pmi_malloc")
+            self._bytes = want
+        return self._table
+
+    def count(self):
+        if not self._dn:
+            _lib.check(_lib.load().pmi_malloc(ctypes.byref(self._dn), 8), "pmi_malloc")
+        return self._dn
+
+    def free(self):
+        L = _lib.load()
+        if self._table:
+            L.pmi_free(self._table)
+        if self._dn:
+            L.pmi_free(self._dn)
+        self._table, self._bytes, self._dn = ctypes.c_void_p(), 0, ctypes.c_void_p()
+
+
+class DeviceStream:
+    """A non-blocking HIP stream of the library (pmi_stream_create)."""
+
+    def __init__(self):
+        self.handle = ctypes.c_void_p()
+        _lib.check(_lib.load().pmi_stream_create(ctypes.byref(self.handle)), "pmi_stream_create")
+
+    def destroy(self):
+        if self.handle:
+            _lib.load().pmi_stream_destroy(self.handle)
+            self.handle = ctypes.c_void_p()
+
+
+def _localize_device(call, columns, d_movie_ptr, dtype, shape, roi, frame_bounds, cap, stream, f_lo, f_hi, work=None):
+    """Shared driver of the fused pipelines: allocate the table (or take it from `work`), submit, grow on
+    overflow, copy the columns back (on `stream` when one is given, so that nothing orders against the
+    default stream)."""
     _lib.require_gpu()
     L = _lib.load()
     F, Y, X = shape
@@ -319,36 +367,44 @@ def _localize_device(call, columns, d_movie_ptr, dtype, shape, roi, frame_bounds
         hi = min(hi, f_hi)
     cap = int(cap or max(4096, 256 * F))
     ncol = len(columns)
-    while True:
-        table = ctypes.c_void_p()
-        dn = ctypes.c_void_p()
-        _lib.check(L.pmi_malloc(ctypes.byref(table), ncol * cap * 4), "pmi_malloc")
-        _lib.check(L.pmi_malloc(ctypes.byref(dn), 8), "pmi_malloc")
-        try:
+    own = work is None
+    ws = DeviceWorkspace() if own else work
+
+    def fetch(dst, src, nbytes):
+        if stream is None:
+            _lib.check(L.pmi_memcpy_d2h(_lib.ptr(dst), src, nbytes), "d2h")
+        else:
+            _lib.check(L.pmi_memcpy_d2h_async(_lib.ptr(dst), src, nbytes, stream), "d2h")
+
+    try:
+        while True:
+            table = ws.table(ncol * cap * 4)
+            dn = ws.count()
+            n = np.zeros(1, np.int64)
             with _lib.lock():
                 call(L, d_movie_ptr, dtype_code(dtype), F, Y, X, r, lo, hi, table, cap, dn, stream)
+                fetch(n, dn, 8)
                 _lib.check(L.pmi_stream_synchronize(stream), "sync")
-            n = np.zeros(1, np.int64)
-            _lib.check(L.pmi_memcpy_d2h(_lib.ptr(n), dn, 8), "d2h")
             n = int(n[0])
             if n > cap:
                 cap = n
                 continue
             out = {}
             for c, (name, dt) in enumerate(columns):
-                col = np.empty(n, dt)
+                out[name] = np.empty(n, dt)
                 if n:
-                    _lib.check(L.pmi_memcpy_d2h(_lib.ptr(col), ctypes.c_void_p(table.value + c * cap * 4), n * 4), "d2h")
-                out[name] = col
+                    fetch(out[name], ctypes.c_void_p(table.value + c * cap * 4), n * 4)
+            if stream is not None and n:
+                _lib.check(L.pmi_stream_synchronize(stream), "sync")
             return out
-        finally:
-            L.pmi_free(table)
-            L.pmi_free(dn)
+    finally:
+        if own:
+            ws.free()
 
 
 def localize_mle_device(d_movie_ptr, dtype, shape, box, min_ng, camera, eps=1e-3, max_it=100,
                         method="sigmaxy", roi=None, frame_bounds=None, cap=None, stream=None,
-                        f_lo=None, f_hi=None):
+                        f_lo=None, f_hi=None, work=None):
     """identify -> fused cut+fit -> table on a resident movie.  Returns a dict of
     numpy columns (LOC_COLUMNS).  d_movie_ptr: int / c_void_p device address."""
     def call(L, d_movie, code, F, Y, X, r, lo, hi, table, cap_, dn, stream_):
@@ -356,11 +412,11 @@ def localize_mle_device(d_movie_ptr, dtype, shape, box, min_ng, camera, eps=1e-3
                                     float(camera["Baseline"]), float(camera["Sensitivity"]), float(camera["Gain"]),
                                     float(eps), int(max_it), _lib.MLE_METHODS[method], table, cap_, dn, stream_)
         _lib.check(rc, "pmi_localize_mle_dev")
-    return _localize_device(call, LOC_COLUMNS, d_movie_ptr, dtype, shape, roi, frame_bounds, cap, stream, f_lo, f_hi)
+    return _localize_device(call, LOC_COLUMNS, d_movie_ptr, dtype, shape, roi, frame_bounds, cap, stream, f_lo, f_hi, work)
 
 
 def localize_lq_device(d_movie_ptr, dtype, shape, box, min_ng, camera, roi=None, frame_bounds=None, cap=None,
-                       stream=None, f_lo=None, f_hi=None):
+                       stream=None, f_lo=None, f_hi=None, work=None):
     """identify -> fused cut + least-squares fit -> 11-column table (LQ_COLUMNS)."""
     em = int(camera["Gain"] > 1)
 
@@ -369,4 +425,4 @@ def localize_lq_device(d_movie_ptr, dtype, shape, box, min_ng, camera, roi=None,
                                    float(camera["Baseline"]), float(camera["Sensitivity"]), float(camera["Gain"]),
                                    em, table, cap_, dn, stream_)
         _lib.check(rc, "pmi_localize_lq_dev")
-    return _localize_device(call, LQ_COLUMNS, d_movie_ptr, dtype, shape, roi, frame_bounds, cap, stream, f_lo, f_hi)
+    return _localize_device(call, LQ_COLUMNS, d_movie_ptr, dtype, shape, roi, frame_bounds, cap, stream, f_lo, f_hi, work)

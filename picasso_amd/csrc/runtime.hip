@@ -108,6 +108,21 @@ int pmi_free(void *dptr) { PMI_HIP(hipFree(dptr)); return PMI_OK; }
 int pmi_memcpy_h2d(void *d, const void *h, size_t bytes) { PMI_HIP(hipMemcpy(d, h, bytes, hipMemcpyHostToDevice)); return PMI_OK; }
 int pmi_memcpy_d2h(void *h, const void *d, size_t bytes) { PMI_HIP(hipMemcpy(h, d, bytes, hipMemcpyDeviceToHost)); return PMI_OK; }
 int pmi_stream_synchronize(void *stream) { PMI_HIP(hipStreamSynchronize((hipStream_t)stream)); return PMI_OK; }
+int pmi_stream_create(void **stream)
+{
+    // non-blocking: work on it does not order against the default stream, so a host thread's blocking upload of the
+    // next frame chunk runs beside this stream's kernels and row copies
+    hipStream_t s;
+    PMI_HIP(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void *)s;
+    return PMI_OK;
+}
+int pmi_stream_destroy(void *stream) { PMI_HIP(hipStreamDestroy((hipStream_t)stream)); return PMI_OK; }
+int pmi_memcpy_d2h_async(void *h, const void *d, size_t bytes, void *stream)
+{
+    PMI_HIP(hipMemcpyAsync(h, d, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return PMI_OK;
+}
 int pmi_release_scratch(void) { pmi::release_fft_plans(); return pmi::scratch_release_all(); }
 
 int pmi_event_create(void **event)

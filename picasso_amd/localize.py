@@ -537,11 +537,12 @@ def localize_resident(movie: np.ndarray, camera_info: dict, parameters: dict, *,
 
 def localize_streamed(movie, camera_info: dict, parameters: dict, *, roi=None, frame_bounds=None,
                       fitting_method: str = "gaussmle", eps: float = 0.001, max_it: int = 100,
-                      mle_method: str = "sigmaxy", chunk_bytes: int = 1 << 30,
+                      mle_method: str = "sigmaxy", chunk_bytes: int = 1 << 28,
                       progress_callback=None) -> pd.DataFrame:
     """The fused device pipeline over a host movie of any length (ndarray, memmap or a picasso movie
-    object): frames go up in chunks of about ``chunk_bytes`` through one staging allocation, each chunk runs
-    identify -> cut+fit -> table on the device, only the table rows come back.  The movie crosses PCIe once
+    object): frames go up in chunks of about ``chunk_bytes`` through two staging allocations (the upload of
+    one chunk overlaps the device work and the row copy of the previous one, which run on a stream of their
+    own), each chunk runs identify -> cut+fit -> table on the device, only the table rows come back.  The movie crosses PCIe once
     and neither host RAM nor HBM has to hold it whole.  Same rows as ``localize_resident``."""
     if fitting_method not in ("gaussmle", "gausslq"):
         raise ValueError("localize_streamed supports fitting_method 'gaussmle' or 'gausslq'")
@@ -552,30 +553,50 @@ def localize_streamed(movie, camera_info: dict, parameters: dict, *, roi=None, f
     columns = backend.LQ_COLUMNS if fitting_method == "gausslq" else backend.LOC_COLUMNS
     parts = []
     if hi >= lo:
+        from concurrent.futures import ThreadPoolExecutor
         first = np.asarray(movie[lo])
         per = max(1, int(chunk_bytes) // max(first.nbytes, 1))
-        stage = None
+        # Two staging allocations.  This thread uploads chunk i + 1 (a blocking default-stream copy; ctypes
+        # releases the GIL) while a worker thread runs chunk i on a non-blocking stream of its own — kernels,
+        # row copies, DataFrame — with table buffers that live for the whole run (no hipFree in between, which
+        # would wait for the upload).
+        stages = [None, None]
+        stream = backend.DeviceStream()
+        work = backend.DeviceWorkspace()
+
+        def on_device(stage, c0):
+            if fitting_method == "gausslq":
+                cols = backend.localize_lq_device(stage.ptr, stage.dtype, stage.shape, box, min_ng, camera_info, roi=roi,
+                                                  stream=stream.handle, work=work)
+            else:
+                cols = backend.localize_mle_device(stage.ptr, stage.dtype, stage.shape, box, min_ng, camera_info,
+                                                   eps, max_it, mle_method, roi=roi, stream=stream.handle, work=work)
+            cols["frame"] = cols["frame"] + np.asarray(c0, cols["frame"].dtype)
+            return pd.DataFrame(cols)
+
+        futures = []
         try:
-            for c0 in range(lo, hi + 1, per):
-                c1 = min(hi + 1, c0 + per)
-                chunk = _frames(movie, c0, c1)
-                if stage is None:
-                    stage = backend.DeviceMovie(chunk)
-                else:
-                    stage.load(chunk)
-                if fitting_method == "gausslq":
-                    cols = backend.localize_lq_device(stage.ptr, stage.dtype, stage.shape, box, min_ng, camera_info,
-                                                      roi=roi)
-                else:
-                    cols = backend.localize_mle_device(stage.ptr, stage.dtype, stage.shape, box, min_ng, camera_info,
-                                                       eps, max_it, mle_method, roi=roi)
-                cols["frame"] = cols["frame"] + np.asarray(c0, cols["frame"].dtype)
-                parts.append(pd.DataFrame(cols))
-                if callable(progress_callback):
-                    progress_callback(c1 - lo)
+            with ThreadPoolExecutor(max_workers=1) as pool:
+                for i, c0 in enumerate(range(lo, hi + 1, per)):
+                    c1 = min(hi + 1, c0 + per)
+                    k = i & 1
+                    if i >= 2:
+                        futures[i - 2].result()          # that chunk is done with staging allocation k
+                    chunk = _frames(movie, c0, c1)
+                    if stages[k] is None:
+                        stages[k] = backend.DeviceMovie(chunk)
+                    else:
+                        stages[k].load(chunk)
+                    futures.append(pool.submit(on_device, stages[k], c0))
+                    if callable(progress_callback):
+                        progress_callback(c1 - lo)
+                parts = [f.result() for f in futures]
         finally:
-            if stage is not None:
-                stage.free()
+            for st in stages:
+                if st is not None:
+                    st.free()
+            work.free()
+            stream.destroy()
     if not parts:
         return pd.DataFrame({name: np.empty(0, dt) for name, dt in columns})
     return parts[0] if len(parts) == 1 else pd.concat(parts, ignore_index=True)

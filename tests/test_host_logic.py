@@ -224,7 +224,7 @@ def test_install_rebinds_the_reference_functions():
 def test_localize_streamed_chunking_logic(monkeypatch, testdata_movie):
     """Host logic of the chunked upload (no GPU): the device calls are replaced by the oracle's identify, so what
     is checked is the chunk boundaries, the frame labels, frame bounds, the progress callback, the reuse of one
-    staging allocation and the empty result; the device side of the same function is the GPU tier's."""
+    staging allocations and the empty result; the device side of the same function is the GPU tier's."""
     from oracle import oracle as orc
 
     class FakeStage:
@@ -251,7 +251,14 @@ def test_localize_streamed_chunking_logic(monkeypatch, testdata_movie):
         cols["x"], cols["y"], cols["net_gradient"] = x.astype(np.float32), y.astype(np.float32), ng
         return cols
 
+    class Dummy:
+        handle = None
+        def destroy(self): pass
+        def free(self): pass
+
     monkeypatch.setattr(backend, "DeviceMovie", FakeStage)
+    monkeypatch.setattr(backend, "DeviceStream", Dummy)
+    monkeypatch.setattr(backend, "DeviceWorkspace", Dummy)
     monkeypatch.setattr(backend, "localize_mle_device", fake_device)
     mov = np.ascontiguousarray(testdata_movie)
     cam = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
@@ -259,7 +266,7 @@ def test_localize_streamed_chunking_logic(monkeypatch, testdata_movie):
     whole = pd.DataFrame(fake_device(mov, mov.dtype, mov.shape, 7, 3000, cam))
     seen = []
     got = localize.localize_streamed(mov, cam, params, chunk_bytes=13 * mov[0].nbytes, progress_callback=seen.append)
-    assert FakeStage.made == 1 and seen == [13, 26, 39, 52, 65, 78, 91, 100]
+    assert FakeStage.made == 2 and seen == [13, 26, 39, 52, 65, 78, 91, 100]      # two staging allocations, reused
     assert len(got) == len(whole) > 20 and got.equals(whole)
 
     class FrameOnly:

@@ -23,8 +23,10 @@ for rep in range(3):
     t3 = time.perf_counter()
     print(f"{F} frames ({gb:.2f} GB), {len(fr)} spots: identify {1e3 * (t1 - t0):.0f} ms ({gb / (t1 - t0):.1f} GB/s), "
           f"get_spots {1e3 * (t2 - t1):.0f} ms, gaussmle {1e3 * (t3 - t2):.0f} ms -> {len(fr) / (t3 - t0) / 1e6:.2f} M loc/s end to end")
-    t4 = time.perf_counter()
-    locs = localize.localize_streamed(mov, cam, {"Min. Net Gradient": 5000.0, "Box Size": 7})
-    t5 = time.perf_counter()
-    print(f"   localize_streamed (one upload, fused): {1e3 * (t5 - t4):.0f} ms ({gb / (t5 - t4):.1f} GB/s) -> "
-          f"{len(locs) / (t5 - t4) / 1e6:.2f} M loc/s")
+    for mib in ([None] if rep < 2 else [None, 128, 256, 512]):
+        kw = {} if mib is None else {"chunk_bytes": mib << 20}
+        t4 = time.perf_counter()
+        locs = localize.localize_streamed(mov, cam, {"Min. Net Gradient": 5000.0, "Box Size": 7}, **kw)
+        t5 = time.perf_counter()
+        print(f"   localize_streamed (one upload, fused, chunk {mib or 'default'} MiB): {1e3 * (t5 - t4):.0f} ms "
+              f"({gb / (t5 - t4):.1f} GB/s) -> {len(locs) / (t5 - t4) / 1e6:.2f} M loc/s")

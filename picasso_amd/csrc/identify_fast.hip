@@ -4,7 +4,8 @@
 // Same semantics as identify_scan_kernel in identify.hip (picasso/localize.py:97-134
 // _local_maxima, :202-244 _net_gradient, :288 threshold); only the schedule differs:
 //
-//   * one wavefront owns a band of RB rows x 512 columns of one frame; lane l holds
+//   * one wavefront owns a band of RB rows x 512 columns of one frame (frames at most 256 / 128 pixels wide:
+//     two / four consecutive bands side by side, template parameter P); lane l holds
 //     8 consecutive pixels of the current row as four packed u16x2 registers (one
 //     16-byte global load per row) plus the 4 pixels on either side, taken from the
 //     neighbouring lanes' registers by DPP wave_shr/wave_shl (lanes 0 and 63 load
@@ -211,12 +212,17 @@ __device__ __forceinline__ float exact_ng_noWrap(const uint16_t *__restrict__ sr
     return exact_ng_rows<H, KM, BOX>(base, X, ng);
 }
 
-template <int H, int RB, int D>
+// P > 1 (frames at most 512 / P pixels wide): the wave works on P consecutive bands of the frame at once, NL = 64 / P
+// lanes each, in lock step (row step r handles row r of every sub-band).  Neighbour pixels that a lane at a
+// sub-band's edge takes from the adjacent sub-band only reach positions outside the crop, which are masked.
+template <int H, int RB, int D, int P = 1>
 __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6 ? 3 : 2))) void identify_scan_u16_fast_kernel(
     FastParams p, const float *__restrict__ uxy, Record *__restrict__ recs, long long cap,
     unsigned long long *__restrict__ shard_cnt, int *__restrict__ frame_count)
 {
     constexpr int BOX = 2 * H + 1;
+    constexpr int NL = 64 / P;                             // lanes per sub-band
+    static_assert(P == 1 || P == 2 || P == 4 || P == 8, "sub-bands split the wavefront evenly");
     // Boxes 11 to 17 (H = 5..8) need 8 neighbour pixels per side and keep an Hrow ring of H slots of which
     // the slot about to be overwritten is skipped: both rings then share the period H.
     constexpr bool WIDE = H >= 5;
@@ -258,7 +264,9 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
     const int fi = (m / p.bpf) * 8 + xcd;
     const int unit = (m % p.bpf) * FAST_WAVES + w;
     if (fi >= p.nframes || unit >= p.bands * p.segs) return;
-    const int band = unit / p.segs, seg = unit - band * p.segs;
+    const int band = unit / p.segs, seg = unit - band * p.segs;       // P > 1: `band` counts groups of P bands, seg = 0
+    const int sub = P > 1 ? lane / NL : 0;                            // this lane's sub-band and its rows' offset
+    const int sub_rows = sub * RB;
 
     // The crop may start at any column: lanes work on 8-pixel chunks aligned in the FRAME (16-byte
     // loads), xoff pixels of the first chunk lie left of the crop.  Positions outside the crop are
@@ -267,16 +275,19 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
     // statistics cells are relative to the aligned origin, j = ja - xoff is relative to the crop.
     const int xoff = p.x0 & 7;
     const int nch = (xoff + p.cx + 7) >> 3;           // 8-pixel chunks per row
-    const int c8 = seg * 64 + lane;
+    const int c8 = P > 1 ? lane % NL : seg * 64 + lane;
     const bool lane_valid = c8 < nch;
     const int cm = min(c8, nch - 1);
     const uint16_t *src = p.movie + ((int64_t)(p.f_lo + fi) * p.Y + p.y0) * p.X + p.x0;
     const int col_m = cm * 8;
     const int col_l = cm > 0 ? col_m - NB : col_m;                // clamped copies feed invalid pixels only
     const int col_r = cm + 1 < nch ? col_m + 8 : col_m + 8 - NB;
-    const int band_lo = band * RB, band_hi = min(band_lo + RB, p.cy);
+    const int band_lo = band * (RB * P), band_hi = min(band_lo + RB, p.cy);  // P > 1: of sub-band 0
     const int row_lo = max(band_lo, H), row_hi = min(band_hi, p.cy - H - 1);   // rows that may hold a maximum
     const int rs0 = band_lo - H - 1;
+    // P > 1: the same limits for this lane's sub-band, in sub-band 0's row numbering
+    const int lo_rel = max(band_lo + sub_rows, H) - sub_rows;
+    const int hi_rel = min(min(band_lo + sub_rows + RB, p.cy), p.cy - H - 1) - sub_rows;
 
     // which of the lane's 8 pixels may hold a maximum: even pixels -> bits 0..3, odd -> bits 16..19,
     // replicated for the four row slots of the candidate accumulator
@@ -297,7 +308,7 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
     // fill is still in flight are not merged).  Only lanes 0 and 63 load the 4 pixels beyond the wave.
     const unsigned off_m = (unsigned)col_m * 2u;
     const unsigned off_e = (unsigned)(lane == 0 ? col_l : col_r) * 2u;
-    const bool edge_lane = lane == 0 || lane == 63;
+    const bool edge_lane = P == 1 && (lane == 0 || lane == 63);       // a sub-band's row lies wholly inside its lanes
     // Rows are fetched with buffer loads: the frame base sits in a scalar resource descriptor, the
     // row offset in a scalar register and the lane's column offset in one VGPR, so a row costs no
     // vector address arithmetic at all (a 64-bit global address per lane would take two VALU adds).
@@ -314,10 +325,18 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
     // interior bands never touch a row outside the crop: no clamping in their row loop
     const bool interior = rs0 >= 0 && rs0 + NRP + D <= p.cy;
     auto load_row = [&](int r) -> RowRegs {
-        const int rc = interior ? r : min(max(r, 0), p.cy - 1);
-        const unsigned soff = (unsigned)rc * pitch;
         RowRegs o;
-        const u32x4_t m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_m, (int)soff, 0);
+        unsigned soff = 0;
+        u32x4_t m;
+        if constexpr (P > 1) {
+            // every sub-band clamps its own row: the row offset joins the lane's column offset
+            const int rl = min(max(r + sub_rows, 0), p.cy - 1);
+            m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off_m + (unsigned)rl * pitch), 0, 0);
+        } else {
+            const int rc = interior ? r : min(max(r, 0), p.cy - 1);
+            soff = (unsigned)rc * pitch;
+            m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_m, (int)soff, 0);
+        }
         o.m = make_uint4(m.x, m.y, m.z, m.w);
         // only lanes 0 and 63 ever read `e` (as the DPP fill value): the other lanes leave it undefined
         // instead of spending two or four v_mov per row on zeros
@@ -410,8 +429,10 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
                 const int rd0 = rs0 + (st - t4) - H;   // decision row of slot 0
                 u32 rowmask = 0;
 #pragma unroll
-                for (int tt = 0; tt <= t4; tt++)
-                    if (rd0 + tt >= row_lo && rd0 + tt < row_hi) rowmask |= 0x000f000fu << (4 * tt);
+                for (int tt = 0; tt <= t4; tt++) {
+                    if constexpr (P > 1) { if (rd0 + tt >= lo_rel && rd0 + tt < hi_rel) rowmask |= 0x000f000fu << (4 * tt); }
+                    else { if (rd0 + tt >= row_lo && rd0 + tt < row_hi) rowmask |= 0x000f000fu << (4 * tt); }
+                }
                 u32 pass = ~acc & rowmask & colmask;
                 acc = 0;
                 // Append to the wave's own list: every round each lane that still has a candidate emits
@@ -533,6 +554,19 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
         append(i, j, ng);
     };
 
+    // list entry -> row, crop column, and the column inside the sub-band's (or the wave's) own lanes
+    auto decode = [&](unsigned e, int &i, int &j, int &jown) {
+        if constexpr (P > 1) {
+            const int le = (int)(e & 511u) >> 3;
+            i = band_lo + (le / NL) * RB + (int)(e >> 9);
+            jown = (le % NL) * 8 + (int)(e & 7u);
+            j = jown - xoff;
+        } else {
+            i = band_lo + (int)(e >> 9);
+            jown = (int)(e & 511u);
+            j = seg * 512 + jown - xoff;
+        }
+    };
     const int found = cnt;
     if (found <= LIST) {
         // pass 1: cheap level-1 bound on every candidate; survivors are compacted in place
@@ -544,13 +578,14 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
             unsigned short e = 0;
             if (q < found) {
                 e = s_list[w][q];
-                const int i = band_lo + (int)(e >> 9), j = seg * 512 + (int)(e & 511u) - xoff;
+                int i, j, jown;
+                decode(e, i, j, jown);
                 keep = true;
-                const int jl = (int)(e & 511u);
+                const int jl = (int)(e & 511u);          // column in the wave's lanes: indexes the statistics cells
                 // |ng| <= P_box * (max - min) over statistics cells covering the (2H+3)^2 stencil; candidates whose
-                // stencil wraps or leaves this wave's 512 columns are always kept
-                if (i != H && j != H && jl - H - 1 >= 0 && jl + H + 1 <= 511) {
-                    const int rr = i - rs0;
+                // stencil wraps or leaves this wave's 512 columns (its sub-band's lanes) are always kept
+                if (i != H && j != H && jown - H - 1 >= 0 && jown + H + 1 <= 8 * NL - 1) {
+                    const int rr = (int)(e >> 9) + H + 1;       // = row - first pipeline row of its (sub-)band
                     const int jlo = jl - H - 1, jhi = jl + H + 1;
                     constexpr int NLANE = (2 * H + 2) / 8 + 2;               // lanes (8 columns each) a stencil row can touch
                     unsigned lo = 0xffffu, hi = 0u;
@@ -582,7 +617,8 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
             const int q = q0 + lane;
             if (q < kept) {
                 const unsigned e = s_list[w][q];
-                const int i = band_lo + (int)(e >> 9), j = seg * 512 + (int)(e & 511u) - xoff;
+                int i, j, jown;
+                decode(e, i, j, jown);
                 const bool wraps = (i == H) || (j == H);
                 // the packed test cannot see ties at 65535 (saturating +1): those are rechecked exactly
                 const bool saturated = src[(int64_t)i * p.X + j] == 0xffffu;
@@ -599,20 +635,28 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
         const int j0 = seg * 512 - xoff, j1 = min(j0 + 512, p.cx);
         for (int idx0 = 0; idx0 < RB * 512; idx0 += 64) {
             const int idx = idx0 + lane;
-            const int i = band_lo + idx / 512, j = j0 + (idx & 511);
-            if (i >= row_lo && i < row_hi && j < j1 && j >= H && j < p.cx - H - 1) process_slow(i, j, true);
+            if constexpr (P > 1) {
+                int i, j, jown;
+                decode((unsigned)idx, i, j, jown);       // same layout as a list entry: (row << 9) | column in the wave's lanes
+                const int sb_lo = band_lo + (((idx & 511) >> 3) / NL) * RB;
+                const int rlo = max(sb_lo, H), rhi = min(min(sb_lo + RB, p.cy), p.cy - H - 1);
+                if (i >= rlo && i < rhi && jown < nch * 8 && j >= H && j < p.cx - H - 1) process_slow(i, j, true);
+            } else {
+                const int i = band_lo + idx / 512, j = j0 + (idx & 511);
+                if (i >= row_lo && i < row_hi && j < j1 && j >= H && j < p.cx - H - 1) process_slow(i, j, true);
+            }
             flush();
         }
     }
 }
 
-template <int H, int RB, int D>
+template <int H, int RB, int D, int P = 1>
 static int launch_fast(const FastParams &p, const float *d_tab, Record *recs, long long cap,
                        unsigned long long *shard_cnt, int *frame_count, hipStream_t s)
 {
     long long blocks = 8LL * p.bpf * ((p.nframes + 7) / 8);
     if (blocks > 0x7fffffffLL) { set_error("identify: too many blocks (%lld)", blocks); return PMI_ERR_ARG; }
-    hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, RB, D>), dim3((unsigned)blocks), dim3(FAST_WAVES * 64), 0, s,
+    hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, RB, D, P>), dim3((unsigned)blocks), dim3(FAST_WAVES * 64), 0, s,
                        p, d_tab, recs, cap, shard_cnt, frame_count);
     PMI_HIP(hipGetLastError());
     return PMI_OK;
@@ -653,12 +697,20 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     if (!unit_vectors_match()) return PMI_OK;          // never expected; the generic kernel uses the runtime table
     if ((X & 1) || cx < 16 || ((uintptr_t)d_movie & 3)) return PMI_OK;       // rows must start 4-byte aligned (buffer loads); the crop may not
     if (cy > 65535 || cx > 65535 || X > 65535 || Y * X * 2 >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets
-    const int RB = h == 1 ? 16 : (h == 2 ? 32 : 64);     // keeps the per-wave candidate list <= 8.5 KB of LDS
+    int RB = h == 1 ? 16 : (h == 2 ? 32 : 64);           // keeps the per-wave candidate list <= 8.5 KB of LDS
+    // narrow frames (box 7): several bands side by side in one wavefront instead of idle lanes
+    const int nch = ((x0 & 7) + cx + 7) / 8;
+    static const bool no_pack = getenv("PMI_IDENTIFY_NOPACK") != nullptr;
+    int pack = 1;
+    if (h >= 2 && h <= 4 && !no_pack) {
+        if (nch <= 16) { pack = 4; RB = (h > 2 && cy >= 256) ? 64 : 32; }     // short frames: shorter bands, no idle sub-band
+        else if (nch <= 32) pack = 2;
+    }
     FastParams p;
     p.movie = (const uint16_t *)d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;
     p.f_lo = f_lo; p.label_off = label_off; p.nframes = nframes; p.box = box; p.min_ng = min_ng;
-    p.bands = (cy + RB - 1) / RB;
-    p.segs = (((x0 & 7) + cx + 7) / 8 + 63) / 64;
+    p.bands = (cy + RB * pack - 1) / (RB * pack);
+    p.segs = pack > 1 ? 1 : (nch + 63) / 64;
     p.bpf = (p.bands * p.segs + FAST_WAVES - 1) / FAST_WAVES;
     // ng is a linear functional sum_p w(p) f(p) of the (2H+3)^2 neighbourhood with sum_p w(p) = 0 (a constant
     // image has no gradient), hence |ng| <= P_box * (max - min), P_box = sum of the positive weights
@@ -683,9 +735,23 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     int rc;
     switch (h) {
     case 1: rc = launch_fast<1, 16, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
-    case 2: rc = launch_fast<2, 32, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
-    case 3: rc = launch_fast<3, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s); break;
-    case 4: rc = launch_fast<4, 64, 4>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 2:
+        if (pack == 4) rc = launch_fast<2, 32, 2, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 2) rc = launch_fast<2, 32, 2, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<2, 32, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        break;
+    case 3:
+        if (pack == 4 && RB == 64) rc = launch_fast<3, 64, 3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 4) rc = launch_fast<3, 32, 3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 2) rc = launch_fast<3, 64, 3, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<3, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s);
+        break;
+    case 4:
+        if (pack == 4 && RB == 64) rc = launch_fast<4, 64, 4, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 4) rc = launch_fast<4, 32, 4, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 2) rc = launch_fast<4, 64, 4, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<4, 64, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        break;
     case 5: rc = launch_fast<5, 64, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     case 6: rc = launch_fast<6, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     case 7: rc = launch_fast<7, 64, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;

@@ -214,6 +214,46 @@ def test_identify_fast_path_vs_oracle(be, orc, shape, box):
                 assert all(np.array_equal(p, q) for p, q in zip(a, b)), (roi, min_ng)
 
 
+@pytest.mark.parametrize("shape,box", [((5, 128, 128), 7), ((3, 200, 128), 7), ((2, 300, 100), 7), ((2, 520, 256), 7), ((3, 70, 250), 7),
+                                       ((2, 33, 64), 7), ((3, 260, 120), 7), ((4, 97, 130), 5), ((2, 300, 128), 5), ((2, 150, 256), 9),
+                                       ((3, 280, 96), 9), ((2, 41, 200), 9), ((6, 64, 64), 5)])
+def test_identify_narrow_frames_packed_bands(be, orc, shape, box):
+    """Frames at most 256 (128) pixels wide put two (four) bands of a frame side by side in one wavefront
+    (boxes 5, 7, 9): heights that leave sub-bands partly or wholly empty, crops that start off the 8-pixel grid,
+    maxima on the first / last allowed rows and columns of every sub-band, a saturated plateau (overflow rescan)."""
+    rng = np.random.default_rng(shape[1] * 1000 + shape[2] + box)
+    F, Y, X = shape
+    mov = rng.poisson(25, size=shape).astype(np.uint16) + 90
+    h = box // 2
+    for f in range(F):
+        for _ in range(max(3, Y * X // 900)):
+            y, x = int(rng.integers(1, Y - 1)), int(rng.integers(1, X - 1))
+            amp = int(rng.integers(150, 3000))
+            mov[f, max(0, y - 1):y + 2, max(0, x - 1):x + 2] += np.uint16(amp // 3)
+            mov[f, y, x] += np.uint16(amp)
+        for y in (h, h + 1, 31, 32, 33, 63, 64, 65, Y - h - 2, Y - h - 3):          # band seams and frame edges
+            for x in (h, X - h - 2, X // 2):
+                if 0 < y < Y - 1:
+                    mov[f, y, x] += np.uint16(2500 + 7 * y + x)
+    mov[0, 5:9, 4:10] = 65535
+    mov[:, ::11, ::3] = mov[:, ::11, ::3] // 4 * 4
+    for min_ng in (-1e9, 400.0, 15000.0):
+        a = be.identify_arrays(mov, min_ng, box)
+        b = orc.identify(mov, min_ng, box, threads=4)
+        assert len(a[0]) == len(b[0]), (min_ng, len(a[0]), len(b[0]))
+        assert all(np.array_equal(p, q) for p, q in zip(a, b)), min_ng
+    for roi in (((0, 3), (Y, X - 1)), ((2, 5), (Y - 3, X - 6)), ((1, 9), (Y - 1, min(X, 9 + 101))), ((7, 0), (Y - 2, X // 2 + 3))):
+        a = be.identify_arrays(mov, 400.0, box, roi=roi)
+        b = orc.identify(mov, 400.0, box, roi=roi, threads=4)
+        assert len(a[0]) == len(b[0]), roi
+        assert all(np.array_equal(p, q) for p, q in zip(a, b)), roi
+    sat = np.full((2, Y, X), 65535, np.uint16)                  # every pixel a packed-test candidate: the rescan path
+    sat[1, Y // 2, X // 2] = 100
+    a = be.identify_arrays(sat, -1e9, box)
+    b = orc.identify(sat, -1e9, box, threads=4)
+    assert all(np.array_equal(p, q) for p, q in zip(a, b))
+
+
 def test_identify_fast_path_all_zero_and_all_saturated(be, orc):
     for val in (0, 65535, 777):
         mov = np.full((2, 80, 256), val, np.uint16)

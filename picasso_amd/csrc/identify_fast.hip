@@ -702,8 +702,8 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     const int nch = ((x0 & 7) + cx + 7) / 8;
     static const bool no_pack = getenv("PMI_IDENTIFY_NOPACK") != nullptr;
     int pack = 1;
-    if (h >= 2 && h <= 4 && !no_pack) {
-        if (nch <= 16) { pack = 4; RB = (h > 2 && cy >= 256) ? 64 : 32; }     // short frames: shorter bands, no idle sub-band
+    if (h >= 2 && h <= 6 && !no_pack) {
+        if (nch <= 16 && h <= 4) { pack = 4; RB = (h > 2 && cy >= 256) ? 64 : 32; }     // short frames: shorter bands, no idle sub-band
         else if (nch <= 32) pack = 2;
     }
     FastParams p;
@@ -752,8 +752,14 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
         else if (pack == 2) rc = launch_fast<4, 64, 4, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
         else rc = launch_fast<4, 64, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
         break;
-    case 5: rc = launch_fast<5, 64, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
-    case 6: rc = launch_fast<6, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 5:
+        if (pack == 2) rc = launch_fast<5, 64, 2, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<5, 64, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        break;
+    case 6:
+        if (pack == 2) rc = launch_fast<6, 64, 3, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<6, 64, 3>(p, d_tab, recs, cap, n_total, frame_count, s);
+        break;
     case 7: rc = launch_fast<7, 64, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     default: rc = launch_fast<8, 64, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     }

@@ -114,7 +114,10 @@ struct FastParams {
     int dbg;                   // PMI_IDENTIFY_DBG: 1 = skip the exact net gradient, 2 = skip the record append (timing only)
 };
 
-constexpr int FAST_WAVES = 4;
+#ifndef FAST_WAVES_N
+#define FAST_WAVES_N 1          // one wavefront per workgroup: frames with few bands leave no idle waves (128 x 128: 1.3 -> 2.2 TB/s), larger ones gain 2-3 %
+#endif
+constexpr int FAST_WAVES = FAST_WAVES_N;
 #ifndef FAST_D_H3
 #define FAST_D_H3 6          // rows prefetched ahead in the box-7 scan (divides its unroll period of 6): 6 instead of 3, 1.65 -> 1.60 ms
 #endif

@@ -759,9 +759,9 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
         else rc = launch_fast<2, 32, FAST_D_H2>(p, d_tab, recs, cap, n_total, frame_count, s);
         break;
     case 3:
-        if (pack == 4 && RB == 64) rc = launch_fast<3, 64, 3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 4) rc = launch_fast<3, 32, 3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 2) rc = launch_fast<3, 64, 3, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        if (pack == 4 && RB == 64) rc = launch_fast<3, 64, FAST_D_H3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 4) rc = launch_fast<3, 32, FAST_D_H3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 2) rc = launch_fast<3, 64, FAST_D_H3, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
         else rc = launch_fast<3, 64, FAST_D_H3>(p, d_tab, recs, cap, n_total, frame_count, s);
         break;
     case 4:

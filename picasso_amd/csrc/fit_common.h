@@ -6,7 +6,10 @@
 
 namespace pmi {
 
-constexpr int FIT_WAVES = 4;                 // waves per workgroup
+#ifndef FIT_WAVES_N
+#define FIT_WAVES_N 4
+#endif
+constexpr int FIT_WAVES = FIT_WAVES_N;       // waves per workgroup
 constexpr int FIT_NT = FIT_WAVES * PMI_WAVE;
 constexpr int FIT_MAXPIX = PMI_MAX_BOX * PMI_MAX_BOX;
 

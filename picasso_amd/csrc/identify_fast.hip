@@ -721,7 +721,8 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     static const bool no_pack = getenv("PMI_IDENTIFY_NOPACK") != nullptr;
     int pack = 1;
     if (h >= 2 && h <= 6 && !no_pack) {
-        if (nch <= 16 && h <= 4) { pack = 4; RB = (h > 2 && cy >= 256) ? 64 : 32; }     // short frames: shorter bands, no idle sub-band
+        if (nch <= 8 && h == 3) { pack = 8; RB = cy >= 256 ? 32 : (cy >= 128 ? 16 : 8); }   // <= 64 px wide: eight bands side by side
+        else if (nch <= 16 && h <= 4) { pack = 4; RB = (h > 2 && cy >= 256) ? 64 : 32; }     // short frames: shorter bands, no idle sub-band
         else if (nch <= 32) pack = 2;
     }
     FastParams p;
@@ -759,7 +760,10 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
         else rc = launch_fast<2, 32, FAST_D_H2>(p, d_tab, recs, cap, n_total, frame_count, s);
         break;
     case 3:
-        if (pack == 4 && RB == 64) rc = launch_fast<3, 64, FAST_D_H3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        if (pack == 8 && RB == 32) rc = launch_fast<3, 32, FAST_D_H3, 8>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 8 && RB == 16) rc = launch_fast<3, 16, FAST_D_H3, 8>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 8) rc = launch_fast<3, 8, FAST_D_H3, 8>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 4 && RB == 64) rc = launch_fast<3, 64, FAST_D_H3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
         else if (pack == 4) rc = launch_fast<3, 32, FAST_D_H3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
         else if (pack == 2) rc = launch_fast<3, 64, FAST_D_H3, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
         else rc = launch_fast<3, 64, FAST_D_H3>(p, d_tab, recs, cap, n_total, frame_count, s);

@@ -217,7 +217,7 @@ def test_identify_fast_path_vs_oracle(be, orc, shape, box):
 @pytest.mark.parametrize("shape,box", [((5, 128, 128), 7), ((3, 200, 128), 7), ((2, 300, 100), 7), ((2, 520, 256), 7), ((3, 70, 250), 7),
                                        ((2, 33, 64), 7), ((3, 260, 120), 7), ((4, 97, 130), 5), ((2, 300, 128), 5), ((2, 150, 256), 9),
                                        ((3, 280, 96), 9), ((2, 41, 200), 9), ((6, 64, 64), 5), ((2, 200, 256), 13), ((3, 90, 130), 11),
-                                       ((2, 150, 120), 13), ((2, 260, 250), 11)])
+                                       ((2, 150, 120), 13), ((2, 260, 250), 11), ((7, 64, 64), 7), ((3, 130, 60), 7), ((2, 300, 48), 7), ((4, 40, 34), 7)])
 def test_identify_narrow_frames_packed_bands(be, orc, shape, box):
     """Frames at most 256 (128) pixels wide put two (four) bands of a frame side by side in one wavefront
     (boxes 5, 7, 9): heights that leave sub-bands partly or wholly empty, crops that start off the 8-pixel grid,

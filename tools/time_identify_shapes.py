@@ -9,7 +9,7 @@ sys.path.insert(0, ".")
 from picasso_amd import _lib, synth  # noqa: E402
 
 L = _lib.load()
-for H, W in ((64, 64), (128, 128), (256, 256), (512, 512), (1024, 1024), (2048, 2048), (128, 1024), (1024, 128), (512, 200), (300, 300), (512, 511)):
+for H, W in ((64, 64), (128, 128), (256, 256), (512, 512), (1024, 1024), (2048, 2048), (128, 1024), (1024, 128), (1024, 64), (512, 200), (300, 300), (512, 511)):
     F = max(8, int(2.0e9 / (H * W * 2)))
     mov = synth.simulate_movie(F, H, W, emitters_per_frame=max(1, H * W // 2300), device="cuda", chunk_frames=max(1, 2 ** 25 // (H * W)))
     torch.cuda.synchronize()

@@ -141,6 +141,24 @@ int pmi_gaussmle_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y,
                            float *d_thetas, float *d_crlbs, float *d_loglik,
                            int32_t *d_iterations, void *stream);
 
+/* How the Newton loop of pmi_gaussmle* runs.  The reference (picasso/gaussmle.py:745-857 under numba) keeps theta
+ * and its accumulators in float32 arrays and evaluates every per-pixel intermediate in float64; its convergence
+ * test |delta| < eps (:844-852, :632-638) is a discrete decision.
+ *   PMI_MLE_FAST    the float32 loop only: ~1e-5 px from the reference, but a step that lands within rounding
+ *                   distance of eps can end the fit an iteration earlier or later than the reference does;
+ *   PMI_MLE_REFIT   (default) float32 loop, and every spot whose largest tested step came within `margin`
+ *                   (relative) of eps in any iteration, or that ran into max_it, is fitted again from its initial
+ *                   parameters in the reference's own arithmetic (float64 intermediates, float32 stores, the
+ *                   reference's summation order) inside the same call;
+ *   PMI_MLE_STRICT  every spot in the reference's arithmetic.
+ * Process-wide; the environment variable PMI_MLE_MODE = fast | refit | strict overrides the mode.
+ * pmi_mle_last_refit_count: spots the last pmi_gaussmle*_dev / pmi_localize_mle_dev call on `stream` fitted again
+ * (synchronises the stream).                                                 */
+enum pmi_mle_mode { PMI_MLE_FAST = 0, PMI_MLE_REFIT = 1, PMI_MLE_STRICT = 2 };
+int pmi_mle_set_mode(int mode, double margin);
+int pmi_mle_get_mode(int *mode, double *margin);
+int pmi_mle_last_refit_count(int64_t *n_refit, void *stream);
+
 /* ---- locs_from_fits (gaussmle.py:957-1037) ---------------------------- *
  * Builds the 17-column localization table as structure-of-arrays, row i from
  * identification i (rows stay in identification order = frame order).

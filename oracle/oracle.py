@@ -47,6 +47,8 @@ def lib():
         L.orc_get_spots.restype = i32
         L.orc_gaussmle.argtypes = [p, i64, i32, f64, i32, i32, p, p, p, p, i32]
         L.orc_gaussmle.restype = i32
+        L.orc_gaussmle_closeness.argtypes = [p, i64, i32, f64, i32, i32, p, p, p, p, p, i32]
+        L.orc_gaussmle_closeness.restype = i32
         L.orc_initial_parameters.argtypes = [p, i64, i32, p]
         L.orc_initial_parameters.restype = i32
         L.orc_unit_vectors.argtypes = [i32, p, p]
@@ -143,6 +145,25 @@ def gaussmle(spots, eps, max_it, method="sigmaxy", threads=1):
     if rc != 0:
         raise ValueError(f"orc_gaussmle failed ({rc})")
     return thetas, crlbs, ll, it
+
+
+def gaussmle_closeness(spots, eps, max_it, method="sigmaxy", threads=1):
+    """gaussmle plus, per spot, min over the iterations of |D / eps - 1| (D = the largest step the convergence
+    test looks at): the relative margin by which the fit's stop / continue decisions were taken."""
+    spots = np.ascontiguousarray(spots, np.float32)
+    N, box, _ = spots.shape
+    if method not in METHODS:
+        raise ValueError("Method not available.")
+    thetas = np.zeros((N, 6), np.float32)
+    crlbs = np.full((N, 6), np.inf, np.float32)
+    ll = np.zeros(N, np.float32)
+    it = np.zeros(N, np.int32)
+    close = np.zeros(N, np.float32)
+    rc = lib().orc_gaussmle_closeness(_ptr(spots), N, box, float(eps), int(max_it), METHODS[method],
+                                      _ptr(thetas), _ptr(crlbs), _ptr(ll), _ptr(it), _ptr(close), int(threads))
+    if rc != 0:
+        raise ValueError(f"orc_gaussmle_closeness failed ({rc})")
+    return thetas, crlbs, ll, it, close
 
 
 def initial_parameters(spots):

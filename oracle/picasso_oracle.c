@@ -297,8 +297,9 @@ static float mean_filter_min(const float *spot, int size)
     return best;
 }
 
-/* gaussmle.py:94-139; theta6 = x, y, photons, bg, sx, sy as float32 */
-static void initial_parameters(const float *spot, int size, float *theta6)
+/* gaussmle.py:94-139; theta6 = x, y, photons, bg, sx, sy as float32; sxy (optional) receives the
+ * float64 sx, sy that _initial_theta_sigma averages BEFORE the float32 store (:150-153) */
+static void initial_parameters_d(const float *spot, int size, float *theta6, double *sxy)
 {
     double sum, y, x;
     sum_and_com(spot, size, &sum, &y, &x);
@@ -326,7 +327,9 @@ static void initial_parameters(const float *spot, int size, float *theta6)
     if (sy == 0) sy = 0.01;
     theta6[0] = (float)x; theta6[1] = (float)y; theta6[2] = (float)photons_sane;
     theta6[3] = bg; theta6[4] = (float)sx; theta6[5] = (float)sy;
+    if (sxy) { sxy[0] = sx; sxy[1] = sy; }
 }
+static void initial_parameters(const float *spot, int size, float *theta6) { initial_parameters_d(spot, size, theta6, 0); }
 
 /* gaussmle.py:268-280 */
 static inline double gaussian_integral(int x, float mu, float sigma)
@@ -461,14 +464,18 @@ static void pinv_diag_sym(const double *Min, int n, double *diag)
 /* One spot, both methods.  thetas/crlbs rows of 6, as gaussmle.py:455-459
  * allocates them (the caller pre-fills crlbs with +inf, thetas with 0). */
 static void mlefit_one(const float *spot, int size, int method, double eps, int max_it,
-                       float *theta_out, float *crlb_out, float *ll_out, int32_t *it_out)
+                       float *theta_out, float *crlb_out, float *ll_out, int32_t *it_out, float *closeness)
 {
+    /* closeness (optional, not part of the reference): min over the iterations of |D / eps - 1|, D = the largest
+     * of the steps the convergence test looks at — how close the fit came to deciding the other way */
+    float close = INFINITY;
     const int np_ = method == ORC_SIGMAXY ? 6 : 5;
     float theta[6], init[6];
-    initial_parameters(spot, size, init);
+    double sxy[2];
+    initial_parameters_d(spot, size, init, sxy);
     theta[0] = init[0]; theta[1] = init[1]; theta[2] = init[2]; theta[3] = init[3];
     if (method == ORC_SIGMAXY) { theta[4] = init[4]; theta[5] = init[5]; }
-    else { theta[4] = (float)(((double)init[4] + (double)init[5]) / 2); theta[5] = 0.0f; }
+    else { theta[4] = (float)((sxy[0] + sxy[1]) / 2); theta[5] = 0.0f; }   /* float64 mean, then the float32 store */
 
     float max_step[6];
     max_step[0] = theta[4]; max_step[1] = theta[4];
@@ -531,6 +538,12 @@ static void mlefit_one(const float *spot, int size, int method, double eps, int 
             theta[5] = (float)np_max((double)theta[5], 0.01);
             int conv = ((double)fabsf(old_x - theta[0]) < eps) && ((double)fabsf(old_y - theta[1]) < eps)
                        && ((double)fabsf(old_sx - theta[4]) < eps) && ((double)fabsf(old_sy - theta[5]) < eps);
+            {
+                float D = fmaxf(fmaxf(fabsf(old_x - theta[0]), fabsf(old_y - theta[1])),
+                                fmaxf(fabsf(old_sx - theta[4]), fabsf(old_sy - theta[5])));
+                float c = (float)fabs((double)D / eps - 1.0);
+                if (c < close) close = c;
+            }
             if (conv) break;
             old_x = theta[0]; old_y = theta[1]; old_sx = theta[4]; old_sy = theta[5];
         } else {                                                       /* gaussmle.py:647-670 */
@@ -545,6 +558,11 @@ static void mlefit_one(const float *spot, int size, int method, double eps, int 
             theta[4] = (float)np_max((double)theta[4], 0.01);
             theta[4] = (float)np_min((double)theta[4], (double)size);
             int conv = ((double)fabsf(old_x - theta[0]) < eps) && ((double)fabsf(old_y - theta[1]) < eps);
+            {
+                float D = fmaxf(fabsf(old_x - theta[0]), fabsf(old_y - theta[1]));
+                float c = (float)fabs((double)D / eps - 1.0);
+                if (c < close) close = c;
+            }
             if (conv) break;
             old_x = theta[0]; old_y = theta[1];
         }
@@ -552,6 +570,7 @@ static void mlefit_one(const float *spot, int size, int method, double eps, int 
     for (int l = 0; l < 5; l++) theta_out[l] = theta[l];
     theta_out[5] = method == ORC_SIGMAXY ? theta[5] : theta[4];
     *it_out = kk;
+    if (closeness) *closeness = close;
 
     /* CRLB and log-likelihood (gaussmle.py:673-742, 887-954) */
     double M[36];
@@ -612,7 +631,27 @@ int orc_gaussmle(const float *spots, int64_t N, int box, double eps, int max_it,
     for (int64_t i = 0; i < N; i++) {
         for (int l = 0; l < 6; l++) { thetas[i * 6 + l] = 0.0f; crlbs[i * 6 + l] = INFINITY; }
         mlefit_one(spots + i * box * box, box, method, eps, max_it,
-                   thetas + i * 6, crlbs + i * 6, loglik + i, iterations + i);
+                   thetas + i * 6, crlbs + i * 6, loglik + i, iterations + i, 0);
+    }
+    return 0;
+}
+
+/* The same fit, additionally reporting per spot how close its convergence test came to the other outcome
+ * (see mlefit_one).  Used by the tests to bound the margin inside which the float32 device loop may disagree. */
+int orc_gaussmle_closeness(const float *spots, int64_t N, int box, double eps, int max_it, int method,
+                           float *thetas, float *crlbs, float *loglik, int32_t *iterations, float *closeness,
+                           int nthreads)
+{
+    if (box < 1 || box > ORC_MAX_BOX) return -1;
+    if (method != ORC_SIGMA && method != ORC_SIGMAXY) return -2;
+#ifdef _OPENMP
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel for schedule(dynamic, 64) num_threads(nthreads)
+#endif
+    for (int64_t i = 0; i < N; i++) {
+        for (int l = 0; l < 6; l++) { thetas[i * 6 + l] = 0.0f; crlbs[i * 6 + l] = INFINITY; }
+        mlefit_one(spots + i * box * box, box, method, eps, max_it,
+                   thetas + i * 6, crlbs + i * 6, loglik + i, iterations + i, closeness + i);
     }
     return 0;
 }

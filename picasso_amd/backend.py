@@ -133,6 +133,31 @@ def get_spots_array(movie: np.ndarray, frame, y, x, box: int, baseline, sensitiv
     return spots
 
 
+MLE_MODES = {"fast": 0, "refit": 1, "strict": 2}
+
+
+def set_mle_mode(mode: str = "refit", margin: float = 0.001):
+    """How the Newton loop of the MLE fit runs (pmi_mle_set_mode): "fast" = float32 loop only; "refit" (default) =
+    float32 loop, then spots whose convergence decision (picasso/gaussmle.py:844-852) came within `margin` of eps
+    are fitted again in the reference's float64-intermediate arithmetic; "strict" = every spot that way."""
+    if mode not in MLE_MODES:
+        raise ValueError(f"unknown MLE mode {mode!r}")
+    _lib.check(_lib.load().pmi_mle_set_mode(MLE_MODES[mode], float(margin)), "pmi_mle_set_mode")
+
+
+def get_mle_mode():
+    m, g = ctypes.c_int(0), ctypes.c_double(0)
+    _lib.check(_lib.load().pmi_mle_get_mode(ctypes.byref(m), ctypes.byref(g)), "pmi_mle_get_mode")
+    return {v: k for k, v in MLE_MODES.items()}[m.value], g.value
+
+
+def last_refit_count(stream=None) -> int:
+    """Spots the last MLE call fitted a second time (synchronises `stream`)."""
+    n = ctypes.c_int64(0)
+    _lib.check(_lib.load().pmi_mle_last_refit_count(ctypes.byref(n), stream), "pmi_mle_last_refit_count")
+    return int(n.value)
+
+
 def gaussmle_arrays(spots: np.ndarray, eps: float, max_it: int, method: str = "sigmaxy"):
     """The allocation contract of picasso/gaussmle.py:455-459."""
     if method not in _lib.MLE_METHODS:

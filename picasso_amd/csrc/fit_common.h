@@ -57,8 +57,17 @@ struct FitParams {
     unsigned long long *queue;   // dynamic spot queue of this batch (counts from 0)
     int64_t first;               // first spot of this batch; the kernel handles [first, min(N, *d_n))
     double *fisher;              // upper triangle of the Fisher matrix, 21 doubles per spot of the batch
+    // borderline-convergence flags (gaussmle_strict.hip): a spot whose largest tested step |delta| came within
+    // [eps_lo, eps_hi) of eps in any iteration, or that ran into max_it, is appended to flag_list
+    float eps_lo, eps_hi;
+    int32_t *flag_list;          // spot indices, capacity = spots of the batch (nullptr: no flagging)
+    unsigned *flag_count;
 };
 constexpr int FISHER_STRIDE = 21;
+enum { FIT_STAGE_NEWTON = 1, FIT_STAGE_FINAL = 2 };
+// a fit that takes more iterations than this is re-fitted whatever its steps were: it spent dozens of iterations
+// within a few percent of eps and the float32 loop has drifted (config 2: four spots in ten thousand)
+constexpr int FIT_SLOW_ITERATIONS = 32;
 
 // ---- DPP wave reductions -------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xf>

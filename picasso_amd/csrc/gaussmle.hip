@@ -18,14 +18,26 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <vector>
 
 #include "fit_common.h"
 
 namespace pmi {
 
+// Spots to fit again in the reference's arithmetic (gaussmle_strict.hip): the largest tested step D of iteration
+// kk (counted from 1) lies within the margin [eps_lo, eps_hi) of eps, widened with the iteration count (a slow fit
+// takes many steps close to eps and the float32 loop drifts from the reference by more than a few ulps)
+__device__ __forceinline__ bool borderline(float D, int kk, float eps_lo, float eps_hi)
+{
+    const float wide = fmaxf(1.0f, (float)(kk - 1) * 0.0625f);
+    const float epsf = 0.5f * (eps_lo + eps_hi), epsm = 0.5f * (eps_hi - eps_lo) * wide;
+    return (D >= epsf - epsm && D < epsf + epsm) || kk > FIT_SLOW_ITERATIONS;
+}
+
 // NP = params (5: "sigma", 6: "sigmaxy"); PPL = pixels per lane = ceil(box^2/64)
 template <int NP, int PPL, bool FROM_MOVIE>
-__global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p)
+__global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p, int stages)
 {
     __shared__ float s_spot[FIT_WAVES][FIT_MAXPIX + 7];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -75,6 +87,13 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p)
         __builtin_amdgcn_wave_barrier();
         __threadfence_block();
 
+        float th[6];
+        int kk = 0;
+        if (!(stages & FIT_STAGE_NEWTON)) {          // thetas in memory (re-fitted spots included): final stage only
+#pragma unroll
+            for (int l = 0; l < 6; l++) th[l] = p.thetas[sidx * 6 + l];
+            kk = p.iterations[sidx];
+        } else {
         // ---- initial parameters (gaussmle.py:28-139) -------------------
         double ds = 0.0, dsy = 0.0, dsx = 0.0;
         float fmin_local = INFINITY;
@@ -115,7 +134,6 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p)
         if (isx == 0) isx = 0.01;
         if (isy == 0) isy = 0.01;
 
-        float th[6];
         th[0] = (float)com_x; th[1] = (float)com_y; th[2] = (float)photons; th[3] = bg0;
         if (NP == 6) { th[4] = (float)isx; th[5] = (float)isy; }
         else { th[4] = (float)((isx + isy) / 2); th[5] = 0.f; }
@@ -125,7 +143,7 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p)
         ms[4] = (float)(0.2 * (double)th[4]); ms[5] = (float)(0.2 * (double)th[5]);
 
         float old_x = th[0], old_y = th[1], old_sx = th[4], old_sy = th[5];
-        int kk = 0;
+        bool flagged = false, conv = false;
         while (kk < p.max_it) {
             kk++;
             float num[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, den[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
@@ -165,7 +183,10 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p)
                 }
             }
 #pragma unroll
-            for (int l = 0; l < NP; l++) { num[l] = wave_sum(num[l]); den[l] = wave_sum(den[l]); }
+            for (int l = 0; l < NP; l++) {
+                num[l] = wave_sum(num[l]); den[l] = wave_sum(den[l]);
+                flagged = flagged || den[l] >= 0.0f;          // curvature not negative: chaotic trajectory (see borderline())
+            }
 
             if (NP == 6) {                                  // gaussmle.py:860-884
 #pragma unroll
@@ -175,8 +196,11 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p)
                 }
                 th[2] = np_maxf(th[2], 1.0f); th[3] = np_maxf(th[3], 0.01f);
                 th[4] = np_maxf(th[4], 0.01f); th[5] = np_maxf(th[5], 0.01f);
-                bool conv = ((double)fabsf(old_x - th[0]) < p.eps) && ((double)fabsf(old_y - th[1]) < p.eps) &&
-                            ((double)fabsf(old_sx - th[4]) < p.eps) && ((double)fabsf(old_sy - th[5]) < p.eps);
+                // largest tested step; NaN (never converged in the reference) must win the maximum
+                const float dx = fabsf(old_x - th[0]), dy = fabsf(old_y - th[1]), dsx_ = fabsf(old_sx - th[4]), dsy_ = fabsf(old_sy - th[5]);
+                const float D = __uint_as_float(max(max(__float_as_uint(dx), __float_as_uint(dy)), max(__float_as_uint(dsx_), __float_as_uint(dsy_))));
+                conv = (double)D < p.eps;
+                flagged = flagged || borderline(D, kk, p.eps_lo, p.eps_hi);
                 if (conv) break;
                 old_x = th[0]; old_y = th[1]; old_sx = th[4]; old_sy = th[5];
             } else {                                        // gaussmle.py:647-670
@@ -189,11 +213,25 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p)
                 }
                 th[2] = np_maxf(th[2], 1.0f); th[3] = np_maxf(th[3], 0.01f);
                 th[4] = np_maxf(th[4], 0.01f); th[4] = np_minf(th[4], (float)box);
-                bool conv = ((double)fabsf(old_x - th[0]) < p.eps) && ((double)fabsf(old_y - th[1]) < p.eps);
+                const float dx = fabsf(old_x - th[0]), dy = fabsf(old_y - th[1]);
+                const float D = __uint_as_float(max(__float_as_uint(dx), __float_as_uint(dy)));
+                conv = (double)D < p.eps;
+                flagged = flagged || borderline(D, kk, p.eps_lo, p.eps_hi);
                 if (conv) break;
                 old_x = th[0]; old_y = th[1];
             }
         }
+        if (!conv && p.max_it > 0 && th[0] == th[0]) flagged = true;      // ran into max_it
+        if (lane == 0) {
+            float *to = p.thetas + sidx * 6;
+#pragma unroll
+            for (int l = 0; l < 5; l++) to[l] = th[l];
+            to[5] = NP == 6 ? th[5] : th[4];
+            p.iterations[sidx] = kk;
+            if (flagged && p.flag_list) p.flag_list[atomicAdd(p.flag_count, 1u)] = (int32_t)sidx;
+        }
+        }   // FIT_STAGE_NEWTON
+        if (!(stages & FIT_STAGE_FINAL)) { __builtin_amdgcn_wave_barrier(); continue; }
 
         // ---- CRLB and log-likelihood (gaussmle.py:673-742, 887-954) ----
         double Mloc[21];
@@ -241,12 +279,7 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p)
         }
         const float ll = wave_sum(ll_loc);
         if (lane == 0) {
-            float *to = p.thetas + sidx * 6;
-#pragma unroll
-            for (int l = 0; l < 5; l++) to[l] = th[l];
-            to[5] = NP == 6 ? th[5] : th[4];
             p.loglik[sidx] = ll;
-            p.iterations[sidx] = kk;
             double *fo = p.fisher + (sidx - (unsigned long long)p.first) * FISHER_STRIDE;
 #pragma unroll
             for (int e = 0; e < NP * (NP + 1) / 2; e++) fo[e] = Msum[e];
@@ -359,22 +392,46 @@ __global__ __launch_bounds__(256) void crlb_kernel(const double *__restrict__ fi
 }
 
 template <int NP, bool FROM_MOVIE>
-static void launch_fit_ppl(int ppl, dim3 grid, hipStream_t s, const FitParams &p)
+static void launch_fit_ppl(int ppl, dim3 grid, hipStream_t s, const FitParams &p, int stages)
 {
     switch (ppl) {
-    case 1: hipLaunchKernelGGL((mle_fit_kernel<NP, 1, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
-    case 2: hipLaunchKernelGGL((mle_fit_kernel<NP, 2, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
-    case 3: hipLaunchKernelGGL((mle_fit_kernel<NP, 3, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
-    case 4: hipLaunchKernelGGL((mle_fit_kernel<NP, 4, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
-    case 5: hipLaunchKernelGGL((mle_fit_kernel<NP, 5, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
-    case 6: hipLaunchKernelGGL((mle_fit_kernel<NP, 6, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
-    default: hipLaunchKernelGGL((mle_fit_kernel<NP, 7, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p); break;
+    case 1: hipLaunchKernelGGL((mle_fit_kernel<NP, 1, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p, stages); break;
+    case 2: hipLaunchKernelGGL((mle_fit_kernel<NP, 2, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p, stages); break;
+    case 3: hipLaunchKernelGGL((mle_fit_kernel<NP, 3, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p, stages); break;
+    case 4: hipLaunchKernelGGL((mle_fit_kernel<NP, 4, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p, stages); break;
+    case 5: hipLaunchKernelGGL((mle_fit_kernel<NP, 5, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p, stages); break;
+    case 6: hipLaunchKernelGGL((mle_fit_kernel<NP, 6, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p, stages); break;
+    default: hipLaunchKernelGGL((mle_fit_kernel<NP, 7, FROM_MOVIE>), grid, dim3(FIT_NT), 0, s, p, stages); break;
     }
 }
 
 static int g_cu_count = 0;
 
-bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, float *state, hipStream_t s);   // gaussmle_g8.hip
+bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, float *state, int stages, hipStream_t s);   // gaussmle_g8.hip
+void launch_fit_strict(const FitParams &p, int method, bool from_movie, const int32_t *list, const unsigned *list_n,
+                       int64_t max_items, int cu_count, hipStream_t s);                                                    // gaussmle_strict.hip
+
+// How the Newton loop is run (pmi_mle_set_mode):
+//   PMI_MLE_FAST    float32 loop only (round-1 behaviour; a borderline |delta| < eps decision may fall the other way
+//                   than in the reference's float64 arithmetic)
+//   PMI_MLE_REFIT   float32 loop; spots whose decisive step came within `margin` (relative) of eps, or that ran into
+//                   max_it, are re-fitted in the reference's arithmetic (default)
+//   PMI_MLE_STRICT  every spot in the reference's arithmetic
+static int g_mle_mode = PMI_MLE_REFIT;
+static double g_mle_margin = 0.001;
+static const unsigned *g_last_flag_counts = nullptr;     // device, one counter per batch of the last call
+static int64_t g_last_flag_batches = 0;
+
+static int mle_mode_now()
+{
+    static const char *env = getenv("PMI_MLE_MODE");      // "fast" | "refit" | "strict" overrides pmi_mle_set_mode
+    if (env) {
+        if (!strcmp(env, "fast")) return PMI_MLE_FAST;
+        if (!strcmp(env, "strict")) return PMI_MLE_STRICT;
+        if (!strcmp(env, "refit")) return PMI_MLE_REFIT;
+    }
+    return g_mle_mode;
+}
 
 int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
 {
@@ -388,40 +445,72 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         PMI_HIP(hipGetDevice(&dev));
         PMI_HIP(hipDeviceGetAttribute(&g_cu_count, hipDeviceAttributeMultiprocessorCount, dev));
     }
+    const int mode = mle_mode_now();
     // Spots are processed in batches so that the Fisher scratch (168 B per spot) stays bounded;
-    // every batch has its own queue word.  With a device-side row count (d_n) the batches past
-    // the count exit immediately.
+    // every batch has its own queue words and flag counter.  With a device-side row count (d_n) the
+    // batches past the count exit immediately.
     const int64_t BATCH = 1 << 22;
     const int64_t nb = (p.N + BATCH - 1) / BATCH;
     void *ptr = nullptr, *fptr = nullptr;
     int rc;
-    if ((rc = scratch(SCR_FIT, (size_t)nb * 8 + 64, &ptr)) != PMI_OK) return rc;
-    // per spot of a batch: 21 doubles of Fisher triangle + 12 floats of Newton start state
+    // per batch: two queue words (Newton stage, final stage) and the flag counter
+    if ((rc = scratch(SCR_FIT, (size_t)nb * 24 + 64, &ptr)) != PMI_OK) return rc;
+    // per spot of a batch: 21 doubles of Fisher triangle + 12 floats of Newton start state + a flag-list slot
     const size_t per_batch = (size_t)std::min<int64_t>(p.N, BATCH);
-    if ((rc = scratch(SCR_STAGE_D, per_batch * (FISHER_STRIDE * sizeof(double) + 12 * sizeof(float)), &fptr)) != PMI_OK) return rc;
+    if ((rc = scratch(SCR_STAGE_D, per_batch * (FISHER_STRIDE * sizeof(double) + 12 * sizeof(float) + sizeof(int32_t)), &fptr)) != PMI_OK) return rc;
     float *state = reinterpret_cast<float *>((char *)fptr + per_batch * FISHER_STRIDE * sizeof(double));
-    PMI_HIP(hipMemsetAsync(ptr, 0, (size_t)nb * 8, s));
+    int32_t *flag_list = reinterpret_cast<int32_t *>(state + per_batch * 12);
+    PMI_HIP(hipMemsetAsync(ptr, 0, (size_t)nb * 24, s));
+    unsigned long long *queues = (unsigned long long *)ptr;
+    unsigned *flag_counts = (unsigned *)(queues + 2 * nb);
+    g_last_flag_counts = flag_counts;
+    g_last_flag_batches = mode == PMI_MLE_REFIT ? nb : 0;
     p.fisher = (double *)fptr;
+    static const char *menv = getenv("PMI_MLE_MARGIN");       // overrides the margin of pmi_mle_set_mode (tuning runs)
+    const double margin = menv ? atof(menv) : g_mle_margin;
+    // The tested step |delta| is a difference of float32 coordinates near box/2, i.e. a multiple of their ulp: the
+    // two arithmetics differ by a few ulps there, so the margin is never smaller than four of them
+    // (7x7: 9.5e-7 = eps/1000 at the default eps; 13x13: 1.9e-6; 17x17 and up: 3.8e-6).
+    const double ulp = ldexp(1.0, (int)floor(log2(std::max(1.0, p.box / 2.0))) - 23);
+    const double margin_abs = std::max(p.eps * margin, 4.0 * ulp);
+    p.eps_lo = (float)(p.eps - margin_abs);
+    p.eps_hi = (float)(p.eps + margin_abs);
     const int ppl = (p.box * p.box + 63) / 64;
     const int64_t Ntotal = p.N;
     ScopedKernelTimer tm(s, &g_last_times.fit_ms);
     static const bool force_wave_per_spot = getenv("PMI_FIT_WAVE_PER_SPOT") != nullptr;
+    const bool g8 = !force_wave_per_spot && p.box <= 15;
     for (int64_t bi = 0; bi < nb; bi++) {
         p.first = bi * BATCH;
         p.N = std::min<int64_t>(Ntotal, p.first + BATCH);
-        p.queue = (unsigned long long *)ptr + bi;
+        p.flag_list = mode == PMI_MLE_REFIT ? flag_list : nullptr;
+        p.flag_count = flag_counts + bi;
         const int64_t count = p.N - p.first;
-        // boxes <= 15: eight or four spots per wavefront (gaussmle_g8.hip); boxes 17..21: one wavefront per spot
-        if (!force_wave_per_spot && launch_fit_g8(p, method, from_movie, g_cu_count, state, s)) {
-        } else {
-            int64_t blocks = std::min<int64_t>((count + FIT_WAVES - 1) / FIT_WAVES, (int64_t)g_cu_count * 8);
-            dim3 grid((unsigned)std::max<int64_t>(blocks, 1));
+        const int64_t blocks = std::min<int64_t>((count + FIT_WAVES - 1) / FIT_WAVES, (int64_t)g_cu_count * 8);
+        const dim3 grid((unsigned)std::max<int64_t>(blocks, 1));
+        auto wave_per_spot = [&](int stages) {
+            p.queue = queues + 2 * bi + (stages == FIT_STAGE_FINAL ? 1 : 0);
             if (method == PMI_MLE_SIGMAXY) {
-                if (from_movie) launch_fit_ppl<6, true>(ppl, grid, s, p); else launch_fit_ppl<6, false>(ppl, grid, s, p);
+                if (from_movie) launch_fit_ppl<6, true>(ppl, grid, s, p, stages); else launch_fit_ppl<6, false>(ppl, grid, s, p, stages);
             } else {
-                if (from_movie) launch_fit_ppl<5, true>(ppl, grid, s, p); else launch_fit_ppl<5, false>(ppl, grid, s, p);
+                if (from_movie) launch_fit_ppl<5, true>(ppl, grid, s, p, stages); else launch_fit_ppl<5, false>(ppl, grid, s, p, stages);
             }
+        };
+        // Newton stage: boxes <= 15 run eight or four spots per wavefront (gaussmle_g8.hip), boxes 17..21 one
+        // wavefront per spot; then the flagged spots again in the reference's arithmetic; then Fisher matrix and
+        // log-likelihood at the final thetas
+        if (mode == PMI_MLE_STRICT) {
+            launch_fit_strict(p, method, from_movie, nullptr, nullptr, count, g_cu_count, s);
+        } else {
+            if (g8) launch_fit_g8(p, method, from_movie, g_cu_count, state, FIT_STAGE_NEWTON, s);
+            else wave_per_spot(FIT_STAGE_NEWTON);
+            PMI_HIP(hipGetLastError());
+            if (mode == PMI_MLE_REFIT)
+                launch_fit_strict(p, method, from_movie, flag_list, p.flag_count, count, g_cu_count, s);
         }
+        PMI_HIP(hipGetLastError());
+        if (g8) launch_fit_g8(p, method, from_movie, g_cu_count, state, FIT_STAGE_FINAL, s);
+        else wave_per_spot(FIT_STAGE_FINAL);
         PMI_HIP(hipGetLastError());
         const unsigned cb = (unsigned)((count + 255) / 256);
         if (method == PMI_MLE_SIGMAXY)
@@ -496,6 +585,37 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
 }  // namespace pmi
 
 extern "C" {
+
+int pmi_mle_set_mode(int mode, double margin)
+{
+    using namespace pmi;
+    if (mode != PMI_MLE_FAST && mode != PMI_MLE_REFIT && mode != PMI_MLE_STRICT) { set_error("unknown MLE mode %d", mode); return PMI_ERR_ARG; }
+    if (!(margin >= 0.0 && margin < 1.0)) { set_error("margin must lie in [0, 1)"); return PMI_ERR_ARG; }
+    g_mle_mode = mode;
+    g_mle_margin = margin;
+    return PMI_OK;
+}
+
+int pmi_mle_get_mode(int *mode, double *margin)
+{
+    if (mode) *mode = pmi::mle_mode_now();
+    if (margin) *margin = pmi::g_mle_margin;
+    return PMI_OK;
+}
+
+int pmi_mle_last_refit_count(int64_t *n_refit, void *stream)
+{
+    using namespace pmi;
+    int64_t total = 0;
+    if (g_last_flag_batches > 0) {
+        std::vector<unsigned> h((size_t)g_last_flag_batches);
+        PMI_HIP(hipStreamSynchronize((hipStream_t)stream));
+        PMI_HIP(hipMemcpy(h.data(), g_last_flag_counts, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
+        for (unsigned v : h) total += v;
+    }
+    if (n_refit) *n_refit = total;
+    return PMI_OK;
+}
 
 int pmi_gaussmle_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box, double eps, int max_it,
                      int method, float *d_thetas, float *d_crlbs, float *d_loglik, int32_t *d_iterations,

@@ -72,6 +72,19 @@ template <int GS> __device__ __forceinline__ double gsum_d(double v)
     if (GS == 16) v += dpp_d<0x140>(v);
     return v;
 }
+// group maximum of unsigned values (bit patterns of non-negative floats order like the floats, NaN on top)
+template <int CTRL> __device__ __forceinline__ unsigned dpp_u(unsigned v)
+{
+    return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
+}
+template <int GS> __device__ __forceinline__ unsigned gmax_u(unsigned v)
+{
+    v = max(v, dpp_u<0xB1>(v));
+    v = max(v, dpp_u<0x4E>(v));
+    v = max(v, dpp_u<0x141>(v));
+    if (GS == 16) v = max(v, dpp_u<0x140>(v));
+    return v;
+}
 // value of lane+1 / lane-1 (0 past the 16-lane DPP row; callers mask the group edges)
 __device__ __forceinline__ float from_next(float v) { return dpp_f<0x101>(v); }   // row_shl:1
 __device__ __forceinline__ double from_next_d(double v) { return dpp_d<0x101>(v); }
@@ -187,7 +200,8 @@ struct LaneRole {          // what lane j does in the update stage: parameter j 
 
 template <int NP, int B>
 __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6], LaneRole &role, float *lds,
-                                            int j, bool rowok, bool active, int &kk, double eps, int max_it)
+                                            int j, bool rowok, bool active, int &kk, double eps, int max_it,
+                                            float eps_lo, float eps_hi, bool &flagged)
 {
     constexpr int GS = GroupOf<B>::GS;
     float *cols = lds, *red = lds + GS * 12, *bc = lds + 2 * GS * 12;
@@ -275,10 +289,18 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
     float nt = role.th - (denl == 0.0f ? stepz : stepn);
     nt = max_np(nt, role.floor_);
     nt = min_np(nt, role.cap);
-    const bool conv_l = !role.conv_rel || ((double)fabsf(role.th - nt) < eps);
-    const unsigned long long vote = __ballot(conv_l);
-    constexpr unsigned long long gmask = GS == 8 ? 0xffull : 0xffffull;
-    const bool conv = ((vote >> (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & ~(unsigned)(GS - 1))) & gmask) == gmask;
+    // D = the largest of the tested steps |delta| (x, y and for sigmaxy the two sigmas, gaussmle.py:844-852 /
+    // :632-638); a NaN step stays on top of the unsigned maximum, so D is NaN and the test fails like the reference's
+    const float D = __uint_as_float(gmax_u<GS>(role.conv_rel ? __float_as_uint(fabsf(role.th - nt)) : 0u));
+    const bool conv = (double)D < eps;
+    // a decision taken within the margin of eps may fall the other way in the reference's float64 arithmetic:
+    // such spots are re-fitted by mle_strict_kernel (gaussmle_strict.hip)
+    // (the margin widens with the iteration count: a slow fit takes many steps close to eps and the two arithmetics
+    // drift apart by more than a few ulps), and so are spots whose curvature term is not negative for some
+    // parameter — the update then runs uphill or into its clamp and the trajectory is chaotic in any arithmetic
+    const float wide = fmaxf(1.0f, (float)kk * 0.0625f);
+    const float epsf = 0.5f * (eps_lo + eps_hi), epsm = 0.5f * (eps_hi - eps_lo) * wide;
+    flagged = flagged || (active && ((D >= epsf - epsm && D < epsf + epsm) || (j < NP && denl >= 0.0f) || kk >= FIT_SLOW_ITERATIONS));
     // the previous-iteration values the reference compares with ARE th (old_x = theta after every pass);
     // finished groups keep their state
     role.th = active ? nt : role.th;
@@ -292,6 +314,7 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
         if (NP == 6) th[5] = t1.y;
     }
     kk += active ? 1 : 0;
+    flagged = flagged || (active && !conv && kk >= max_it && D == D);      // ran into max_it: chaotic in float32
     return active && !(conv || kk >= max_it);
 }
 
@@ -439,7 +462,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
     LaneRole role = make_role<NP, B>(th, ms, j);
     int kk = 0;
     int64_t sidx = -1;
-    bool active = false;
+    bool active = false, flagged = false;
     const unsigned long long below = (1ull << (lane & ~(GS - 1))) - 1ull;     // lanes of lower groups
 
     for (;;) {
@@ -452,12 +475,16 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
         const bool any_active = __any(active);
         if (__popcll(pend) >= REFILL_K || (pend != 0 && !any_active) || (empty != 0 && next < end)) {
             // finished groups publish theta / iteration count, then take the next spots of the chunk
+            // (the curvature flag is per parameter lane: any lane of the group flags the spot)
+            constexpr unsigned long long gmask = GS == 8 ? 0xffull : 0xffffull;
+            const bool gflag = ((__ballot(flagged) >> (lane & ~(GS - 1))) & gmask) != 0;
             if (!active && sidx >= 0 && j == 0) {
                 float *to = p.thetas + sidx * 6;
 #pragma unroll
                 for (int l = 0; l < 5; l++) to[l] = th[l];
                 to[5] = NP == 6 ? th[5] : th[4];
                 p.iterations[sidx] = kk;
+                if (gflag && p.flag_list) p.flag_list[atomicAdd(p.flag_count, 1u)] = (int32_t)sidx;
             }
             const unsigned long long want = pend | empty;
             const int64_t cand = next + __popcll(want & below);
@@ -472,6 +499,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
                     load_row<B, FROM_MOVIE>(p, sidx, j, rowok, d);
                     role = make_role<NP, B>(th, ms, j);
                     kk = 0;
+                    flagged = false;
                     active = p.max_it > 0;
                     if (!active && j == 0) {          // max_it == 0: the initial theta is the result
                         float *to = p.thetas + sidx * 6;
@@ -491,7 +519,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
         } else if (!any_active) {
             break;                                     // nothing running, nothing pending, chunk exhausted
         }
-        active = newton_step<NP, B>(d, th, role, xs, j, rowok, active, kk, p.eps, p.max_it);
+        active = newton_step<NP, B>(d, th, role, xs, j, rowok, active, kk, p.eps, p.max_it, p.eps_lo, p.eps_hi, flagged);
     }
 }
 
@@ -621,8 +649,10 @@ __global__ __launch_bounds__(FIT_NT) void g8_final_kernel(FitParams p)
     if (spot_ok && j == 0) p.loglik[sidx] = ll;
 }
 
+// stages: FIT_STAGE_NEWTON = initial parameters + Newton iterations (thetas, iterations, borderline flags),
+// FIT_STAGE_FINAL = Fisher matrix and log-likelihood at the thetas in memory
 template <int NP, int B, bool FROM_MOVIE>
-static void launch_g8(const FitParams &p, float *state, int cu_count, hipStream_t s)
+static void launch_g8(const FitParams &p, float *state, int cu_count, int stages, hipStream_t s)
 {
     constexpr int NSPW = 64 / GroupOf<B>::GS;
     const int64_t count = p.N - p.first;
@@ -631,34 +661,36 @@ static void launch_g8(const FitParams &p, float *state, int cu_count, hipStream_
     // persistent iterate grid: 6 workgroups (24 waves, 73 VGPRs each) per CU, each wave owning >= 64 spots when possible
     const int64_t pw = std::max<int64_t>(1, std::min<int64_t>((int64_t)cu_count * 24, (count + 63) / 64));
     const dim3 pers((unsigned)((pw + FIT_WAVES - 1) / FIT_WAVES));
-    hipLaunchKernelGGL((g8_init_kernel<NP, B, FROM_MOVIE>), flat, dim3(FIT_NT), 0, s, p, state);
-    hipLaunchKernelGGL((g8_iterate_kernel<NP, B, FROM_MOVIE>), pers, dim3(FIT_NT), 0, s, p, (const float *)state);
-    hipLaunchKernelGGL((g8_final_kernel<NP, B, FROM_MOVIE>), flat, dim3(FIT_NT), 0, s, p);
+    if (stages & FIT_STAGE_NEWTON) {
+        hipLaunchKernelGGL((g8_init_kernel<NP, B, FROM_MOVIE>), flat, dim3(FIT_NT), 0, s, p, state);
+        hipLaunchKernelGGL((g8_iterate_kernel<NP, B, FROM_MOVIE>), pers, dim3(FIT_NT), 0, s, p, (const float *)state);
+    }
+    if (stages & FIT_STAGE_FINAL)
+        hipLaunchKernelGGL((g8_final_kernel<NP, B, FROM_MOVIE>), flat, dim3(FIT_NT), 0, s, p);
 }
 
 template <int NP, bool FROM_MOVIE>
-static void launch_g8_box(const FitParams &p, float *state, int cu_count, hipStream_t s)
+static void launch_g8_box(const FitParams &p, float *state, int cu_count, int stages, hipStream_t s)
 {
     switch (p.box) {
-    case 3: launch_g8<NP, 3, FROM_MOVIE>(p, state, cu_count, s); break;
-    case 5: launch_g8<NP, 5, FROM_MOVIE>(p, state, cu_count, s); break;
-    case 7: launch_g8<NP, 7, FROM_MOVIE>(p, state, cu_count, s); break;
-    case 9: launch_g8<NP, 9, FROM_MOVIE>(p, state, cu_count, s); break;
-    case 11: launch_g8<NP, 11, FROM_MOVIE>(p, state, cu_count, s); break;
-    case 13: launch_g8<NP, 13, FROM_MOVIE>(p, state, cu_count, s); break;
-    default: launch_g8<NP, 15, FROM_MOVIE>(p, state, cu_count, s); break;
+    case 3: launch_g8<NP, 3, FROM_MOVIE>(p, state, cu_count, stages, s); break;
+    case 5: launch_g8<NP, 5, FROM_MOVIE>(p, state, cu_count, stages, s); break;
+    case 7: launch_g8<NP, 7, FROM_MOVIE>(p, state, cu_count, stages, s); break;
+    case 9: launch_g8<NP, 9, FROM_MOVIE>(p, state, cu_count, stages, s); break;
+    case 11: launch_g8<NP, 11, FROM_MOVIE>(p, state, cu_count, stages, s); break;
+    case 13: launch_g8<NP, 13, FROM_MOVIE>(p, state, cu_count, stages, s); break;
+    default: launch_g8<NP, 15, FROM_MOVIE>(p, state, cu_count, stages, s); break;
     }
 }
 
-// boxes 3, 5, 7: eight spots per wavefront.  `state` = 12 floats per spot of the batch.
-// Returns false when the box is not handled.
-bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, float *state, hipStream_t s)
+// boxes 3..15.  `state` = 12 floats per spot of the batch.  Returns false when the box is not handled.
+bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, float *state, int stages, hipStream_t s)
 {
     if (p.box > 15) return false;
     if (method == PMI_MLE_SIGMAXY) {
-        if (from_movie) launch_g8_box<6, true>(p, state, cu_count, s); else launch_g8_box<6, false>(p, state, cu_count, s);
+        if (from_movie) launch_g8_box<6, true>(p, state, cu_count, stages, s); else launch_g8_box<6, false>(p, state, cu_count, stages, s);
     } else {
-        if (from_movie) launch_g8_box<5, true>(p, state, cu_count, s); else launch_g8_box<5, false>(p, state, cu_count, s);
+        if (from_movie) launch_g8_box<5, true>(p, state, cu_count, stages, s); else launch_g8_box<5, false>(p, state, cu_count, stages, s);
     }
     return true;
 }

@@ -1,0 +1,379 @@
+// gaussmle_strict.hip — the MLE Newton loop in the reference's own arithmetic.
+//
+// picasso/gaussmle.py runs under numba: theta, the per-pixel derivative arrays and the
+// numerator / denominator accumulators are float32 ARRAYS, every scalar intermediate is
+// float64 (int64 pixel index - float32 theta -> float64), and the pixel loop is sequential
+// (ii = column outer, jj = row inner, :798-839).  The fast kernels (gaussmle_g8.hip,
+// gaussmle.hip) run that loop in float32; their result agrees to ~1e-5 px, but the
+// convergence test |delta| < eps (:844-852 / :632-638) is a discrete decision, and when a
+// step lands within rounding distance of eps the two arithmetics stop an iteration apart.
+// The fast kernels therefore FLAG every spot whose decisive step came within a relative
+// margin of eps (and every spot that ran into max_it), and this kernel re-fits the flagged
+// spots from their initial parameters exactly as the reference does:
+//
+//   * float64 erf / exp / divisions, float32 rounding at every point where the reference
+//     stores into a float32 array (dudt, d2udt2, numerator, denominator, theta);
+//   * no contraction of a*b+c (numba without fastmath never fuses);
+//   * the accumulators are advanced pixel by pixel in the reference's (ii, jj) order —
+//     one lane per accumulator walks the per-pixel terms that the other lanes computed.
+//
+// The transcendental work is still separable: every function of (pixel index, mu, sigma)
+// the reference evaluates per pixel is a deterministic function of the pixel BOUNDARY
+// values (d - 1/2, d + 1/2), so it is evaluated once per boundary (phase A), combined per
+// column / row (phase B) and per pixel (phase C) with the reference's operation order, which
+// gives the same bits as evaluating it B^2 times.  (d + 1/2 of pixel k and d - 1/2 of pixel
+// k + 1 are the same float64 whenever k - mu is exact, i.e. |mu| > 3e-8.)
+//
+// Mapping: a group of GS lanes per spot (GS = 64: one wavefront per spot, the lowest
+// latency, used for the flagged-spot list; GS = 16 / 32: four / two spots per wavefront
+// for boxes <= 7 / <= 15 when every spot is fitted this way, PMI_MLE_STRICT).
+#include <algorithm>
+#include <cstdlib>
+
+#include "fit_common.h"
+
+#pragma clang fp contract(off)
+
+namespace pmi {
+
+namespace {
+
+constexpr double K_SQRT_2PI = 2.5066282746310002;   // np.sqrt(2.0 * np.pi)
+constexpr double K_SQRT_2 = 1.4142135623730951;
+constexpr double K_SQRT_PI = 1.7724538509055159;
+
+__device__ __forceinline__ double np_max_d(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a > b ? a : b)); }
+__device__ __forceinline__ double np_min_d(double a, double b) { return (a != a) ? a : ((b != b) ? b : (a < b ? a : b)); }
+// float32 / float32, correctly rounded (float64 quotient rounds innocuously: 53 >= 2*24 + 2)
+__device__ __forceinline__ float div_rn(float a, float b) { return (float)((double)a / (double)b); }
+
+__device__ __forceinline__ void lds_sync()
+{
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+}
+
+// LDS of one group, in bytes: spot (float32), boundary values, column / row terms, per-pixel terms of one round,
+// accumulators
+template <int GS> struct SLds {
+    static constexpr int MAXB = GS == 16 ? 7 : (GS == 32 ? 15 : PMI_MAX_BOX);
+    static constexpr int SPOT = ((MAXB * MAXB * 4 + 15) / 16) * 16;
+    static constexpr int BND = 2 * (MAXB + 1) * 4 * 8;
+    static constexpr int COL = 2 * MAXB * 5 * 8;
+    static constexpr int TERM = GS * 12 * 8;
+    static constexpr int ACC = 24 * 4;      // 12 accumulators + 6 updated parameters
+    static constexpr int BYTES = SPOT + BND + COL + TERM + ACC;
+};
+
+}  // namespace
+
+// list: spot indices to fit (entries [0, *list_n)), or nullptr = every spot of [p.first, min(p.N, *p.d_n)).
+template <int NP, int GS, bool FROM_MOVIE>
+__global__ __launch_bounds__(FIT_NT) void mle_strict_kernel(FitParams p, const int32_t *__restrict__ list,
+                                                            const unsigned *__restrict__ list_n)
+{
+    constexpr int NSPW = 64 / GS;
+    __shared__ __attribute__((aligned(16))) char s_mem[FIT_WAVES][NSPW][SLds<GS>::BYTES];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int g = lane / GS, j = lane & (GS - 1);
+    char *mem = &s_mem[wid][g][0];
+    float *spot = reinterpret_cast<float *>(mem);
+    double *bnd = reinterpret_cast<double *>(mem + SLds<GS>::SPOT);
+    double *col = reinterpret_cast<double *>(mem + SLds<GS>::SPOT + SLds<GS>::BND);
+    double *term = reinterpret_cast<double *>(mem + SLds<GS>::SPOT + SLds<GS>::BND + SLds<GS>::COL);
+    float *accs = reinterpret_cast<float *>(mem + SLds<GS>::SPOT + SLds<GS>::BND + SLds<GS>::COL + SLds<GS>::TERM);
+
+    const int B = p.box, npix = B * B, H = B / 2;
+    int64_t n = p.N;
+    if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+    int64_t items = list ? (int64_t)*list_n : n - p.first;
+    if (list && items > n - p.first) items = n - p.first;
+    const int64_t total_groups = (int64_t)gridDim.x * FIT_WAVES * NSPW;
+    const int64_t group0 = ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW + g;
+
+    for (int64_t w0 = group0 - g; w0 < items; w0 += total_groups) {      // w0: wave-uniform
+        const int64_t w = w0 + g;
+        const bool have = w < items;
+        const int64_t sidx = have ? (list ? (int64_t)list[w] : p.first + w) : 0;
+
+        // ---- the spot, in photons (localize.py:917-931, 1101-1112) --------------------
+        for (int q = j; q < npix; q += GS) {
+            float v = 0.f;
+            if (have) {
+                if (FROM_MOVIE) {
+                    const int a = q / B, c = q - a * B;
+                    const int64_t fr = p.frame[sidx], yy = p.y[sidx], xx = p.x[sidx];
+                    const float raw = load_movie_px(p.movie, p.dtype, (fr * p.Y + (yy - H + a)) * p.X + (xx - H + c));
+                    v = div_const((raw - p.baseline) * p.sensitivity, p.gdiv);
+                } else {
+                    v = p.spots[sidx * npix + q];
+                }
+            }
+            spot[q] = v;
+        }
+        lds_sync();
+
+        // ---- initial parameters (gaussmle.py:28-168) -----------------------------------
+        // 3x3 edge-clipped mean filter, float64 sum in (m, n) order, float32 store (:61-91); its minimum (:135)
+        float best = INFINITY;
+        for (int q = j; q < npix; q += GS) {
+            const int k = q / B, l = q - k * B;
+            const int m0 = k - 1 > 0 ? k - 1 : 0, m1 = k + 2 < B ? k + 2 : B;
+            const int n0 = l - 1 > 0 ? l - 1 : 0, n1 = l + 2 < B ? l + 2 : B;
+            double nsum = 0.0;
+            for (int m = m0; m < m1; m++)
+                for (int c = n0; c < n1; c++) nsum += (double)spot[m * B + c];
+            const float f = (float)(nsum / (double)((m1 - m0) * (n1 - n0)));
+            best = (best != best) ? best : ((f != f) ? f : (f < best ? f : best));        // np.min: NaN propagates
+        }
+        float *fscr = reinterpret_cast<float *>(term);
+        fscr[j] = best;
+        lds_sync();
+        float bg0 = INFINITY;
+        for (int r = 0; r < GS; r++) {
+            const float f = fscr[r];
+            bg0 = (bg0 != bg0) ? bg0 : ((f != f) ? f : (f < bg0 ? f : bg0));
+        }
+        // sum and centre of mass, sequential float64 like the reference (:28-48); every lane does the same
+        double s_ = 0.0, sy_ = 0.0, sx_ = 0.0;
+        for (int a = 0; a < B; a++)
+            for (int c = 0; c < B; c++) {
+                const double v = (double)spot[a * B + c];
+                sy_ += v * (double)a;
+                sx_ += v * (double)c;
+                s_ += v;
+            }
+        double com_y, com_x;
+        if (s_ <= 0.0) { s_ = 0.01; com_y = (B - 1) / 2.0; com_x = (B - 1) / 2.0; }
+        else { com_y = sy_ / s_; com_x = sx_ / s_; }
+        const double photons0 = np_max_d(1.0, s_ - (double)(B * B) * (double)bg0);
+        double sdy = 0.0, sdx = 0.0, sum_y = 0.0, sum_x = 0.0;
+        for (int a = 0; a < B; a++) {
+            const double d2 = (double)((a - H) * (a - H));
+            const float vy = spot[a * B + H] - bg0;        // spot - bg is a float32 array (:105)
+            const float vx = spot[H * B + a] - bg0;
+            sdy += (double)vy * d2;
+            sdx += (double)vx * d2;
+            sum_y += (double)vy;
+            sum_x += (double)vx;
+        }
+        double isy = sqrt(sdy / sum_y), isx = sqrt(sdx / sum_x);
+        if (!isfinite(isy)) isy = 0.01;
+        if (!isfinite(isx)) isx = 0.01;
+        if (isx == 0) isx = 0.01;
+        if (isy == 0) isy = 0.01;
+
+        float th[6], ms[6];
+        th[0] = (float)com_x; th[1] = (float)com_y; th[2] = (float)photons0; th[3] = bg0;
+        if (NP == 6) { th[4] = (float)isx; th[5] = (float)isy; }
+        else { th[4] = (float)((isx + isy) / 2); th[5] = 0.f; }                  // float64 mean, float32 store (:153)
+        ms[0] = th[4]; ms[1] = th[4];
+        ms[2] = (float)(0.1 * (double)th[2]); ms[3] = (float)(0.1 * (double)th[3]);
+        ms[4] = (float)(0.2 * (double)th[4]); ms[5] = (float)(0.2 * (double)th[5]);
+
+        // ---- Newton iterations (:533-670 sigma, :745-884 sigmaxy) -----------------------
+        int kk = 0;
+        bool active = have && p.max_it > 0;
+        const int nb = B + 1;
+        while (__any(active)) {
+            const float sgy = NP == 6 ? th[5] : th[4];
+            // phase A: lane -> (axis, boundary k)
+            if (j < 2 * nb) {
+                const int a = j >= nb ? 1 : 0, k = j - a * nb;
+                const double dmu = (double)(a ? th[1] : th[0]);
+                const float sgf = a ? sgy : th[4];
+                const double ds = (double)sgf;
+                const double b = k < B ? ((double)k - dmu) - 0.5 : ((double)(B - 1) - dmu) + 0.5;
+                const double sq_norm = 0.70710678118654757 / ds;                     // :276
+                const double eA = erf(b * sq_norm);                                  // :279
+                const double t = b / ds;
+                const double eD = exp(-0.5 * (t * t));                               // :294-295
+                double v2, v3;
+                if (NP == 6) {
+                    const float s2 = sgf * sgf;
+                    const double eG = exp(-(b * b) / (2.0 * (double)s2));            // :312-313
+                    v2 = b * eG;                                                     // a ** 1 * exp
+                    v3 = (b * (b * b)) * eG;                                         // a ** 3 * exp (square-and-multiply)
+                } else {
+                    const double ai = b / (K_SQRT_2 * ds);                           // :354-357
+                    const double ex = exp(-(ai * ai));
+                    v2 = ai * ex;                                                    // term of Fx / Fy (:359)
+                    v3 = (ai * ex) * (1.0 - 2.0 * (ai * ai));                        // term of dFxdt / dFydy (:364-371)
+                }
+                double *o = bnd + (a * nb + k) * 4;
+                o[0] = eA; o[1] = eD; o[2] = v2; o[3] = v3;
+            }
+            lds_sync();
+            // phase B: lane -> (axis, pixel index i): PSF, b - a, (d-.5) b - (d+.5) a, sigma terms
+            if (j < 2 * B) {
+                const int a = j >= B ? 1 : 0, i = j - a * B;
+                const double dmu = (double)(a ? th[1] : th[0]);
+                const float sgf = a ? sgy : th[4];
+                const double ds = (double)sgf;
+                const double *m = bnd + (a * nb + i) * 4, *q = m + 4;               // minus / plus boundary
+                const double d = (double)i - dmu;
+                const double PSF = 0.5 * (q[0] - m[0]);
+                const double bma = m[1] - q[1];
+                const double qq = (d - 0.5) * m[1] - (d + 0.5) * q[1];
+                double S1, S2;
+                if (NP == 6) {
+                    const float s2 = sgf * sgf, s3 = sgf * s2, s5 = sgf * (s2 * s2);   // sigma ** n, float32 (:315)
+                    const double g21 = (m[2] - q[2]) / ((double)s2 * K_SQRT_2PI);
+                    const double g31 = (m[2] - q[2]) / ((double)s3 * K_SQRT_2PI);
+                    const double g53 = (m[3] - q[3]) / ((double)s5 * K_SQRT_2PI);
+                    S1 = g21;                                                        // :330
+                    S2 = g53 - 2.0 * g31;                                            // :334
+                } else {
+                    const double F = m[2] - q[2];                                    // :359
+                    const double dPSF = F / (K_SQRT_PI * ds);                        // :361
+                    const double dF = (q[3] - m[3]) / ds;                            // :364-367
+                    const float s2 = sgf * sgf;
+                    const float sinv = div_rn(1.0f, sgf);                            // sigma ** (-1), float32
+                    S1 = dPSF;
+                    S2 = (1.0 / K_SQRT_PI) * ((-F / (double)s2) + (double)sinv * dF);   // :372-374
+                }
+                double *o = col + (a * B + i) * 5;
+                o[0] = PSF; o[1] = bma; o[2] = qq; o[3] = S1; o[4] = S2;
+            }
+            lds_sync();
+            // phase C + accumulation, GS pixels of the reference's (ii, jj) sequence per round
+            float acc = 0.f;
+            const double N_ = (double)th[2], bgd = (double)th[3];
+            const float sgx = th[4];
+            const double cx = K_SQRT_2PI * (double)sgx, cy = K_SQRT_2PI * (double)sgy;
+            const double c3x = K_SQRT_2PI * (double)(sgx * (sgx * sgx)), c3y = K_SQRT_2PI * (double)(sgy * (sgy * sgy));
+            for (int r0 = 0; r0 < npix; r0 += GS) {
+                const int seq = r0 + j;
+                if (seq < npix) {
+                    const int ii = seq / B, jj = seq - ii * B;
+                    const double *X = col + ii * 5, *Yc = col + (B + jj) * 5;
+                    const double PSFx = X[0], PSFy = Yc[0];
+                    float du[6], d2[6];
+                    du[0] = (float)(N_ * PSFy * X[1] / cx);                          // :296
+                    d2[0] = (float)(N_ * X[2] * PSFy / c3x);                         // :297-302
+                    du[1] = (float)(N_ * PSFx * Yc[1] / cy);
+                    d2[1] = (float)(N_ * Yc[2] * PSFx / c3y);
+                    du[2] = (float)(PSFx * PSFy); d2[2] = 0.f;
+                    du[3] = 1.f; d2[3] = 0.f;
+                    if (NP == 6) {
+                        du[4] = (float)(N_ * PSFy * X[3]);                           // :330-335
+                        d2[4] = (float)(N_ * PSFy * X[4]);
+                        du[5] = (float)(N_ * PSFx * Yc[3]);
+                        d2[5] = (float)(N_ * PSFx * Yc[4]);
+                    } else {
+                        du[4] = (float)(N_ * (PSFy * X[3] + PSFx * Yc[3]));          // :379
+                        d2[4] = (float)(N_ * PSFy * X[4] + 2.0 * X[3] * Yc[3] + PSFx * Yc[4]);   // :380-382
+                        du[5] = 0.f; d2[5] = 0.f;
+                    }
+                    const double model = N_ * PSFx * PSFy + bgd;                     // :828
+                    const double data = (double)spot[jj * B + ii];
+                    double cf = 0.0, df = 0.0;
+                    if (model > 10e-3) { cf = data / model - 1; df = data / (model * model); }
+                    cf = np_min_d(cf, 10e4);
+                    df = np_min_d(df, 10e4);
+                    double *t = term + j * 12;
+#pragma unroll
+                    for (int l = 0; l < 6; l++) {
+                        const float du2 = du[l] * du[l];                             // float32 ** 2
+                        t[l] = cf * (double)du[l];
+                        t[6 + l] = cf * (double)d2[l] - df * (double)du2;
+                    }
+                }
+                lds_sync();
+                if (j < 12) {
+                    // :838-839, one accumulator per lane; eight terms are fetched ahead of the dependent chain of
+                    // (float64 add, float32 round) steps
+                    const int cnt = npix - r0 < GS ? npix - r0 : GS;
+                    if (cnt == GS) {
+#pragma unroll
+                        for (int s0 = 0; s0 < GS; s0 += 8) {
+                            double t[8];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) t[u] = term[(s0 + u) * 12 + j];
+#pragma unroll
+                            for (int u = 0; u < 8; u++) acc = (float)((double)acc + t[u]);
+                        }
+                    } else {
+                        for (int s = 0; s < cnt; s++) acc = (float)((double)acc + term[s * 12 + j]);
+                    }
+                }
+                lds_sync();
+            }
+            if (j < 12) accs[j] = acc;
+            lds_sync();
+            // update (:860-884 / :647-670): lane l updates parameter l, the six new values go round through LDS
+            if (j < NP) {
+                const float num = accs[j], den = accs[6 + j];
+                float msl = ms[0], thl = th[0];
+#pragma unroll
+                for (int l = 1; l < 6; l++) { msl = j == l ? ms[l] : msl; thl = j == l ? th[l] : thl; }
+                float upd;
+                if (NP == 6) upd = den == 0.0f ? np_signf(num) * msl : np_minf(np_maxf(div_rn(num, den), -msl), msl);
+                else upd = den == 0.0f ? np_signf(num * msl) : np_minf(np_maxf(div_rn(num, den), -msl), msl);
+                float v = thl - upd;
+                if (j == 2) v = np_maxf(v, 1.0f);
+                if (j == 3 || j == 4 || j == 5) v = np_maxf(v, 0.01f);
+                if (NP == 5 && j == 4) v = np_minf(v, (float)B);
+                accs[12 + j] = v;
+            }
+            lds_sync();
+            float nt[6];
+#pragma unroll
+            for (int l = 0; l < NP; l++) nt[l] = accs[12 + l];
+            if (NP == 5) nt[5] = th[5];
+            bool conv = ((double)fabsf(th[0] - nt[0]) < p.eps) && ((double)fabsf(th[1] - nt[1]) < p.eps);
+            if (NP == 6) conv = conv && ((double)fabsf(th[4] - nt[4]) < p.eps) && ((double)fabsf(th[5] - nt[5]) < p.eps);
+            if (active) {
+#pragma unroll
+                for (int l = 0; l < 6; l++) th[l] = nt[l];
+                kk++;
+                if (conv || kk >= p.max_it) active = false;
+            }
+            lds_sync();
+        }
+        if (have && j == 0) {
+            float *to = p.thetas + sidx * 6;
+#pragma unroll
+            for (int l = 0; l < 5; l++) to[l] = th[l];
+            to[5] = NP == 6 ? th[5] : th[4];
+            p.iterations[sidx] = kk;
+        }
+        lds_sync();
+    }
+}
+
+template <int NP, int GS>
+static void launch_strict_gs(const FitParams &p, bool from_movie, const int32_t *list, const unsigned *list_n,
+                             int64_t max_items, int cu_count, hipStream_t s)
+{
+    constexpr int NSPW = 64 / GS;
+    const int64_t groups_per_block = (int64_t)FIT_WAVES * NSPW;
+    int64_t blocks = (max_items + groups_per_block - 1) / groups_per_block;
+    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)cu_count * 3));
+    if (from_movie) hipLaunchKernelGGL((mle_strict_kernel<NP, GS, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
+    else hipLaunchKernelGGL((mle_strict_kernel<NP, GS, false>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
+}
+
+// Newton loop in the reference's arithmetic for the spots of `list` (device indices, *list_n of them, at most
+// max_items) or, with list == nullptr, for every spot of the batch.  Writes thetas and iterations only.
+void launch_fit_strict(const FitParams &p, int method, bool from_movie, const int32_t *list, const unsigned *list_n,
+                       int64_t max_items, int cu_count, hipStream_t s)
+{
+    // four / two / one spot per wavefront: the kernel is bound by instruction issue, not by the latency of one fit
+    // (measured on config 2's 6 500 flagged spots: 16-lane groups 0.30 ms, 64-lane groups 0.45 ms)
+    static const char *genv = getenv("PMI_STRICT_LIST_GS");      // tuning: group size for the flagged-spot list
+    const int packed = p.box <= 7 ? 16 : (p.box <= 15 ? 32 : 64);
+    const int gs = list ? std::max(packed, genv ? atoi(genv) : packed) : packed;
+    if (method == PMI_MLE_SIGMAXY) {
+        if (gs == 16) launch_strict_gs<6, 16>(p, from_movie, list, list_n, max_items, cu_count, s);
+        else if (gs == 32) launch_strict_gs<6, 32>(p, from_movie, list, list_n, max_items, cu_count, s);
+        else launch_strict_gs<6, 64>(p, from_movie, list, list_n, max_items, cu_count, s);
+    } else {
+        if (gs == 16) launch_strict_gs<5, 16>(p, from_movie, list, list_n, max_items, cu_count, s);
+        else if (gs == 32) launch_strict_gs<5, 32>(p, from_movie, list, list_n, max_items, cu_count, s);
+        else launch_strict_gs<5, 64>(p, from_movie, list, list_n, max_items, cu_count, s);
+    }
+}
+
+}  // namespace pmi

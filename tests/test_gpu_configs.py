@@ -12,7 +12,7 @@ import numpy as np
 import pandas as pd
 import pytest
 
-from conftest import golden
+from conftest import assert_mle_rows, golden
 
 pytestmark = pytest.mark.gpu
 CAM = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
@@ -68,16 +68,12 @@ def test_config2_full_size_properties(be, orc):
     # ... and the fit of every one of them within the north-star tolerance (x, y, sigma 1e-3 px, photons 1e-2)
     spots = orc.get_spots(host, ofr, oy, ox, 7, CAM)
     th, cr, ll, it = orc.gaussmle(spots, 1e-3, 100, "sigmaxy", threads=orc.max_threads())
-    same = t["iterations"] == it
-    assert same.mean() > 0.98
-    conv = same & (it < 100)
-    assert np.max(np.abs(t["x"] - (th[:, 0] + ox - 3))[conv]) < 1e-3 and np.max(np.abs(t["y"] - (th[:, 1] + oy - 3))[conv]) < 1e-3
-    assert np.max(np.abs(t["sx"] - th[:, 4])[conv]) < 1e-3 and np.max(np.abs(t["sy"] - th[:, 5])[conv]) < 1e-3
-    assert np.max((np.abs(t["photons"] - th[:, 2]) / th[:, 2])[conv]) < 1e-2
-    # where the iteration count differs by one (a convergence test decided in the last bit) the answer still agrees
-    near = ~same & (np.abs(t["iterations"].astype(np.int64) - it) <= 1)
-    assert near.sum() >= 0.9 * (~same).sum()
-    assert np.max(np.abs(t["x"] - (th[:, 0] + ox - 3))[near]) < 2e-3
+    # ALL rows: identical iteration counts, x / y / sigma < 1e-3 px, photons < 1e-2 (borderline convergence
+    # decisions are re-fitted on the device in the reference's arithmetic, inside the same call)
+    assert_mle_rows(t["x"], t["y"], t["sx"], t["sy"], t["photons"], t["iterations"],
+                    th[:, 0] + ox - 3, th[:, 1] + oy - 3, th[:, 4], th[:, 5], th[:, 2], it, label="config 2, all rows")
+    refit = be.last_refit_count()
+    assert 0 < refit < 0.05 * n          # the second fit is the exception (0.7 % of the spots here)
     del host, idf, spots
     # a slice of frames against the oracle: identical identification set, fit within tolerance
     sl = slice(4000, 4040)
@@ -88,11 +84,9 @@ def test_config2_full_size_properties(be, orc):
     assert np.array_equal(t["net_gradient"][m], ong) and np.array_equal(fr[m] - sl.start, ofr)
     spots = orc.get_spots(sub, ofr, oy, ox, 7, CAM)
     th, cr, ll, it = orc.gaussmle(spots, 1e-3, 100, "sigmaxy", threads=4)
-    same = t["iterations"][m] == it
-    assert same.mean() > 0.95
-    assert np.max(np.abs(t["x"][m] - (th[:, 0] + ox - 3))[same]) < 1e-3
-    assert np.max(np.abs(t["y"][m] - (th[:, 1] + oy - 3))[same]) < 1e-3
-    assert np.max(np.abs(t["photons"][m] - th[:, 2])[same] / th[same, 2]) < 1e-4
+    assert_mle_rows(t["x"][m], t["y"][m], t["sx"][m], t["sy"][m], t["photons"][m], t["iterations"][m],
+                    th[:, 0] + ox - 3, th[:, 1] + oy - 3, th[:, 4], th[:, 5], th[:, 2], it, label="frame slice")
+    assert np.max(np.abs(t["photons"][m] - th[:, 2]) / th[:, 2]) < 1e-4
     # agreement with the simulation: every localization sits on a simulated emitter of its frame
     tx, ty, tf = truth["x"], truth["y"], truth["frame"]
     fsel = (tf >= sl.start) & (tf < sl.stop)
@@ -149,10 +143,9 @@ def test_config5_astigmatic_13x13_and_zfit(be, orc):
         spots[i] = rng.poisson(rng.uniform(3000, 9000) * np.outer(ey, ex) + rng.uniform(5, 25))
     th, cr, ll, it = be.gaussmle_arrays(spots, 1e-3, 100, "sigmaxy")
     oth, ocr, oll, oit = orc.gaussmle(spots, 1e-3, 100, "sigmaxy", threads=4)
-    same = it == oit
-    assert same.mean() > 0.95
-    assert np.max(np.abs(th[same][:, [0, 1, 4, 5]] - oth[same][:, [0, 1, 4, 5]])) < 1e-3
-    assert np.max(np.abs(th[same, 2] - oth[same, 2]) / oth[same, 2]) < 1e-4
+    assert_mle_rows(th[:, 0], th[:, 1], th[:, 4], th[:, 5], th[:, 2], it,
+                    oth[:, 0], oth[:, 1], oth[:, 4], oth[:, 5], oth[:, 2], oit, label="config 5 13x13")
+    assert np.max(np.abs(th[:, 2] - oth[:, 2]) / oth[:, 2]) < 1e-4
     zz, sq = be.zfit_arrays(th[:, 4], th[:, 5], cx, cy)
     oz, osq = orc.zfit(th[:, 4], th[:, 5], cx, cy, threads=4)
     assert np.max(np.abs(zz - oz)) < 5e-5 and np.max(np.abs(sq - osq)) < 1e-9
@@ -183,10 +176,8 @@ def test_config4_geometry_shard_in_miniature(be, orc):
     assert m.sum() == len(ofr) and np.array_equal(fr[m] - 10, ofr) and np.array_equal(t["net_gradient"][m], ong)
     spots = orc.get_spots(sub, ofr, oy, ox, 7, CAM)
     th, cr, ll, it = orc.gaussmle(spots, 1e-3, 100, "sigmaxy", threads=4)
-    same = t["iterations"][m] == it
-    assert same.mean() > 0.95
-    assert np.max(np.abs(t["x"][m] - (th[:, 0] + ox - 3))[same]) < 1e-3
-    assert np.max(np.abs(t["y"][m] - (th[:, 1] + oy - 3))[same]) < 1e-3
+    assert_mle_rows(t["x"][m], t["y"][m], t["sx"][m], t["sy"][m], t["photons"][m], t["iterations"][m],
+                    th[:, 0] + ox - 3, th[:, 1] + oy - 3, th[:, 4], th[:, 5], th[:, 2], it, label="config 4 miniature")
     locs = pd.DataFrame(t)
     drift, und = postprocess.undrift(locs, [{"Frames": F, "Height": H, "Width": W}, {"Pixelsize": 130}], 8, display=False)
     assert len(und) == len(locs) and len(drift) == F and float(np.abs(drift.to_numpy()).max()) < 0.2

@@ -51,8 +51,30 @@ def parse():
     return ap.parse_args()
 
 
+def launch_ranks(args):
+    """`python bench.py --gpus N` with no launcher around it: start N ranks (one per GPU) under
+    torch.distributed.run as a CHILD process, relay rank 0's JSON line and return the children's exit status.
+    Nothing here imports torch or touches HIP — a process that has initialised the GPU must never exec or fork
+    into another program on this pool."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what this pool's driver supports (RCCL)
+    proc = subprocess.run(cmd, env=env)
+    if proc.returncode != 0:
+        print(f"bench.py: the {args.gpus}-rank launch failed with status {proc.returncode}", file=sys.stderr)
+    return proc.returncode
+
+
 def main():
     args = parse()
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch_ranks(args))
     import torch
     import torch.distributed as dist
 
@@ -61,6 +83,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE is {world}: launch one rank per GPU "
+                         f"(python bench.py --gpus N starts them itself)")
     ndev = torch.cuda.device_count()
     if ndev < 1:
         raise SystemExit("bench.py needs an MI355X: no HIP device visible (there is no CPU path)")
@@ -190,6 +215,8 @@ def main():
     result = None
     if rank == 0:
         n_rank0 = int(d_n.item())
+        mle_mode, mle_margin = backend.get_mle_mode()
+        refit = backend.last_refit_count(stream)
         kernels = {
             "identify_scan": {"ms": scan_ms, "algorithmic_bytes": movie_bytes,
                               "GB/s": movie_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms == scan_ms else None},
@@ -212,7 +239,10 @@ def main():
             "metric": "localizations/sec (7x7 ROI, MLE)", "value": value, "unit": "localizations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "vs_baseline": None,
+            # float32 Newton loop; spots whose convergence test falls within rounding distance of eps are fitted again
+            # with the reference's float64 intermediates INSIDE the timed step (csrc/gaussmle_strict.hip)
+            "dtype": {"fast": "f32", "refit": "f32+f64", "strict": "f64"}[mle_mode], "data": "synthetic",
             "config": {"workload": f"{F}-frame {H}x{W} uint16 simulated DNA-PAINT movie per GPU, "
                                    f"{n_total // world} spots per GPU, {box}x{box} ROI MLE ({args.method}), "
                                    "identify+cut+fit+table resident in HBM"
@@ -221,6 +251,7 @@ def main():
                                       if grouped else ""),
                        "frames": F, "height": H, "width": W, "box": box, "min_net_gradient": args.min_ng,
                        "eps": 1e-3, "max_it": 100, "localizations_total": n_total,
+                       "mle_mode": mle_mode, "refit_margin": mle_margin, "refit_spots_rank0": refit,
                        "sharding": f"frames x{world}"},
             "roofline": roofline,
             "cpu_baseline": cpu,

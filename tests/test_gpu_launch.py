@@ -1,0 +1,66 @@
+"""GPU tier: the process-level contracts — RCCL initialises under torch.distributed.run (one rank here; the
+2/4/8-rank runs are the driver's), bench.py starts its own ranks for --gpus N and refuses a world it was not
+asked for.  Every program runs as a CHILD process: a process that has initialised the GPU never execs."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        return sk.getsockname()[1]
+
+
+def _env():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return env
+
+
+def test_rccl_probe_one_rank():
+    """tools/rccl_probe.py: nccl (= RCCL) process group, the table all-gather of picasso_amd/dist.py, the
+    all-reduce of the sharded undrift, the pipelined shard path — on one rank."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "rccl_probe.py")]
+    out = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "rccl probe ok: world 1" in out.stdout
+
+
+def test_bench_one_gpu_line_and_world_checks():
+    small = ["--steps", "2", "--warmup", "1", "--frames", "400", "--cpu-seconds", "0", "--profile-steps", "1"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small, cwd=ROOT, env=_env(),
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads(out.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 1e6
+    assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    # a world the command line did not ask for is refused
+    env = _env()
+    env.update({"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small, cwd=ROOT, env=env,
+                         capture_output=True, text=True, timeout=600)
+    assert bad.returncode != 0 and "WORLD_SIZE is 2" in bad.stderr
+
+
+def test_bench_starts_its_own_ranks():
+    """--gpus 2 without a launcher: bench.py spawns torch.distributed.run itself.  On a one-GPU box the second rank
+    finds no device and the whole launch fails loudly; on a box with two GPUs it prints a 2-GPU line."""
+    import torch
+    small = ["--steps", "2", "--warmup", "1", "--frames", "400", "--cpu-seconds", "0", "--profile-steps", "0"]
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"] + small, cwd=ROOT, env=_env(),
+                         capture_output=True, text=True, timeout=900)
+    if torch.cuda.device_count() >= 2:
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert json.loads(out.stdout.strip().splitlines()[-1])["n_gpus"] == 2
+    else:
+        assert out.returncode != 0
+        assert "only 1 GPU(s) visible" in out.stderr and "2-rank launch failed" in out.stderr

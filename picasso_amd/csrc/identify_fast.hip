@@ -107,17 +107,17 @@ struct FastParams {
     int y0, x0, cy, cx;
     int64_t f_lo, label_off;
     int nframes;
-    int bands, segs, bpf;      // bands per frame, 512-col segments per row, blocks per frame
+    int segs;                  // 512-column segments per row (1 when P > 1)
+    int rbu;                   // rows per unit (per sub-band when P > 1)
+    int upf;                   // units per frame: ceil(cy / (rbu * P)) * segs
+    long long units;           // nframes * upf
+    int upw;                   // consecutive units per wavefront
     int box;
     double min_ng;
-    double bound_c;            // P_box: sum of the positive stencil weights, with margin
-    int dbg;                   // PMI_IDENTIFY_DBG: 1 = skip the exact net gradient, 2 = skip the record append (timing only)
+    float filt_alpha, filt_t;  // floor filter: a maximum v can only reach min_ng if v > alpha * (minimum above it) + t; t < 0: off
+    int dbg;                   // PMI_IDENTIFY_DBG: 1 = skip the exact net gradient, 2 = skip the record append, 4 = no floor filter (timing only)
 };
 
-#ifndef FAST_WAVES_N
-#define FAST_WAVES_N 1          // one wavefront per workgroup: frames with few bands leave no idle waves (128 x 128: 1.3 -> 2.2 TB/s), larger ones gain 2-3 %
-#endif
-constexpr int FAST_WAVES = FAST_WAVES_N;
 #ifndef FAST_D_H3
 #define FAST_D_H3 6          // rows prefetched ahead in the box-7 scan (divides its unroll period of 6): 6 instead of 3, 1.65 -> 1.60 ms
 #endif
@@ -133,9 +133,13 @@ constexpr int FAST_WAVES = FAST_WAVES_N;
 #ifndef FAST_D_H6
 #define FAST_D_H6 3
 #endif
+#ifndef FAST_ROUND
+#define FAST_ROUND 32         // candidates per in-loop round of exact net gradients (lanes busy vs. rows still in the Infinity Cache)
+#endif
 #ifndef FAST_MIN_WAVES
 #define FAST_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for
 #endif
+constexpr int fast_waves_per_simd(int H) { return H <= 4 ? FAST_MIN_WAVES : (H <= 6 ? 3 : 2); }
 
 // pair `s` = pixels (s, s+1) relative to the lane's first pixel.  A holds NA packed pairs: the lane's
 // own four in the middle, NB = NA - 4 neighbour pixels on either side (4 for boxes up to 9, 8 for
@@ -173,32 +177,38 @@ struct RowRegs { uint4 m; uint4 e; };   // 8 own pixels + (lanes 0 / 63 only) th
 __device__ __forceinline__ u32 from_lane_below(u32 v, u32 edge) { return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
 __device__ __forceinline__ u32 from_lane_above(u32 v, u32 edge) { return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
 
-// Exact float32 net gradient of one candidate whose stencil does not wrap, in the reference's
-// (k, l) order.  The (2H+3)^2 neighbourhood is fetched as packed pixel pairs (one wide load + one
-// 2-byte load per row) in two batches of rows whose loads are all in flight together: the rows
-// have usually left L2 by now and a row-by-row loop pays the memory latency 2H+1 times, while
-// holding all 2H+3 rows at once does not fit the register budget of four waves per SIMD.
-// The rows are only 2-byte aligned; gfx950 runs global loads in unaligned mode.
+// Exact float32 net gradient of one candidate in the reference's (k, l) order (picasso/localize.py:202-244).
+// The (2H+3)^2 neighbourhood is fetched as its first column (one 2-byte load per row) plus 2H + 2 pixels as packed
+// pairs (one wide load per row), in two batches of rows whose loads are all in flight together: the rows have
+// usually left L2 by now and a row-by-row loop pays the memory latency 2H+1 times, while holding all 2H+3 rows at
+// once does not fit the register budget of four waves per SIMD.  The reference indexes row y - 1 and column x - 1
+// without a bounds check: for a maximum in row H (column H) that is index -1, the LAST row (column) of the frame
+// (numba wraps negative indices) — only the first row and the first column of the neighbourhood can wrap, and they
+// are addressed separately here, so the same code serves every candidate.  The rows are only 2-byte aligned;
+// gfx950 runs global loads in unaligned mode.
 template <int H, int K0, int K1>
-__device__ __forceinline__ float exact_ng_rows(const uint16_t *__restrict__ base, int64_t X, float ng)
+__device__ __forceinline__ float exact_ng_rows(const uint16_t *__restrict__ base, const uint16_t *__restrict__ row0w,
+                                               int64_t X, int c0w, float ng)
 {
-    constexpr int BOX = 2 * H + 1, W = 2 * H + 3, NP = (W - 1) / 2;   // W is odd: NP pairs + one single pixel
+    // base = &src[i - H - 1][j - H]: neighbourhood row t, column 1;  row0w = &src[wrapped first row][j - H];
+    // c0w = (wrapped first column) - (j - H): offset of the neighbourhood's column 0 from column 1 (-1 unless it wraps)
+    constexpr int BOX = 2 * H + 1, W = 2 * H + 3, NP = (W - 1) / 2;   // W is odd: one single pixel + NP pairs
     constexpr int R0 = K0, NR = K1 - K0 + 2;                           // window rows K0..K1-1 need neighbourhood rows K0..K1+1
     struct __attribute__((packed, aligned(2))) Pairs { u32 v[NP]; };
     u32 pk[NR][NP];
-    u32 last[NR];
+    u32 first[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-        const uint16_t *row = base + (int64_t)(R0 + r) * X;
+        const uint16_t *row = (R0 + r == 0) ? row0w : base + (int64_t)(R0 + r) * X;
         const Pairs t = *reinterpret_cast<const Pairs *>(row);
 #pragma unroll
         for (int q = 0; q < NP; q++) pk[r][q] = t.v[q];
-        last[r] = row[W - 1];
+        first[r] = row[c0w];
     }
     auto px = [&](int r, int b) -> float {
         r -= R0;
-        if (b == W - 1) return (float)last[r];
-        return (float)((b & 1) ? (pk[r][b >> 1] >> 16) : (pk[r][b >> 1] & 0xffffu));
+        if (b == 0) return (float)first[r];
+        return (float)(((b - 1) & 1) ? (pk[r][(b - 1) >> 1] >> 16) : (pk[r][(b - 1) >> 1] & 0xffffu));
     };
 #pragma unroll
     for (int k = K0; k < K1; k++) {
@@ -219,22 +229,39 @@ __device__ __forceinline__ float exact_ng_rows(const uint16_t *__restrict__ base
 }
 
 template <int H>
-__device__ __forceinline__ float exact_ng_noWrap(const uint16_t *__restrict__ src, int64_t X, int i, int j)
+__device__ __forceinline__ float exact_ng(const uint16_t *__restrict__ src, int64_t X, int cy, int cx, int i, int j)
 {
     constexpr int BOX = 2 * H + 1, KM = (BOX + 1) / 2;
-    const uint16_t *base = src + (int64_t)(i - H - 1) * X + (j - H - 1);
-    float ng = exact_ng_rows<H, 0, KM>(base, X, 0.0f);
+    const uint16_t *base = src + (int64_t)(i - H - 1) * X + (j - H);
+    const int r0 = i - H - 1 < 0 ? i - H - 1 + cy : i - H - 1;          // numba negative-index wrap
+    const uint16_t *row0w = src + (int64_t)r0 * X + (j - H);
+    int c0w = j - H - 1 < 0 ? cx - 1 - (j - H) : -1;
+    float ng = exact_ng_rows<H, 0, KM>(base, row0w, X, c0w, 0.0f);
     // the second batch starts only when the first sum is done (keeps its loads from being hoisted
     // above the first batch, which would double the live registers)
-    asm volatile("" : "+v"(ng), "+v"(base));
-    return exact_ng_rows<H, KM, BOX>(base, X, ng);
+    asm volatile("" : "+v"(ng), "+v"(base), "+v"(c0w));
+    return exact_ng_rows<H, KM, BOX>(base, row0w, X, c0w, ng);
 }
 
-// P > 1 (frames at most 512 / P pixels wide): the wave works on P consecutive bands of the frame at once, NL = 64 / P
-// lanes each, in lock step (row step r handles row r of every sub-band).  Neighbour pixels that a lane at a
-// sub-band's edge takes from the adjacent sub-band only reach positions outside the crop, which are masked.
-template <int H, int RB, int D, int P = 1>
-__global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6 ? 3 : 2))) void identify_scan_u16_fast_kernel(
+// One wavefront per workgroup, persistent: it owns p.upw consecutive UNITS.  A unit is rbu rows x 512 columns of one
+// frame (P > 1, frames at most 512 / P pixels wide: P consecutive row ranges of rbu rows side by side, NL = 64 / P
+// lanes each, in lock step).  Consecutive units of a wave are consecutive row ranges of the same frame, so the 2H + 2
+// halo rows a unit re-reads were fetched by this very wave a few steps earlier (L2 hits, no HBM traffic).
+//
+// Candidates (first maxima that pass the floor filter) go to a ring list in LDS that survives from unit to unit; the
+// exact net gradient is evaluated 64 candidates at a time — every lane busy — whenever the ring holds that many at the
+// end of a unit, and for the rest when the wave runs out of units.
+//
+// Floor filter.  The net gradient is a linear functional ng = sum_p w(p) f(p) of the (2H+3)^2 neighbourhood whose
+// positive weights (total P_box) all lie inside the box, where the candidate v is the maximum; the negative weights
+// total -P_box, N_K of it in the rows the scan has already passed when it takes the decision.  Pixels are >= 0, so
+//     ng <= P_box * v - N_K * min(those rows),
+// and ng > min_ng needs v > (N_K / P_box) * min + min_ng / P_box.  The minimum is kept per lane over a window of
+// the last rows (own columns and the neighbour lanes'), the right-hand side becomes a packed u16 floor that joins
+// the first-maximum threshold with one v_pk_max_u16 per pixel pair, and the shot-noise maxima (2 % of all pixels,
+// 20 x more than there are emitters) never reach the list.
+template <int H, int D, int P = 1>
+__global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_fast_kernel(
     FastParams p, const float *__restrict__ uxy, Record *__restrict__ recs, long long cap,
     unsigned long long *__restrict__ shard_cnt, int *__restrict__ frame_count)
 {
@@ -248,260 +275,55 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
     constexpr int HR = WIDE ? H : (H > 1 ? H - 1 : 1);     // Hrow ring length (unused when H == 1)
     constexpr int U_ = WIDE ? (H == 5 ? 10 : 2 * H) : ((H <= 2) ? 4 : H * (H - 1));   // unroll period: a multiple of both ring periods
     static_assert(U_ % D == 0, "prefetch depth must divide the unroll period");
-    constexpr int GS = U_ >= 6 ? U_ : 8;                   // rows per MIN statistics group (cells of 8 columns)
-    constexpr int GM = H <= 2 ? 2 : H;                     // rows per MAX statistics group (cells of 4 columns); divides U_
-    static_assert(U_ % GM == 0 && GS % GM == 0, "max groups close inside the unrolled body");
-    static_assert(2 * H + 2 <= 3 * GM && 2 * H + 2 <= 2 * GS, "the stored windows (4 max groups, 3 min groups) must cover the stencil rows");
-    constexpr int NR = RB + 2 * H + 2;                     // pipeline rows: band + H halo + 1 stats row each side
-    constexpr int NRP = ((NR + GS - 1) / GS) * GS;
-    constexpr int NG = NRP / GS, NGM = NRP / GM;
-    // Local maxima are > H apart, so a band holds at most RB*512/(H+1)^2 of them; shot noise gives ~1/(2H+1)^2
-    // per pixel.  The list is sized at 3/4 of the geometric bound (4 workgroups per CU fit in LDS);
-    // a denser band takes the exact rescan path below.
-    constexpr int LIST_GEO = (RB * 512 / ((H + 1) * (H + 1))) * 3 / 4;
-    constexpr int LIST = LIST_GEO < 1024 ? LIST_GEO : 1024;
-    static_assert(RB <= 128, "list entries keep the row in 7 bits");
+    constexpr int NWL = (H + 1 + 7) / 8;                   // neighbour lanes (8 columns each) a stencil reaches on either side
+    // Candidate ring: entries (row << 16 | column in the aligned row) + frame index.  A chunk of rows ends early when
+    // the ring holds THRESH entries (only without the floor filter, i.e. min_ng <= 0: 2 % of the pixels are maxima).
+    constexpr int LIST = 1024, THRESH = LIST - 128;
 
-    __shared__ unsigned short s_list[FAST_WAVES][LIST];   // (row - band_lo) << 9 | (col - 512 * seg)
-    // Range statistics for the |ng| bound.  The minimum barely varies (background floor): one value
-    // per lane (8 columns) per GS rows.  The maximum is what a nearby emitter inflates, so it is kept
-    // on a finer grid: two 4-column cells per lane per GM rows (low half = left cell).  What is stored
-    // for group g is already the extreme over the window of groups ending at g (4 max groups, 3 min
-    // groups), so that a candidate's query is one entry per lane it touches instead of one per group.
-    __shared__ unsigned short s_min[FAST_WAVES][NG][64];
-    __shared__ unsigned s_max[FAST_WAVES][NGM][64];
+    __shared__ unsigned s_pos[LIST];
+    __shared__ unsigned s_fi[LIST];
     __shared__ float s_u[2 * BOX * BOX];
 
-    const int lane = threadIdx.x & 63;
-    const int w = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave id as a scalar: row addressing stays on the SALU
-    for (int i = threadIdx.x; i < 2 * BOX * BOX; i += FAST_WAVES * 64) s_u[i] = uxy[i];
-    __syncthreads();
+    const int lane = threadIdx.x;
+    for (int i = lane; i < 2 * BOX * BOX; i += 64) s_u[i] = uxy[i];
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
 
-    // XCD-aware mapping: all blocks of a frame share blockIdx % 8 (= the XCD they run on)
-    const int m = blockIdx.x >> 3, xcd = blockIdx.x & 7;
-    const int fi = (m / p.bpf) * 8 + xcd;
-    const int unit = (m % p.bpf) * FAST_WAVES + w;
-    if (fi >= p.nframes || unit >= p.bands * p.segs) return;
-    const int band = unit / p.segs, seg = unit - band * p.segs;       // P > 1: `band` counts groups of P bands, seg = 0
+    const long long unit0 = (long long)blockIdx.x * p.upw;
+    const long long unit1 = unit0 + p.upw < p.units ? unit0 + p.upw : p.units;
+    if (unit0 >= unit1) return;
     const int sub = P > 1 ? lane / NL : 0;                            // this lane's sub-band and its rows' offset
-    const int sub_rows = sub * RB;
+    const int sub_rows = sub * p.rbu;
 
     // The crop may start at any column: lanes work on 8-pixel chunks aligned in the FRAME (16-byte
     // loads), xoff pixels of the first chunk lie left of the crop.  Positions outside the crop are
     // masked; every allowed position has its whole window inside the crop, so looking at frame pixels
-    // beyond the crop edge never changes a decision.  Column indices in the candidate list and the
-    // statistics cells are relative to the aligned origin, j = ja - xoff is relative to the crop.
+    // beyond the crop edge never changes a decision.  Column indices in the candidate list are relative
+    // to the aligned origin, j = ja - xoff is relative to the crop.
     const int xoff = p.x0 & 7;
     const int nch = (xoff + p.cx + 7) >> 3;           // 8-pixel chunks per row
-    const int c8 = P > 1 ? lane % NL : seg * 64 + lane;
-    const bool lane_valid = c8 < nch;
-    const int cm = min(c8, nch - 1);
-    const uint16_t *src = p.movie + ((int64_t)(p.f_lo + fi) * p.Y + p.y0) * p.X + p.x0;
-    const int col_m = cm * 8;
-    const int col_l = cm > 0 ? col_m - NB : col_m;                // clamped copies feed invalid pixels only
-    const int col_r = cm + 1 < nch ? col_m + 8 : col_m + 8 - NB;
-    const int band_lo = band * (RB * P), band_hi = min(band_lo + RB, p.cy);  // P > 1: of sub-band 0
-    const int row_lo = max(band_lo, H), row_hi = min(band_hi, p.cy - H - 1);   // rows that may hold a maximum
-    const int rs0 = band_lo - H - 1;
-    // P > 1: the same limits for this lane's sub-band, in sub-band 0's row numbering
-    const int lo_rel = max(band_lo + sub_rows, H) - sub_rows;
-    const int hi_rel = min(min(band_lo + sub_rows + RB, p.cy), p.cy - H - 1) - sub_rows;
-
-    // which of the lane's 8 pixels may hold a maximum: even pixels -> bits 0..3, odd -> bits 16..19,
-    // replicated for the four row slots of the candidate accumulator
-    u32 colmask = 0;
-    if (lane_valid) {
-#pragma unroll
-        for (int b = 0; b < 8; b++) {
-            int j = c8 * 8 + b - xoff;
-            if (j >= H && j < p.cx - H - 1) colmask |= 1u << ((b >> 1) + 16 * (b & 1));
-        }
-        colmask *= 0x1111u;
-    }
-
-    // per-lane byte offsets inside a row (32-bit) + a wave-uniform row base: the loads use
-    // SGPR-base + VGPR-offset addressing, no 64-bit vector address arithmetic per row
-    // Neighbour pixels come from the adjacent lanes' registers (DPP), not from memory: overlapping
-    // 8-byte loads next to the 16-byte ones doubled the HBM-side traffic (requests to a line whose
-    // fill is still in flight are not merged).  Only lanes 0 and 63 load the 4 pixels beyond the wave.
-    const unsigned off_m = (unsigned)col_m * 2u;
-    const unsigned off_e = (unsigned)(lane == 0 ? col_l : col_r) * 2u;
-    const bool edge_lane = P == 1 && (lane == 0 || lane == 63);       // a sub-band's row lies wholly inside its lanes
-    // Rows are fetched with buffer loads: the frame base sits in a scalar resource descriptor, the
-    // row offset in a scalar register and the lane's column offset in one VGPR, so a row costs no
-    // vector address arithmetic at all (a 64-bit global address per lane would take two VALU adds).
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-    // num_records bounds the descriptor at the end of the frames of this call: when the width is not a
-    // multiple of 8 the last chunk of a row reads into the next row (masked columns), and on the very last
-    // row it would read past the movie — the buffer unit returns 0 there instead
-    const long long remaining = ((long long)(p.nframes - fi) * p.Y * p.X - ((long long)p.y0 * p.X + p.x0 - xoff)) * 2;
-    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<uint16_t *>(src - xoff), 0, (int)(remaining < 0x7fffffffLL ? remaining : 0x7fffffffLL),
-        0x00020000 /* raw 32-bit buffer, gfx94x/gfx950 */);
     const unsigned pitch = (unsigned)p.X * 2u;         // Y * pitch < 2^31 on this path
-    // interior bands never touch a row outside the crop: no clamping in their row loop
-    const bool interior = rs0 >= 0 && rs0 + NRP + D <= p.cy;
-    auto load_row = [&](int r) -> RowRegs {
-        RowRegs o;
-        unsigned soff = 0;
-        u32x4_t m;
-        if constexpr (P > 1) {
-            // every sub-band clamps its own row: the row offset joins the lane's column offset
-            const int rl = min(max(r + sub_rows, 0), p.cy - 1);
-            m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off_m + (unsigned)rl * pitch), 0, 0);
-        } else {
-            const int rc = interior ? r : min(max(r, 0), p.cy - 1);
-            soff = (unsigned)rc * pitch;
-            m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_m, (int)soff, 0);
-        }
-        o.m = make_uint4(m.x, m.y, m.z, m.w);
-        // only lanes 0 and 63 ever read `e` (as the DPP fill value): the other lanes leave it undefined
-        // instead of spending two or four v_mov per row on zeros
-        asm("" : "=v"(o.e.x), "=v"(o.e.y), "=v"(o.e.z), "=v"(o.e.w));
-        if (edge_lane) {
-            if constexpr (WIDE) {
-                const u32x4_t e = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_e, (int)soff, 0);
-                o.e = make_uint4(e.x, e.y, e.z, e.w);
-            } else {
-                const u32x2_t e = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off_e, (int)soff, 0);
-                o.e.x = e.x; o.e.y = e.y;
-            }
-        }
-        return o;
-    };
-
-    u32 Hring[HR][4], Uprev[4], Dv[H][4], Dpre[H][4];
-#pragma unroll
-    for (int q = 0; q < 4; q++) {
-        Uprev[q] = 0xffffffffu;
-#pragma unroll
-        for (int t = 0; t < HR; t++) Hring[t][q] = 0xffffffffu;
-#pragma unroll
-        for (int t = 0; t < H; t++) { Dv[t][q] = 0u; Dpre[t][q] = 0xffffffffu; }
-    }
-    u32 mn = 0xffffffffu, mxL = 0u, mxR = 0u;
-    u32 mprev = 0u, mpair1 = 0u, mpair2 = 0u;         // previous max group, pair maxima of groups (g-1, g-2) and (g-2, g-3)
-    u32 lo1 = 0xffffu, lo2 = 0xffffu;                 // minima of the previous two min groups
-    u32 acc = 0;                                      // "failed the test" bits of up to four rows
-    int cnt = 0;                                      // candidates found so far (wave-uniform)
-    const u32 lane8 = (u32)lane << 3;
-
-    RowRegs pf[D];
-#pragma unroll
-    for (int d = 0; d < D; d++) pf[d] = load_row(rs0 + d);
-
-    for (int sb = 0; sb < NRP; sb += U_) {
-#pragma unroll
-        for (int u = 0; u < U_; u++) {
-            const int st = sb + u;                    // pipeline step; row r = rs0 + st
-            const RowRegs cur = pf[u % D];
-            pf[u % D] = load_row(rs0 + st + D);
-            u32 A[NA], Bp[NA];
-            if constexpr (WIDE) {
-                A[0] = from_lane_below(cur.m.x, cur.e.x); A[1] = from_lane_below(cur.m.y, cur.e.y);
-                A[2] = from_lane_below(cur.m.z, cur.e.z); A[3] = from_lane_below(cur.m.w, cur.e.w);
-                A[8] = from_lane_above(cur.m.x, cur.e.x); A[9] = from_lane_above(cur.m.y, cur.e.y);
-                A[10] = from_lane_above(cur.m.z, cur.e.z); A[11] = from_lane_above(cur.m.w, cur.e.w);
-            } else {
-                A[0] = from_lane_below(cur.m.z, cur.e.x); A[1] = from_lane_below(cur.m.w, cur.e.y);
-                A[6] = from_lane_above(cur.m.x, cur.e.x); A[7] = from_lane_above(cur.m.y, cur.e.y);
-            }
-            A[OWN] = cur.m.x; A[OWN + 1] = cur.m.y; A[OWN + 2] = cur.m.z; A[OWN + 3] = cur.m.w;
-            Bp[0] = 0;
-#pragma unroll
-            for (int k = 1; k < NA; k++) Bp[k] = __builtin_amdgcn_alignbit(A[k], A[k - 1], 16);
-            mn = pk_min(pk_min(mn, pk_min(A[OWN], A[OWN + 1])), pk_min(A[OWN + 2], A[OWN + 3]));
-            mxL = pk_max(mxL, pk_max(A[OWN], A[OWN + 1]));
-            mxR = pk_max(mxR, pk_max(A[OWN + 2], A[OWN + 3]));
-
-            u32 L[4], R[4];
-            L[0] = LR<H, 0, 0, NA>::left(A, Bp); R[0] = LR<H, 0, 0, NA>::right(A, Bp);
-            L[1] = LR<H, 1, 0, NA>::left(A, Bp); R[1] = LR<H, 1, 0, NA>::right(A, Bp);
-            L[2] = LR<H, 2, 0, NA>::left(A, Bp); R[2] = LR<H, 2, 0, NA>::right(A, Bp);
-            L[3] = LR<H, 3, 0, NA>::left(A, Bp); R[3] = LR<H, 3, 0, NA>::right(A, Bp);
-            u32 tq[4];
-#pragma unroll
-            for (int q = 0; q < 4; q++) {
-                const u32 v = A[q + OWN];
-                const u32 hrow = pk_max(pk_max(L[q], v), R[q]);
-                u32 Ucur = hrow;
-                if (H > 1) {
-#pragma unroll
-                    for (int t = 0; t < HR; t++)
-                        if (!WIDE || t != u % HR) Ucur = pk_max(Ucur, Hring[t][q]);     // WIDE: slot u % H holds the row H steps back
-                }
-                const u32 bef = pk_max(Uprev[q], L[q]);
-                const u32 pre = pk_max(pk_add_sat(bef, 0x00010001u), R[q]);
-                // decision for the row H steps back (same ring slot): 0 in a half = passed
-                const u32 thr = pk_max(Dpre[u % H][q], Ucur);
-                tq[q] = pk_min(pk_sub_sat(thr, Dv[u % H][q]), 0x00010001u);
-                Dv[u % H][q] = v;
-                Dpre[u % H][q] = pre;
-                if (H > 1) Hring[u % HR][q] = hrow;
-                Uprev[q] = Ucur;
-            }
-            const int t4 = u % 4;                      // row slot inside the accumulator
-            acc |= (tq[0] | (tq[1] << 1) | (tq[2] << 2) | (tq[3] << 3)) << (4 * t4);
-            if (t4 == 3 || u == U_ - 1) {              // flush the candidates of the last t4+1 rows
-                const int rd0 = rs0 + (st - t4) - H;   // decision row of slot 0
-                u32 rowmask = 0;
-#pragma unroll
-                for (int tt = 0; tt <= t4; tt++) {
-                    if constexpr (P > 1) { if (rd0 + tt >= lo_rel && rd0 + tt < hi_rel) rowmask |= 0x000f000fu << (4 * tt); }
-                    else { if (rd0 + tt >= row_lo && rd0 + tt < row_hi) rowmask |= 0x000f000fu << (4 * tt); }
-                }
-                u32 pass = ~acc & rowmask & colmask;
-                acc = 0;
-                // Append to the wave's own list: every round each lane that still has a candidate emits
-                // its lowest one, slots come from a ballot prefix count and the list length stays in a
-                // scalar register.  (An LDS atomicAdd per lane is turned into a serial per-lane scan by
-                // the compiler's atomic optimizer: ~9 SALU instructions per active lane, per flush.)
-                const u32 ebase = (u32)((rd0 - band_lo) << 9) + lane8;
-                for (;;) {
-                    const bool has = pass != 0;
-                    const unsigned long long bal = __ballot(has);
-                    if (bal == 0) break;
-                    if (has) {
-                        const u32 b = (u32)__ffs(pass) - 1u;
-                        pass &= pass - 1;
-                        // bit b: row slot (b >> 2) & 3, pixel 2 * (b & 3) + (b >> 4)
-                        const u32 e = ebase + (((b >> 2) & 3u) << 9) + ((b & 3u) << 1) + (b >> 4);
-                        const int slot = cnt + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                        if (slot < LIST) s_list[w][slot] = (unsigned short)e;
-                    }
-                    cnt += __popcll(bal);
-                }
-            }
-            if ((u + 1) % GM == 0) {                   // close a maximum group: (right cell << 16) | left cell
-                const u32 lo2_ = __builtin_amdgcn_perm(mxR, mxL, 0x05040100u), hi2_ = __builtin_amdgcn_perm(mxR, mxL, 0x07060302u);
-                const u32 m0 = pk_max(lo2_, hi2_);
-                const u32 pair = pk_max(m0, mprev);                   // groups g, g-1
-                s_max[w][sb / GM + (u + 1) / GM - 1][lane] = pk_max(pair, mpair2);   // + groups g-2, g-3
-                mpair2 = mpair1; mpair1 = pair;
-                mprev = m0;
-                mxL = 0u; mxR = 0u;
-            }
-        }
-        if (((sb + U_) % GS) == 0) {                   // close a minimum group (window of three groups)
-            const u32 lo0 = min(mn & 0xffffu, mn >> 16);
-            s_min[w][(sb + U_) / GS - 1][lane] = (unsigned short)min(lo0, min(lo1, lo2));
-            lo2 = lo1; lo1 = lo0;
-            mn = 0xffffffffu;
-        }
-    }
-    __builtin_amdgcn_wave_barrier();
-    __threadfence_block();
-
     const float *sux = s_u, *suy = s_u + BOX * BOX;
-    // Results are buffered in registers and appended KBUF at a time: ONE slot-allocating atomic per
-    // flush per wave, on the counter of this block's shard (= XCD).  A single hot counter costs
-    // ~11 ns per atomic and was 40 % of the kernel.
+
+    int head = 0, tail = 0;                            // candidate ring (wave-uniform)
+    // The exact net gradients are evaluated as soon as the ring holds a full round of 64: the chunk of rows ends
+    // there, the round runs with every lane busy, and the scan resumes (2H + 2 halo rows, L2 hits).  The waves start
+    // in lock step, so the FIRST round of a wave is taken at a staggered fill level: otherwise every wave of the
+    // chip would send its 64 x (2H+3) scattered row fetches to HBM in the same few microseconds.  Without the floor
+    // filter (min_ng <= 0) 2 % of the pixels are candidates and the ring is drained only when nearly full.
+    const bool filter = p.filt_t >= 0.0f && !(p.dbg & 4);
+    int trigger = filter ? 8 + (FAST_ROUND / 8) * (int)(blockIdx.x % 7u) : THRESH;
+
+    // ---- results: buffered in registers, appended KBUF rounds at a time with ONE slot-allocating atomic per flush
+    // per wave on the counter of this block's shard (a single hot counter costs ~11 ns per atomic)
     constexpr int KBUF = 4;
-    int buf_i[KBUF], buf_j[KBUF], nbuf = 0;
+    int buf_i[KBUF], buf_j[KBUF], buf_f[KBUF], nbuf = 0, rounds = 0;
     float buf_ng[KBUF];
     const int shard = blockIdx.x & 7;
     auto flush = [&]() {
+        rounds = 0;
         if (p.dbg & 2) { nbuf = 0; return; }
         unsigned long long bal[KBUF];
         int total = 0;
@@ -509,7 +331,7 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
         for (int k = 0; k < KBUF; k++) { bal[k] = __ballot(k < nbuf); total += __popcll(bal[k]); }
         if (total) {
             unsigned long long basepos = 0;
-            if (lane == 0) { basepos = atomicAdd(&shard_cnt[shard], (unsigned long long)total); atomicAdd(&frame_count[fi], total); }
+            if (lane == 0) basepos = atomicAdd(&shard_cnt[shard], (unsigned long long)total);
             basepos = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(basepos >> 32)) << 32) |
                       (unsigned)__builtin_amdgcn_readfirstlane((int)(basepos & 0xffffffffu));
             int off = 0;
@@ -517,9 +339,10 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
             for (int k = 0; k < KBUF; k++) {
                 if (k < nbuf) {
                     const long long pos = (long long)basepos + off + __popcll(bal[k] & ((1ull << lane) - 1ull));
+                    atomicAdd(&frame_count[buf_f[k]], 1);          // a round can hold candidates of two frames
                     if (pos < cap) {
                         Record rec;
-                        rec.frame = (int32_t)(p.f_lo + fi + p.label_off);
+                        rec.frame = (int32_t)(p.f_lo + buf_f[k] + p.label_off);
                         rec.y = buf_i[k] + p.y0;
                         rec.x = buf_j[k] + p.x0;
                         rec.ng = buf_ng[k];
@@ -531,15 +354,18 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
         }
         nbuf = 0;
     };
-    auto append = [&](int i, int j, float ng) {
+    auto append = [&](int fi, int i, int j, float ng) {
         if ((double)ng > p.min_ng) {                   // localize.py:288
 #pragma unroll
-            for (int k = 0; k < KBUF; k++) if (k == nbuf) { buf_i[k] = i; buf_j[k] = j; buf_ng[k] = ng; }
+            for (int k = 0; k < KBUF; k++) if (k == nbuf) { buf_f[k] = fi; buf_i[k] = i; buf_j[k] = j; buf_ng[k] = ng; }
             nbuf++;
         }
     };
-    // slow exact path: wrapped stencils, saturated pixels, overflow rescans
-    auto process_slow = [&](int i, int j, bool recheck) {
+    auto frame_src = [&](int fi) -> const uint16_t * {
+        return p.movie + ((int64_t)(p.f_lo + fi) * p.Y + p.y0) * p.X + p.x0;
+    };
+    // slow exact path: saturated pixels, overflow rescans
+    auto process_slow = [&](const uint16_t *src, int fi, int i, int j, bool recheck) {
         const float v = (float)src[(int64_t)i * p.X + j];
         if (recheck) {
 #pragma unroll 1
@@ -569,112 +395,291 @@ __global__ __launch_bounds__(FAST_WAVES * 64, (H <= 4 ? FAST_MIN_WAVES : (H <= 6
                 ng = add_rn(ng, sacc);
             }
         }
-        append(i, j, ng);
+        append(fi, i, j, ng);
+    };
+    // exact float32 net gradient of the n (<= 64) oldest ring entries
+    auto exact_round = [&](int n) {
+        if (lane < n) {
+            const int q = (head + lane) & (LIST - 1);
+            const unsigned e = s_pos[q];
+            const int fi = (int)s_fi[q];
+            const int i = (int)(e >> 16), j = (int)(e & 0xffffu) - xoff;
+            const uint16_t *src = frame_src(fi);
+            // the packed test cannot see ties at 65535 (saturating +1): those are rechecked exactly
+            const bool saturated = src[(int64_t)i * p.X + j] == 0xffffu;
+            if (p.dbg & 1) append(fi, i, j, (e & 7) == 0 ? 1e9f : 0.0f);
+            else if (!saturated) append(fi, i, j, exact_ng<H>(src, p.X, p.cy, p.cx, i, j));
+            else process_slow(src, fi, i, j, true);
+        }
+        head += n;
+        if (++rounds == KBUF) flush();
     };
 
-    // list entry -> row, crop column, and the column inside the sub-band's (or the wave's) own lanes
-    auto decode = [&](unsigned e, int &i, int &j, int &jown) {
-        if constexpr (P > 1) {
-            const int le = (int)(e & 511u) >> 3;
-            i = band_lo + (le / NL) * RB + (int)(e >> 9);
-            jown = (le % NL) * 8 + (int)(e & 7u);
-            j = jown - xoff;
-        } else {
-            i = band_lo + (int)(e >> 9);
-            jown = (int)(e & 511u);
-            j = seg * 512 + jown - xoff;
-        }
-    };
-    const int found = cnt;
-    if (found <= LIST) {
-        // pass 1: cheap level-1 bound on every candidate; survivors are compacted in place
-        // (ballot + prefix count) so that the exact evaluation runs with full lanes
-        int kept = 0;
-        for (int q0 = 0; q0 < found; q0 += 64) {
-            const int q = q0 + lane;
-            bool keep = false;
-            unsigned short e = 0;
-            if (q < found) {
-                e = s_list[w][q];
-                int i, j, jown;
-                decode(e, i, j, jown);
-                keep = true;
-                const int jl = (int)(e & 511u);          // column in the wave's lanes: indexes the statistics cells
-                // |ng| <= P_box * (max - min) over statistics cells covering the (2H+3)^2 stencil; candidates whose
-                // stencil wraps or leaves this wave's 512 columns (its sub-band's lanes) are always kept
-                if (i != H && j != H && jown - H - 1 >= 0 && jown + H + 1 <= 8 * NL - 1) {
-                    const int rr = (int)(e >> 9) + H + 1;       // = row - first pipeline row of its (sub-)band
-                    const int jlo = jl - H - 1, jhi = jl + H + 1;
-                    constexpr int NLANE = (2 * H + 2) / 8 + 2;               // lanes (8 columns each) a stencil row can touch
-                    unsigned lo = 0xffffu, hi = 0u;
-                    const unsigned short *mrow = s_min[w][(rr + H + 1) / GS];
-                    const unsigned *xrow = s_max[w][(rr + H + 1) / GM];
-                    const int la = jlo >> 3, lb = jhi >> 3, c0 = jlo >> 2, c1 = jhi >> 2;
+    for (long long unit = unit0; unit < unit1; unit++) {
+        const int fi = (int)(unit / p.upf);
+        const int rem = (int)(unit - (long long)fi * p.upf);
+        // consecutive units = consecutive row ranges of one 512-column segment (P > 1: `band` counts groups of P row ranges, seg = 0)
+        const int bands = p.upf / p.segs;
+        const int seg = rem / bands, band = rem - seg * bands;
+        const int c8 = P > 1 ? lane % NL : seg * 64 + lane;
+        const bool lane_valid = c8 < nch;
+        const int cm = min(c8, nch - 1);
+        const uint16_t *src = frame_src(fi);
+        const int col_m = cm * 8;
+        const int col_l = cm > 0 ? col_m - NB : col_m;                // clamped copies feed invalid pixels only
+        const int col_r = cm + 1 < nch ? col_m + 8 : col_m + 8 - NB;
+
+        // which of the lane's 8 pixels may hold a maximum: even pixels -> bits 0..3, odd -> bits 16..19,
+        // replicated for the four row slots of the candidate accumulator
+        u32 colmask = 0;
+        bool wrapcol = false;                              // a column with j == H: its stencil wraps to the last column
+        if (lane_valid) {
 #pragma unroll
-                    for (int t = 0; t < NLANE; t++) {
-                        const int l = min(la + t, lb);
-                        lo = min(lo, (unsigned)mrow[l]);
-                        const unsigned sv = xrow[l];
-                        if (2 * l >= c0) hi = max(hi, sv & 0xffffu);         // left cell of lane l is cell 2l
-                        if (2 * l + 1 <= c1) hi = max(hi, sv >> 16);
+            for (int b = 0; b < 8; b++) {
+                int j = c8 * 8 + b - xoff;
+                if (j >= H && j < p.cx - H - 1) colmask |= 1u << ((b >> 1) + 16 * (b & 1));
+                if (j == H) wrapcol = true;
+            }
+            colmask *= 0x1111u;
+        }
+        // lanes whose stencils reach columns no lane of this wave holds take no floor
+        const bool no_floor = wrapcol || (P == 1 && ((seg > 0 && lane < NWL) || (seg + 1 < p.segs && lane >= 64 - NWL)));
+
+        // per-lane byte offsets inside a row (32-bit) + a wave-uniform row base: the loads use
+        // SGPR-base + VGPR-offset addressing, no 64-bit vector address arithmetic per row.
+        // Neighbour pixels come from the adjacent lanes' registers (DPP), not from memory: overlapping
+        // 8-byte loads next to the 16-byte ones doubled the HBM-side traffic (requests to a line whose
+        // fill is still in flight are not merged).  Only lanes 0 and 63 load the 4 pixels beyond the wave.
+        const unsigned off_m = (unsigned)col_m * 2u;
+        const unsigned off_e = (unsigned)(lane == 0 ? col_l : col_r) * 2u;
+        // a sub-band's row lies wholly inside its lanes, and so does the row of a frame at most 512 pixels wide: the
+        // pixels lanes 0 and 63 would take from beyond the wave then only feed masked positions
+        const bool any_edge = P == 1 && p.segs > 1;
+        const bool edge_lane = lane == 0 || lane == 63;
+        // num_records bounds the descriptor at the end of the frames of this call: when the width is not a
+        // multiple of 8 the last chunk of a row reads into the next row (masked columns), and on the very last
+        // row it would read past the movie — the buffer unit returns 0 there instead
+        const long long remaining = ((long long)(p.nframes - fi) * p.Y * p.X - ((long long)p.y0 * p.X + p.x0 - xoff)) * 2;
+        const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<uint16_t *>(src - xoff), 0, (int)(remaining < 0x7fffffffLL ? remaining : 0x7fffffffLL),
+            0x00020000 /* raw 32-bit buffer, gfx94x/gfx950 */);
+
+        const int b0 = band * (p.rbu * P);                 // first row of sub-band 0
+        const int unit_rows = min(p.rbu, p.cy - b0);       // rows of sub-band 0 (the others may hold fewer: masked)
+        int o = 0;                                         // rows of the unit already decided
+        while (o < unit_rows) {
+            // ---- one chunk: rows [clo, clo + len) of every sub-band (len shrinks if the ring fills up) ----
+            const int clo = b0 + o, len = unit_rows - o;
+            const int rs0 = clo - H - 1;
+            const int nr = len + 2 * H + 1;                // pipeline rows: one row above the stencils of row clo .. H below the last row
+            // rows that may hold a maximum, in sub-band 0's numbering
+            const int lo_rel = max(clo + sub_rows, H) - sub_rows;
+            const int hi_rel = min(min(clo + len, b0 + p.rbu) + sub_rows, min(p.cy, p.cy - H - 1)) - sub_rows;
+            // interior chunks never touch a row outside the crop: no clamping in their row loop
+            const bool interior = P == 1 && rs0 >= 0 && rs0 + nr + U_ + D <= p.cy;
+            auto load_row = [&](int r) -> RowRegs {
+                RowRegs ro;
+                unsigned soff = 0;
+                u32x4_t m;
+                if constexpr (P > 1) {
+                    // every sub-band clamps its own row: the row offset joins the lane's column offset
+                    const int rl = min(max(r + sub_rows, 0), p.cy - 1);
+                    m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off_m + (unsigned)rl * pitch), 0, 0);
+                } else {
+                    const int rc = interior ? r : min(max(r, 0), p.cy - 1);
+                    soff = (unsigned)rc * pitch;
+                    m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_m, (int)soff, 0);
+                }
+                ro.m = make_uint4(m.x, m.y, m.z, m.w);
+                // only lanes 0 and 63 ever read `e` (as the DPP fill value): the other lanes leave it undefined
+                // instead of spending two or four v_mov per row on zeros
+                asm("" : "=v"(ro.e.x), "=v"(ro.e.y), "=v"(ro.e.z), "=v"(ro.e.w));
+                if (any_edge && edge_lane) {
+                    if constexpr (WIDE) {
+                        const u32x4_t e = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_e, (int)soff, 0);
+                        ro.e = make_uint4(e.x, e.y, e.z, e.w);
+                    } else {
+                        const u32x2_t e = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off_e, (int)soff, 0);
+                        ro.e.x = e.x; ro.e.y = e.y;
                     }
-                    if ((double)(hi - lo) * p.bound_c < p.min_ng) keep = false;
+                }
+                return ro;
+            };
+
+            u32 Hring[HR][4], Uprev[4], Dv[H][4], Dpre[H][4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+                Uprev[q] = 0xffffffffu;
+#pragma unroll
+                for (int t = 0; t < HR; t++) Hring[t][q] = 0xffffffffu;
+#pragma unroll
+                for (int t = 0; t < H; t++) { Dv[t][q] = 0u; Dpre[t][q] = 0xffffffffu; }
+            }
+            u32 mn = 0xffffffffu;                             // packed minimum of the lane's pixels since the last flush
+            u32 gring[H];                                     // the same for the H flush groups before (>= 2 rows each: 2H + 2 rows back)
+#pragma unroll
+            for (int t = 0; t < H; t++) gring[t] = 0xffffffffu;
+            u32 F = 0u;                                       // floor, both halves
+            u32 acc = 0;                                      // "failed the test" bits of up to four rows
+            const int tail0 = tail;                           // ring state at the start of the chunk
+            int added = 0;                                    // candidates of this chunk, counted even when the ring is full
+
+            RowRegs pf[D];
+#pragma unroll
+            for (int d = 0; d < D; d++) pf[d] = load_row(rs0 + d);
+
+            int sb = 0;
+            for (; sb < nr; sb += U_) {
+#pragma unroll
+                for (int u = 0; u < U_; u++) {
+                    const int st = sb + u;                    // pipeline step; row r = rs0 + st
+                    const RowRegs cur = pf[u % D];
+                    pf[u % D] = load_row(rs0 + st + D);
+                    u32 A[NA], Bp[NA];
+                    if constexpr (WIDE) {
+                        A[0] = from_lane_below(cur.m.x, cur.e.x); A[1] = from_lane_below(cur.m.y, cur.e.y);
+                        A[2] = from_lane_below(cur.m.z, cur.e.z); A[3] = from_lane_below(cur.m.w, cur.e.w);
+                        A[8] = from_lane_above(cur.m.x, cur.e.x); A[9] = from_lane_above(cur.m.y, cur.e.y);
+                        A[10] = from_lane_above(cur.m.z, cur.e.z); A[11] = from_lane_above(cur.m.w, cur.e.w);
+                    } else {
+                        A[0] = from_lane_below(cur.m.z, cur.e.x); A[1] = from_lane_below(cur.m.w, cur.e.y);
+                        A[6] = from_lane_above(cur.m.x, cur.e.x); A[7] = from_lane_above(cur.m.y, cur.e.y);
+                    }
+                    A[OWN] = cur.m.x; A[OWN + 1] = cur.m.y; A[OWN + 2] = cur.m.z; A[OWN + 3] = cur.m.w;
+                    Bp[0] = 0;
+#pragma unroll
+                    for (int k = 1; k < NA; k++) Bp[k] = __builtin_amdgcn_alignbit(A[k], A[k - 1], 16);
+                    mn = pk_min(pk_min(mn, pk_min(A[OWN], A[OWN + 1])), pk_min(A[OWN + 2], A[OWN + 3]));
+
+                    u32 L[4], R[4];
+                    L[0] = LR<H, 0, 0, NA>::left(A, Bp); R[0] = LR<H, 0, 0, NA>::right(A, Bp);
+                    L[1] = LR<H, 1, 0, NA>::left(A, Bp); R[1] = LR<H, 1, 0, NA>::right(A, Bp);
+                    L[2] = LR<H, 2, 0, NA>::left(A, Bp); R[2] = LR<H, 2, 0, NA>::right(A, Bp);
+                    L[3] = LR<H, 3, 0, NA>::left(A, Bp); R[3] = LR<H, 3, 0, NA>::right(A, Bp);
+                    u32 tq[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) {
+                        const u32 v = A[q + OWN];
+                        const u32 hrow = pk_max(pk_max(L[q], v), R[q]);
+                        u32 Ucur = hrow;
+                        if (H > 1) {
+#pragma unroll
+                            for (int t = 0; t < HR; t++)
+                                if (!WIDE || t != u % HR) Ucur = pk_max(Ucur, Hring[t][q]);     // WIDE: slot u % H holds the row H steps back
+                        }
+                        const u32 bef = pk_max(Uprev[q], L[q]);
+                        const u32 pre = pk_max(pk_add_sat(bef, 0x00010001u), R[q]);
+                        // decision for the row H steps back (same ring slot): 0 in a half = passed
+                        const u32 thr = pk_max(pk_max(Dpre[u % H][q], Ucur), F);
+                        tq[q] = pk_min(pk_sub_sat(thr, Dv[u % H][q]), 0x00010001u);
+                        Dv[u % H][q] = v;
+                        Dpre[u % H][q] = pre;
+                        if (H > 1) Hring[u % HR][q] = hrow;
+                        Uprev[q] = Ucur;
+                    }
+                    const int t4 = u % 4;                      // row slot inside the accumulator
+                    acc |= (tq[0] | (tq[1] << 1) | (tq[2] << 2) | (tq[3] << 3)) << (4 * t4);
+                    if (t4 == 3 || u == U_ - 1) {              // flush the candidates of the last t4+1 rows
+                        const int rd0 = rs0 + (st - t4) - H;   // decision row of slot 0
+                        u32 rowmask = 0;
+#pragma unroll
+                        for (int tt = 0; tt <= t4; tt++)
+                            if (rd0 + tt >= lo_rel && rd0 + tt < hi_rel) rowmask |= 0x000f000fu << (4 * tt);
+                        u32 pass = ~acc & rowmask & colmask;
+                        acc = 0;
+                        // Append to the wave's ring: every round each lane that still has a candidate emits its
+                        // lowest one, slots come from a ballot prefix count and the ring state stays in scalar
+                        // registers.  (An LDS atomicAdd per lane is turned into a serial per-lane scan by the
+                        // compiler's atomic optimizer: ~9 SALU instructions per active lane, per flush.)
+                        const u32 ebase = ((u32)(rd0 + sub_rows) << 16) + (u32)(c8 << 3);
+                        for (;;) {
+                            const bool has = pass != 0;
+                            const unsigned long long bal = __ballot(has);
+                            if (bal == 0) break;
+                            if (has) {
+                                const u32 b = (u32)__ffs(pass) - 1u;
+                                pass &= pass - 1;
+                                // bit b: row slot (b >> 2) & 3, pixel 2 * (b & 3) + (b >> 4)
+                                const u32 e = ebase + (((b >> 2) & 3u) << 16) + ((b & 3u) << 1) + (b >> 4);
+                                const int slot = tail + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
+                                if (slot - head < LIST) { s_pos[slot & (LIST - 1)] = e; s_fi[slot & (LIST - 1)] = (unsigned)fi; }
+                            }
+                            const int nb_ = __popcll(bal);
+                            added += nb_;
+                            tail = min(tail + nb_, head + LIST);
+                        }
+                        // ---- the floor for the decisions of the next flush group ----
+                        if (filter) {
+                            const u32 gm = pk_min(mn, __builtin_amdgcn_alignbit(mn, mn, 16));    // both halves = the lane's minimum
+                            u32 wmin = gm;
+#pragma unroll
+                            for (int t = 0; t < H; t++) wmin = pk_min(wmin, gring[t]);
+#pragma unroll
+                            for (int t = H - 1; t > 0; t--) gring[t] = gring[t - 1];
+                            gring[0] = gm;
+                            mn = 0xffffffffu;
+                            u32 wl = wmin, wr = wmin;
+#pragma unroll
+                            for (int t = 0; t < NWL; t++) {
+                                wl = from_lane_below(wl, 0xffffffffu); wr = from_lane_above(wr, 0xffffffffu);
+                                wmin = pk_min(wmin, pk_min(wl, wr));
+                            }
+                            // the next group decides rows r - H + 1 .. r - H + 4 (r = this row); the row with index H
+                            // reads its upper ring row from the LAST row (wrap): no floor then
+                            const int rnext = rs0 + st + 1 - H + sub_rows;
+                            const float fl = fmaf(p.filt_alpha, (float)(wmin & 0xffffu), p.filt_t);
+                            u32 fi_ = (u32)fminf(fl, 65535.0f);                                    // fl >= 0
+                            fi_ = (no_floor || (rnext <= H && rnext + 3 >= H)) ? 0u : fi_;
+                            F = fi_ | (fi_ << 16);
+                        }
+                    }
+                }
+                if (tail - head >= trigger || added > LIST - 64) { sb += U_; break; }
+            }
+            // rows decided: every row whose decision step lies before sb
+            const int dn = min(len, sb - 2 * H - 1);
+            __builtin_amdgcn_wave_barrier();
+            __threadfence_block();
+            if (added > LIST - (tail0 - head)) {
+                // More candidates than the ring holds: a saturated (65535) plateau flooded the packed test.
+                // Drop this chunk's entries and rescan its rows pixel by pixel with the exact test (slow, rare).
+                tail = tail0;
+                const int wcols = P > 1 ? NL * 8 : 512;
+                for (int s = 0; s < P; s++) {
+                    const int r_lo = max(clo + s * p.rbu, H), r_hi = min(min(clo + dn, b0 + p.rbu) + s * p.rbu, p.cy - H - 1);
+                    for (int idx0 = 0; idx0 < dn * wcols; idx0 += 64) {
+                        const int idx = idx0 + lane;
+                        const int i = clo + s * p.rbu + idx / wcols;
+                        const int ja = (P > 1 ? 0 : seg * 512) + idx % wcols, j = ja - xoff;
+                        if (i >= r_lo && i < r_hi && ja < nch * 8 && j >= H && j < p.cx - H - 1) process_slow(src, fi, i, j, true);
+                        flush();
+                    }
                 }
             }
-            const unsigned long long bal = __ballot(keep);
-            const int pos = kept + __popcll(bal & ((1ull << lane) - 1ull));
-            __builtin_amdgcn_wave_barrier();
-            if (keep) s_list[w][pos] = e;     // pos <= q: never overwrites an unread entry of a later chunk
-            kept += __popcll(bal);
-        }
-        __builtin_amdgcn_wave_barrier();
-        __threadfence_block();
-        // pass 2: exact float32 net gradient
-        int rounds = 0;
-        for (int q0 = 0; q0 < kept; q0 += 64) {
-            const int q = q0 + lane;
-            if (q < kept) {
-                const unsigned e = s_list[w][q];
-                int i, j, jown;
-                decode(e, i, j, jown);
-                const bool wraps = (i == H) || (j == H);
-                // the packed test cannot see ties at 65535 (saturating +1): those are rechecked exactly
-                const bool saturated = src[(int64_t)i * p.X + j] == 0xffffu;
-                if (p.dbg & 1) append(i, j, (e & 7) == 0 ? 1e9f : 0.0f);
-                else if (!wraps && !saturated) append(i, j, exact_ng_noWrap<H>(src, p.X, i, j));
-                else process_slow(i, j, saturated);
+            // (evaluating in place, inside the row loop, was tried: the scan's 120 live registers and the round's 50
+            // do not fit, and the spills land in the row loop — 5.1 ms instead of 1.5)
+            if (!filter || tail - head >= trigger) {
+                while (tail - head >= 64) exact_round(64);
+                if (filter) {
+                    if (tail - head >= FAST_ROUND || (trigger < FAST_ROUND && tail > head)) exact_round(tail - head);
+                    trigger = FAST_ROUND;
+                }
             }
-            if (++rounds == KBUF) { flush(); rounds = 0; }
-        }
-        flush();
-    } else {
-        // More candidates than local maxima can exist: a saturated (65535) plateau flooded the
-        // packed test.  Rescan this band pixel by pixel with the exact test (slow, rare).
-        const int j0 = seg * 512 - xoff, j1 = min(j0 + 512, p.cx);
-        for (int idx0 = 0; idx0 < RB * 512; idx0 += 64) {
-            const int idx = idx0 + lane;
-            if constexpr (P > 1) {
-                int i, j, jown;
-                decode((unsigned)idx, i, j, jown);       // same layout as a list entry: (row << 9) | column in the wave's lanes
-                const int sb_lo = band_lo + (((idx & 511) >> 3) / NL) * RB;
-                const int rlo = max(sb_lo, H), rhi = min(min(sb_lo + RB, p.cy), p.cy - H - 1);
-                if (i >= rlo && i < rhi && jown < nch * 8 && j >= H && j < p.cx - H - 1) process_slow(i, j, true);
-            } else {
-                const int i = band_lo + idx / 512, j = j0 + (idx & 511);
-                if (i >= row_lo && i < row_hi && j < j1 && j >= H && j < p.cx - H - 1) process_slow(i, j, true);
-            }
-            flush();
+            o += dn;
         }
     }
+    while (tail - head >= 64) exact_round(64);
+    if (tail > head) exact_round(tail - head);
+    flush();
 }
 
-template <int H, int RB, int D, int P = 1>
+template <int H, int D, int P = 1>
 static int launch_fast(const FastParams &p, const float *d_tab, Record *recs, long long cap,
                        unsigned long long *shard_cnt, int *frame_count, hipStream_t s)
 {
-    long long blocks = 8LL * p.bpf * ((p.nframes + 7) / 8);
+    const long long blocks = (p.units + p.upw - 1) / p.upw;
     if (blocks > 0x7fffffffLL) { set_error("identify: too many blocks (%lld)", blocks); return PMI_ERR_ARG; }
-    hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, RB, D, P>), dim3((unsigned)blocks), dim3(FAST_WAVES * 64), 0, s,
+    hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P>), dim3((unsigned)blocks), dim3(64), 0, s,
                        p, d_tab, recs, cap, shard_cnt, frame_count);
     PMI_HIP(hipGetLastError());
     return PMI_OK;
@@ -702,6 +707,8 @@ static bool unit_vectors_match()
     return ok;
 }
 
+static int g_fast_cus = 0;
+
 // Returns PMI_OK and sets *handled when the fast path applies.
 int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
                          int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
@@ -714,28 +721,52 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     if (h < 1 || h > 8) return PMI_OK;
     if (!unit_vectors_match()) return PMI_OK;          // never expected; the generic kernel uses the runtime table
     if ((X & 1) || cx < 16 || ((uintptr_t)d_movie & 3)) return PMI_OK;       // rows must start 4-byte aligned (buffer loads); the crop may not
-    if (cy > 65535 || cx > 65535 || X > 65535 || Y * X * 2 >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets
-    int RB = h == 1 ? 16 : (h == 2 ? 32 : 64);           // keeps the per-wave candidate list <= 8.5 KB of LDS
-    // narrow frames (box 7): several bands side by side in one wavefront instead of idle lanes
+    if (cy > 65535 || cx > 65520 || X > 65535 || Y * X * 2 >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets, 16-bit list columns
+    if (!g_fast_cus) {
+        int dev = 0;
+        PMI_HIP(hipGetDevice(&dev));
+        PMI_HIP(hipDeviceGetAttribute(&g_fast_cus, hipDeviceAttributeMultiprocessorCount, dev));
+    }
+    // narrow frames: several row ranges side by side in one wavefront instead of idle lanes
     const int nch = ((x0 & 7) + cx + 7) / 8;
     static const bool no_pack = getenv("PMI_IDENTIFY_NOPACK") != nullptr;
     int pack = 1;
     if (h >= 2 && h <= 6 && !no_pack) {
-        if (nch <= 8 && h == 3) { pack = 8; RB = cy >= 256 ? 32 : (cy >= 128 ? 16 : 8); }   // <= 64 px wide: eight bands side by side
-        else if (nch <= 16 && h <= 4) { pack = 4; RB = (h > 2 && cy >= 256) ? 64 : 32; }     // short frames: shorter bands, no idle sub-band
+        if (nch <= 8 && h == 3) pack = 8;              // <= 64 px wide: eight row ranges side by side
+        else if (nch <= 16 && h <= 4) pack = 4;
         else if (nch <= 32) pack = 2;
     }
     FastParams p;
     p.movie = (const uint16_t *)d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;
     p.f_lo = f_lo; p.label_off = label_off; p.nframes = nframes; p.box = box; p.min_ng = min_ng;
-    p.bands = (cy + RB * pack - 1) / (RB * pack);
     p.segs = pack > 1 ? 1 : (nch + 63) / 64;
-    p.bpf = (p.bands * p.segs + FAST_WAVES - 1) / FAST_WAVES;
-    // ng is a linear functional sum_p w(p) f(p) of the (2H+3)^2 neighbourhood with sum_p w(p) = 0 (a constant
-    // image has no gradient), hence |ng| <= P_box * (max - min), P_box = sum of the positive weights
-    // (35.06 for box 7; the cruder sum of |ux| + |uy| is 60.9).  Double precision, +0.1 % margin for the
-    // float32 rounding of the reference's own summation.
-    double c = 0.0;
+    // Rows per unit: long units amortise the 2H + 2 pipeline rows a unit spends on its halo, short ones balance the
+    // persistent waves (every wave runs ceil(units / waves) units).  Pick the length with the least total work.
+    const long long waves = (long long)g_fast_cus * 4 * fast_waves_per_simd(h);
+    static const int force_rbu = getenv("PMI_IDENTIFY_RBU") ? atoi(getenv("PMI_IDENTIFY_RBU")) : 0;
+    int best_rbu = 0;
+    double best_cost = 0.0;
+    const int full = (cy + pack - 1) / pack;
+    const int cand_rbu[] = {full, 1024, 512, 256, 128, 64, 32, 16, 8};
+    for (int r : cand_rbu) {
+        if (r > full || r < 1 || (r < 8 && r != full)) continue;
+        if (force_rbu > 0) r = std::min(force_rbu, full);
+        const long long upf = (long long)((cy + r * pack - 1) / (r * pack)) * p.segs;
+        const long long units = upf * nframes;
+        const long long per_wave = (units + waves - 1) / waves;
+        const double cost = (double)per_wave * (r + 2 * h + 2);      // pipeline rows of the busiest wave
+        if (!best_rbu || cost < best_cost) { best_rbu = r; best_cost = cost; }
+    }
+    p.rbu = best_rbu;
+    p.upf = ((cy + p.rbu * pack - 1) / (p.rbu * pack)) * p.segs;
+    p.units = (long long)p.upf * nframes;
+    const long long blocks = std::min<long long>(p.units, waves);
+    p.upw = (int)((p.units + blocks - 1) / blocks);
+    // Floor filter (see the kernel): ng = sum_p w(p) f(p) over the (2H+3)^2 neighbourhood, sum_p w(p) = 0, positive
+    // weights (total P_box) inside the box only.  N_K = negative weight in the rows a <= 2H - 3 of the neighbourhood,
+    // the ones certainly behind the scan when it decides (a flush group is at most 4 rows).  Double precision;
+    // 0.1 % margin for the float32 rounding of the reference's own summation.
+    double P_box = 0.0, N_K = 0.0;
     {
         const int n = 2 * h + 3;
         std::vector<double> wgt((size_t)n * n, 0.0);
@@ -746,44 +777,50 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
                 wgt[(size_t)(k + 2) * n + (l + 1)] += vy / r; wgt[(size_t)k * n + (l + 1)] -= vy / r;
                 wgt[(size_t)(k + 1) * n + (l + 2)] += vx / r; wgt[(size_t)(k + 1) * n + l] -= vx / r;
             }
-        for (double v : wgt) if (v > 0) c += v;
+        for (int a = 0; a < n; a++)
+            for (int b = 0; b < n; b++) {
+                const double v = wgt[(size_t)a * n + b];
+                if (v > 0) P_box += v;
+                else if (a <= 2 * h - 3) N_K -= v;
+            }
     }
-    p.bound_c = c * 1.001;
+    if (min_ng > 0.0 && std::isfinite(min_ng)) {
+        p.filt_alpha = (float)(N_K / P_box * 0.998);
+        p.filt_t = (float)std::max(0.0, min_ng / (P_box * 1.001) - 1.0);     // one count of slack for the float32 evaluation
+    } else {
+        p.filt_alpha = 0.0f; p.filt_t = -1.0f;
+    }
     static const int dbg = getenv("PMI_IDENTIFY_DBG") ? atoi(getenv("PMI_IDENTIFY_DBG")) : 0;
     p.dbg = dbg;
     int rc;
     switch (h) {
-    case 1: rc = launch_fast<1, 16, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 1: rc = launch_fast<1, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     case 2:
-        if (pack == 4) rc = launch_fast<2, 32, 2, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 2) rc = launch_fast<2, 32, 2, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else rc = launch_fast<2, 32, FAST_D_H2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        if (pack == 4) rc = launch_fast<2, 2, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 2) rc = launch_fast<2, 2, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<2, FAST_D_H2>(p, d_tab, recs, cap, n_total, frame_count, s);
         break;
     case 3:
-        if (pack == 8 && RB == 32) rc = launch_fast<3, 32, FAST_D_H3, 8>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 8 && RB == 16) rc = launch_fast<3, 16, FAST_D_H3, 8>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 8) rc = launch_fast<3, 8, FAST_D_H3, 8>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 4 && RB == 64) rc = launch_fast<3, 64, FAST_D_H3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 4) rc = launch_fast<3, 32, FAST_D_H3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 2) rc = launch_fast<3, 64, FAST_D_H3, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else rc = launch_fast<3, 64, FAST_D_H3>(p, d_tab, recs, cap, n_total, frame_count, s);
+        if (pack == 8) rc = launch_fast<3, FAST_D_H3, 8>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 4) rc = launch_fast<3, FAST_D_H3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 2) rc = launch_fast<3, FAST_D_H3, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<3, FAST_D_H3>(p, d_tab, recs, cap, n_total, frame_count, s);
         break;
     case 4:
-        if (pack == 4 && RB == 64) rc = launch_fast<4, 64, 4, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 4) rc = launch_fast<4, 32, 4, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 2) rc = launch_fast<4, 64, 4, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else rc = launch_fast<4, 64, FAST_D_H4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        if (pack == 4) rc = launch_fast<4, 4, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 2) rc = launch_fast<4, 4, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<4, FAST_D_H4>(p, d_tab, recs, cap, n_total, frame_count, s);
         break;
     case 5:
-        if (pack == 2) rc = launch_fast<5, 64, 2, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else rc = launch_fast<5, 64, FAST_D_H5>(p, d_tab, recs, cap, n_total, frame_count, s);
+        if (pack == 2) rc = launch_fast<5, 2, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<5, FAST_D_H5>(p, d_tab, recs, cap, n_total, frame_count, s);
         break;
     case 6:
-        if (pack == 2) rc = launch_fast<6, 64, 3, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else rc = launch_fast<6, 64, FAST_D_H6>(p, d_tab, recs, cap, n_total, frame_count, s);
+        if (pack == 2) rc = launch_fast<6, 3, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<6, FAST_D_H6>(p, d_tab, recs, cap, n_total, frame_count, s);
         break;
-    case 7: rc = launch_fast<7, 64, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
-    default: rc = launch_fast<8, 64, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 7: rc = launch_fast<7, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    default: rc = launch_fast<8, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
     }
     if (rc == PMI_OK) *handled = true;
     return rc;

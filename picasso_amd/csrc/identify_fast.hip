@@ -10,20 +10,19 @@
 //     16-byte global load per row) plus the 4 pixels on either side, taken from the
 //     neighbouring lanes' registers by DPP wave_shr/wave_shl (lanes 0 and 63 load
 //     theirs with one masked 8-byte load);
-//   * horizontal: L = max of the h pixels left of each pixel, R = max of the h to
-//     the right, Hrow = max(L, v, R), all as v_pk_max_u16 on aligned/odd pixel pairs
-//     (odd pairs by v_alignbit);
-//   * vertical: U[r] = max(Hrow[r-h+1..r]) from a register ring; a pixel of row r'
-//     is the FIRST maximum of its window iff v > max(U[r'-1], L) and
-//     v >= max(R, U[r'+h]); the first half is folded into pre = max(sat(bef+1), R)
-//     at row r', the second is tested h rows later: sat(max(pre, U) - v) == 0;
-//   * candidates (~2 % of pixels on shot noise) go to a per-wave LDS list; a range
-//     bound |ng| <= P_box * (max - min over statistics cells covering the stencil)
-//     rejects the ones that cannot reach min_ng without touching memory again; the
-//     survivors get the exact float32 net gradient in the reference's (k,l) order.
+//   * horizontal: Hrow = maximum of the 2h+1 pixels around each pixel, as v_pk_max_u16 on aligned / odd
+//     pixel pairs (odd pairs by v_alignbit), window by doubling;
+//   * vertical: U[r] = max(Hrow[r-h..r]) from a register ring; W[r'] = max(U[r'+h], U[r']) is the maximum of the
+//     (2h+1)^2 window of row r', known h rows after it streamed in.  A pixel is a CANDIDATE iff it equals W and
+//     reaches the floor (below): sat(max(W, floor) - v) == 0;
+//   * the floor rejects maxima that cannot reach min_ng whatever their neighbourhood (the shot-noise maxima,
+//     2 % of all pixels), see the kernel;
+//   * candidates go to a per-wave ring in LDS; the exact float32 net gradient is evaluated for 32..64 of them
+//     at a time, in the reference's (k,l) order, and the same neighbourhood decides whether the candidate is the
+//     FIRST maximum of its window (np.argmax: strictly greater than the window pixels before it).
 //
-// HBM traffic: every pixel is fetched once per band plus 2(h+2) halo rows
-// (RB = 64: +12.5 %, absorbed by L2/MALL because a frame's bands run on one XCD).
+// HBM traffic: every pixel is fetched once; the 2h+2 halo rows of a unit were fetched by the same wave a few
+// steps earlier (L2); the neighbourhoods of the candidates are fetched again (11 rows x 64 B each).
 #include <algorithm>
 #include <cmath>
 #include <cstdlib>
@@ -119,7 +118,7 @@ struct FastParams {
 };
 
 #ifndef FAST_D_H3
-#define FAST_D_H3 6          // rows prefetched ahead in the box-7 scan (divides its unroll period of 6): 6 instead of 3, 1.65 -> 1.60 ms
+#define FAST_D_H3 3          // rows prefetched ahead in the box-7 scan (divides its unroll period of 6).  6 / 3 / 2 -> 1.45 / 1.26 / 1.25 ms on one box: the twelve registers a deeper prefetch holds are worth more to the scheduler
 #endif
 #ifndef FAST_D_H2
 #define FAST_D_H2 2
@@ -152,24 +151,17 @@ __device__ __forceinline__ u32 pair_at(const u32 (&A)[NA], const u32 (&Bp)[NA])
     else return Bp[(S + NB + 1) / 2];
 }
 
-// Q = own pair 0..3 (pixels 2Q, 2Q+1)
-template <int H, int Q, int T, int NA>
-struct LR {
-    static __device__ __forceinline__ u32 left(const u32 (&A)[NA], const u32 (&Bp)[NA])
-    {
-        constexpr int c0 = 2 * Q;
-        u32 v = pair_at<c0 - H + T, NA>(A, Bp);
-        if constexpr (T + 1 < H) return pk_max(v, LR<H, Q, T + 1, NA>::left(A, Bp));
-        else return v;
+// maximum of the LEN packed pairs at offsets S .. S + LEN - 1, by doubling (overlapping halves when LEN is not a
+// power of two); identical sub-windows of neighbouring pixel pairs are shared by common-subexpression elimination
+template <int LEN, int S, int NA>
+__device__ __forceinline__ u32 wmax(const u32 (&A)[NA], const u32 (&Bp)[NA])
+{
+    if constexpr (LEN == 1) return pair_at<S, NA>(A, Bp);
+    else {
+        constexpr int P2 = (LEN & (LEN - 1)) == 0 ? LEN / 2 : (LEN >= 16 ? 16 : (LEN >= 8 ? 8 : (LEN >= 4 ? 4 : 2)));
+        return pk_max(wmax<P2, S, NA>(A, Bp), wmax<P2, S + LEN - P2, NA>(A, Bp));
     }
-    static __device__ __forceinline__ u32 right(const u32 (&A)[NA], const u32 (&Bp)[NA])
-    {
-        constexpr int c0 = 2 * Q;
-        u32 v = pair_at<c0 + 1 + T, NA>(A, Bp);
-        if constexpr (T + 1 < H) return pk_max(v, LR<H, Q, T + 1, NA>::right(A, Bp));
-        else return v;
-    }
-};
+}
 
 struct RowRegs { uint4 m; uint4 e; };   // 8 own pixels + (lanes 0 / 63 only) the 4 or 8 pixels beyond the wave's edge (e.z, e.w: boxes 11, 13)
 
@@ -186,9 +178,11 @@ __device__ __forceinline__ u32 from_lane_above(u32 v, u32 edge) { return (u32)__
 // (numba wraps negative indices) — only the first row and the first column of the neighbourhood can wrap, and they
 // are addressed separately here, so the same code serves every candidate.  The rows are only 2-byte aligned;
 // gfx950 runs global loads in unaligned mode.
+// `first` (in/out): the centre is still the FIRST maximum of its window after the rows seen so far — strictly greater
+// than the window pixels before it in row-major order, not smaller than those after it (np.argmax, localize.py:128).
 template <int H, int K0, int K1>
 __device__ __forceinline__ float exact_ng_rows(const uint16_t *__restrict__ base, const uint16_t *__restrict__ row0w,
-                                               int64_t X, int c0w, float ng)
+                                               int64_t X, int c0w, float ng, float &vc, bool &first_max)
 {
     // base = &src[i - H - 1][j - H]: neighbourhood row t, column 1;  row0w = &src[wrapped first row][j - H];
     // c0w = (wrapped first column) - (j - H): offset of the neighbourhood's column 0 from column 1 (-1 unless it wraps)
@@ -210,11 +204,14 @@ __device__ __forceinline__ float exact_ng_rows(const uint16_t *__restrict__ base
         if (b == 0) return (float)first[r];
         return (float)(((b - 1) & 1) ? (pk[r][(b - 1) >> 1] >> 16) : (pk[r][(b - 1) >> 1] & 0xffffu));
     };
+    if (K0 == 0) vc = px(H + 1, H + 1);                            // the centre row belongs to the first batch
 #pragma unroll
     for (int k = K0; k < K1; k++) {
 #pragma unroll
         for (int l = 0; l < BOX; l++) {
             if (k == H && l == H) continue;                        // the centre is skipped (its unit vector is 0/0)
+            const float o = px(k + 1, l + 1);
+            first_max = first_max && ((k < H || (k == H && l < H)) ? vc > o : vc >= o);
             // window pixel (k, l) sits at neighbourhood (k+1, l+1); the unit vectors are literals
             const float cy = unit_y<H>(k, l), cx = unit_x<H>(k, l);
             const float gy = sub_rn(px(k + 2, l + 1), px(k, l + 1));
@@ -229,18 +226,20 @@ __device__ __forceinline__ float exact_ng_rows(const uint16_t *__restrict__ base
 }
 
 template <int H>
-__device__ __forceinline__ float exact_ng(const uint16_t *__restrict__ src, int64_t X, int cy, int cx, int i, int j)
+__device__ __forceinline__ float exact_ng(const uint16_t *__restrict__ src, int64_t X, int cy, int cx, int i, int j, bool &first_max)
 {
     constexpr int BOX = 2 * H + 1, KM = (BOX + 1) / 2;
     const uint16_t *base = src + (int64_t)(i - H - 1) * X + (j - H);
     const int r0 = i - H - 1 < 0 ? i - H - 1 + cy : i - H - 1;          // numba negative-index wrap
     const uint16_t *row0w = src + (int64_t)r0 * X + (j - H);
     int c0w = j - H - 1 < 0 ? cx - 1 - (j - H) : -1;
-    float ng = exact_ng_rows<H, 0, KM>(base, row0w, X, c0w, 0.0f);
+    float vc = 0.0f;
+    first_max = true;
+    float ng = exact_ng_rows<H, 0, KM>(base, row0w, X, c0w, 0.0f, vc, first_max);
     // the second batch starts only when the first sum is done (keeps its loads from being hoisted
     // above the first batch, which would double the live registers)
     asm volatile("" : "+v"(ng), "+v"(base), "+v"(c0w));
-    return exact_ng_rows<H, KM, BOX>(base, row0w, X, c0w, ng);
+    return exact_ng_rows<H, KM, BOX>(base, row0w, X, c0w, ng, vc, first_max);
 }
 
 // One wavefront per workgroup, persistent: it owns p.upw consecutive UNITS.  A unit is rbu rows x 512 columns of one
@@ -272,8 +271,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
     // the slot about to be overwritten is skipped: both rings then share the period H.
     constexpr bool WIDE = H >= 5;
     constexpr int NB = WIDE ? 8 : 4, NA = 4 + NB, OWN = NB / 2;
-    constexpr int HR = WIDE ? H : (H > 1 ? H - 1 : 1);     // Hrow ring length (unused when H == 1)
-    constexpr int U_ = WIDE ? (H == 5 ? 10 : 2 * H) : ((H <= 2) ? 4 : H * (H - 1));   // unroll period: a multiple of both ring periods
+    constexpr int U_ = H <= 2 ? 4 : (H == 3 ? 6 : (H == 4 ? 4 : (H == 5 ? 10 : (H == 6 ? 6 : 2 * H))));   // unroll period: a multiple of the ring period H
     static_assert(U_ % D == 0, "prefetch depth must divide the unroll period");
     constexpr int NWL = (H + 1 + 7) / 8;                   // neighbour lanes (8 columns each) a stencil reaches on either side
     // Candidate ring: entries (row << 16 | column in the aligned row) + frame index.  A chunk of rows ends early when
@@ -364,7 +362,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
     auto frame_src = [&](int fi) -> const uint16_t * {
         return p.movie + ((int64_t)(p.f_lo + fi) * p.Y + p.y0) * p.X + p.x0;
     };
-    // slow exact path: saturated pixels, overflow rescans
+    // slow exact path: overflow rescans (a plateau of equal pixels flooded the ring)
     auto process_slow = [&](const uint16_t *src, int fi, int i, int j, bool recheck) {
         const float v = (float)src[(int64_t)i * p.X + j];
         if (recheck) {
@@ -405,11 +403,12 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             const int fi = (int)s_fi[q];
             const int i = (int)(e >> 16), j = (int)(e & 0xffffu) - xoff;
             const uint16_t *src = frame_src(fi);
-            // the packed test cannot see ties at 65535 (saturating +1): those are rechecked exactly
-            const bool saturated = src[(int64_t)i * p.X + j] == 0xffffu;
             if (p.dbg & 1) append(fi, i, j, (e & 7) == 0 ? 1e9f : 0.0f);
-            else if (!saturated) append(fi, i, j, exact_ng<H>(src, p.X, p.cy, p.cx, i, j));
-            else process_slow(src, fi, i, j, true);
+            else {
+                bool first_max;
+                const float ng = exact_ng<H>(src, p.X, p.cy, p.cx, i, j, first_max);
+                if (first_max) append(fi, i, j, ng);
+            }
         }
         head += n;
         if (++rounds == KBUF) flush();
@@ -506,14 +505,13 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
                 return ro;
             };
 
-            u32 Hring[HR][4], Uprev[4], Dv[H][4], Dpre[H][4];
+            // rings of period H: the horizontal window maxima of the last H rows, the maxima over (H+1) rows ending
+            // at each of the last H rows, and the pixels of the last H rows
+            u32 Hring[H][4], Uring[H][4], Dv[H][4];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-                Uprev[q] = 0xffffffffu;
 #pragma unroll
-                for (int t = 0; t < HR; t++) Hring[t][q] = 0xffffffffu;
-#pragma unroll
-                for (int t = 0; t < H; t++) { Dv[t][q] = 0u; Dpre[t][q] = 0xffffffffu; }
+                for (int t = 0; t < H; t++) { Hring[t][q] = 0u; Uring[t][q] = 0xffffffffu; Dv[t][q] = 0u; }
             }
             u32 mn = 0xffffffffu;                             // packed minimum of the lane's pixels since the last flush
             u32 gring[H];                                     // the same for the H flush groups before (>= 2 rows each: 2H + 2 rows back)
@@ -551,31 +549,70 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
                     for (int k = 1; k < NA; k++) Bp[k] = __builtin_amdgcn_alignbit(A[k], A[k - 1], 16);
                     mn = pk_min(pk_min(mn, pk_min(A[OWN], A[OWN + 1])), pk_min(A[OWN + 2], A[OWN + 3]));
 
-                    u32 L[4], R[4];
-                    L[0] = LR<H, 0, 0, NA>::left(A, Bp); R[0] = LR<H, 0, 0, NA>::right(A, Bp);
-                    L[1] = LR<H, 1, 0, NA>::left(A, Bp); R[1] = LR<H, 1, 0, NA>::right(A, Bp);
-                    L[2] = LR<H, 2, 0, NA>::left(A, Bp); R[2] = LR<H, 2, 0, NA>::right(A, Bp);
-                    L[3] = LR<H, 3, 0, NA>::left(A, Bp); R[3] = LR<H, 3, 0, NA>::right(A, Bp);
+                    // Row r - H holds a candidate where its pixel equals the maximum of its (2H+1)^2 window (rows
+                    // r - 2H .. r) and reaches the floor.  np.argmax takes the FIRST maximum of the window
+                    // (picasso/localize.py:128): equal pixels before the centre disqualify it — that is checked
+                    // on the exact neighbourhood when the net gradient is evaluated, not here.
+                    u32 hrow[4];
                     u32 tq[4];
+                    if constexpr (H == 3) {
+                        // box 7, hand-scheduled.  Horizontal: pair maxima E(s) = max(p(s), p(s+1)) at the six odd
+                        // offsets, two of them doubled, 16 instructions for the four 7-pixel windows (22 by plain
+                        // doubling).  Vertical: P2(r) = max(Hrow r, r-1), U(r) = max(P2(r), P2(r-2)) = rows r-3..r
+                        // in two instructions (Hring[0] = Hrow(r-1), Hring[1..2] = P2 of the last two rows).
+                        // The four pixel pairs advance stage by stage (the empty asm pins each stage): a packed
+                        // instruction that consumes the result of the one just before it costs a wait state, and
+                        // the scheduler, short of registers, otherwise walks one pair's chain after the other.
+                        const u32 Em3 = pk_max(pair_at<-3, NA>(A, Bp), pair_at<-2, NA>(A, Bp));
+                        const u32 Em1 = pk_max(pair_at<-1, NA>(A, Bp), pair_at<0, NA>(A, Bp));
+                        const u32 E1 = pk_max(pair_at<1, NA>(A, Bp), pair_at<2, NA>(A, Bp));
+                        const u32 E3 = pk_max(pair_at<3, NA>(A, Bp), pair_at<4, NA>(A, Bp));
+                        const u32 E5 = pk_max(pair_at<5, NA>(A, Bp), pair_at<6, NA>(A, Bp));
+                        const u32 E7 = pk_max(pair_at<7, NA>(A, Bp), pair_at<8, NA>(A, Bp));
+                        const u32 Fm1 = pk_max(Em1, E1), F3 = pk_max(E3, E5);
+                        u32 h0 = pk_max(Em3, Fm1), h1 = pk_max(Fm1, E3), h2 = pk_max(E1, F3), h3 = pk_max(F3, E7);
+                        asm volatile("" : "+v"(h0), "+v"(h1), "+v"(h2), "+v"(h3));
+                        hrow[0] = pk_max(h0, pair_at<3, NA>(A, Bp)); hrow[1] = pk_max(h1, pair_at<5, NA>(A, Bp));
+                        hrow[2] = pk_max(h2, pair_at<7, NA>(A, Bp)); hrow[3] = pk_max(h3, pair_at<9, NA>(A, Bp));
+                        asm volatile("" : "+v"(hrow[0]), "+v"(hrow[1]), "+v"(hrow[2]), "+v"(hrow[3]));
+                        u32 p2[4], uc[4], t1[4], t2[4], d[4];
 #pragma unroll
-                    for (int q = 0; q < 4; q++) {
-                        const u32 v = A[q + OWN];
-                        const u32 hrow = pk_max(pk_max(L[q], v), R[q]);
-                        u32 Ucur = hrow;
-                        if (H > 1) {
+                        for (int q = 0; q < 4; q++) p2[q] = pk_max(hrow[q], Hring[0][q]);
+                        asm volatile("" : "+v"(p2[0]), "+v"(p2[1]), "+v"(p2[2]), "+v"(p2[3]));
 #pragma unroll
-                            for (int t = 0; t < HR; t++)
-                                if (!WIDE || t != u % HR) Ucur = pk_max(Ucur, Hring[t][q]);     // WIDE: slot u % H holds the row H steps back
+                        for (int q = 0; q < 4; q++) uc[q] = pk_max(p2[q], Hring[1 + u % 2][q]);     // P2(r-2)
+                        asm volatile("" : "+v"(uc[0]), "+v"(uc[1]), "+v"(uc[2]), "+v"(uc[3]));
+#pragma unroll
+                        for (int q = 0; q < 4; q++) t1[q] = pk_max(uc[q], Uring[u % H][q]);
+                        asm volatile("" : "+v"(t1[0]), "+v"(t1[1]), "+v"(t1[2]), "+v"(t1[3]));
+#pragma unroll
+                        for (int q = 0; q < 4; q++) t2[q] = pk_max(t1[q], F);
+                        asm volatile("" : "+v"(t2[0]), "+v"(t2[1]), "+v"(t2[2]), "+v"(t2[3]));
+#pragma unroll
+                        for (int q = 0; q < 4; q++) d[q] = pk_sub_sat(t2[q], Dv[u % H][q]);
+                        asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            tq[q] = pk_min(d[q], 0x00010001u);
+                            Dv[u % H][q] = A[q + OWN];
+                            Uring[u % H][q] = uc[q];
+                            Hring[0][q] = hrow[q];
+                            Hring[1 + u % 2][q] = p2[q];
                         }
-                        const u32 bef = pk_max(Uprev[q], L[q]);
-                        const u32 pre = pk_max(pk_add_sat(bef, 0x00010001u), R[q]);
-                        // decision for the row H steps back (same ring slot): 0 in a half = passed
-                        const u32 thr = pk_max(pk_max(Dpre[u % H][q], Ucur), F);
-                        tq[q] = pk_min(pk_sub_sat(thr, Dv[u % H][q]), 0x00010001u);
-                        Dv[u % H][q] = v;
-                        Dpre[u % H][q] = pre;
-                        if (H > 1) Hring[u % HR][q] = hrow;
-                        Uprev[q] = Ucur;
+                    } else {
+                        hrow[0] = wmax<BOX, 0 - H, NA>(A, Bp); hrow[1] = wmax<BOX, 2 - H, NA>(A, Bp);
+                        hrow[2] = wmax<BOX, 4 - H, NA>(A, Bp); hrow[3] = wmax<BOX, 6 - H, NA>(A, Bp);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            u32 Ucur = hrow[q];                    // rows r - H .. r
+#pragma unroll
+                            for (int t = 0; t < H; t++) Ucur = pk_max(Ucur, Hring[t][q]);
+                            const u32 thr = pk_max(pk_max(Ucur, Uring[u % H][q]), F);       // slot u % H: the row H steps back
+                            tq[q] = pk_min(pk_sub_sat(thr, Dv[u % H][q]), 0x00010001u);     // 0 in a half = candidate
+                            Dv[u % H][q] = A[q + OWN];
+                            Uring[u % H][q] = Ucur;
+                            Hring[u % H][q] = hrow[q];
+                        }
                     }
                     const int t4 = u % 4;                      // row slot inside the accumulator
                     acc |= (tq[0] | (tq[1] << 1) | (tq[2] << 2) | (tq[3] << 3)) << (4 * t4);
@@ -641,8 +678,9 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
             if (added > LIST - (tail0 - head)) {
-                // More candidates than the ring holds: a saturated (65535) plateau flooded the packed test.
-                // Drop this chunk's entries and rescan its rows pixel by pixel with the exact test (slow, rare).
+                // More candidates than the ring holds: a plateau of equal pixels above the floor (saturation) — every
+                // one of them equals its window maximum.  Drop this chunk's entries and rescan its rows pixel by
+                // pixel with the exact test (slow, rare).
                 tail = tail0;
                 const int wcols = P > 1 ? NL * 8 : 512;
                 for (int s = 0; s < P; s++) {

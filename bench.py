@@ -228,9 +228,10 @@ def main():
         # 5.24 kB per localization; the fit moves 166 B and is FP32-ALU bound, listed beside it).
         dom = "identify_scan"
         ach = kernels[dom]["GB/s"]
+        traffic, traffic_source = pmc_traffic_bytes(F, H, W, box)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (ach / HBM_PEAK_GBS) if ach else None,
-                    "traffic": pmc_traffic_bytes(F, H, W, box), "kernels": kernels}
+                    "traffic": traffic, "traffic_source": traffic_source, "kernels": kernels}
         kernels["mle_fit"]["bound"] = "fp32 valu (no MFMA shape); algorithmic bytes are 166 B/spot"
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
@@ -263,19 +264,25 @@ def main():
     return result
 
 
+PMC_TRAFFIC_FILE = "profiles/r02_identify_pmc.json"
+
+
 def pmc_traffic_bytes(F, H, W, box):
-    """HBM-side bytes per launch of the scan kernel from the committed rocprofv3 PMC run
-    (profiles/r01_identify_pmc.json: TCC_EA0_RDREQ x 128 B = 2 x FETCH_SIZE x 1024, the gfx950
-    correction of MI355X_MICROARCH.md), if it was taken on this exact workload; else None."""
-    path = os.path.join(ROOT, "profiles", "r01_identify_pmc.json")
+    """HBM-side bytes per launch of the scan kernel from the committed rocprofv3 PMC run of THIS kernel on THIS
+    workload (TCC_EA0_RDREQ x 128 B = 2 x FETCH_SIZE x 1024, the gfx950 correction of MI355X_MICROARCH.md, plus
+    WRITE_SIZE), and where the number comes from; (None, None) for any other workload.  Counters cannot be read
+    inside an un-profiled run: the figure is a measurement of the committed profile, labelled as such."""
+    path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
     try:
         with open(path) as fh:
             rec = json.load(fh)
         if [rec["frames"], rec["height"], rec["width"], rec["box"]] == [F, H, W, box]:
-            return rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"]
+            return (rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"],
+                    f"{PMC_TRAFFIC_FILE} (rocprofv3 --pmc TCC_EA0_RDREQ_sum / WRITE_SIZE passes of tools/pmc_scan.sh, "
+                    f"kernel {rec['kernel'].split('(')[0].replace('void ', '')})")
     except (OSError, KeyError, ValueError):
         pass
-    return None
+    return None, None
 
 
 def cpu_baseline(movie, cam, box, min_ng, method, budget_s):

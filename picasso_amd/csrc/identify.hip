@@ -350,7 +350,7 @@ static int launch_scan(const void *d_movie, const IdParams &p, const float *d_ta
     return PMI_OK;
 }
 
-int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
+int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
                          int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
                          long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled);
 
@@ -405,8 +405,8 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
         ScopedKernelTimer tm(s, &g_last_times.scan_ms);
         bool fast = false;
         rc = PMI_OK;
-        if (dtype == PMI_U16)      // register-pipelined packed-u16 scan (identify_fast.hip) when the layout allows
-            rc = launch_scan_u16_fast(d_movie, Y, X, p.y0, p.x0, p.cy, p.cx, f_lo, label_offset, p.nframes, box, min_ng,
+        // register-pipelined packed-u16 scan (identify_fast.hip: uint16, uint8, int16) when the layout allows
+        rc = launch_scan_u16_fast(d_movie, dtype, Y, X, p.y0, p.x0, p.cy, p.cx, f_lo, label_offset, p.nframes, box, min_ng,
                                       d_tab, recs, cap, d_total, count, s, &fast);
         if (rc == PMI_OK && !fast) switch (dtype) {
         case PMI_U16: rc = launch_scan<uint16_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;

@@ -100,8 +100,24 @@ __device__ __forceinline__ u32 pk_sub_sat(u32 a, u32 b)
     return d;
 }
 
+// Pixel types of the packed scan: the window test and the floor work on unsigned 16-bit pairs.
+//   PT_U16  as stored;
+//   PT_U8   eight pixels = one 8-byte load per lane-row, widened to four u16 pairs with v_perm_b32;
+//   PT_I16  as stored with the sign bit flipped (x ^ 0x8000 = x + 32768): order-preserving, and the net gradient is
+//           a sum of DIFFERENCES of pixels (picasso/localize.py:233-243), which a common offset does not change —
+//           float32(a + 32768) - float32(b + 32768) = float32(a) - float32(b) exactly for 16-bit values.
+// (float32 / 32-bit integer movies compare as float32 in the reference, picasso/localize.py:332: generic kernel.)
+enum { PT_U16 = 0, PT_U8 = 1, PT_I16 = 2 };
+template <int PT> struct Px { typedef uint16_t T; };
+template <> struct Px<PT_U8> { typedef uint8_t T; };
+template <int PT> __device__ __forceinline__ float px_float(typename Px<PT>::T raw)
+{
+    if constexpr (PT == PT_I16) return (float)(int16_t)raw;
+    else return (float)raw;
+}
+
 struct FastParams {
-    const uint16_t *movie;
+    const void *movie;
     int64_t Y, X;
     int y0, x0, cy, cx;
     int64_t f_lo, label_off;
@@ -114,6 +130,7 @@ struct FastParams {
     int box;
     double min_ng;
     float filt_alpha, filt_t;  // floor filter: a maximum v can only reach min_ng if v > alpha * (minimum above it) + t; t < 0: off
+    int filt_slack;            // counts by which later pixels may undercut the minimum seen so far before a chunk is run again
     int dbg;                   // PMI_IDENTIFY_DBG: 1 = skip the exact net gradient, 2 = skip the record append, 4 = no floor filter (timing only)
 };
 
@@ -180,24 +197,32 @@ __device__ __forceinline__ u32 from_lane_above(u32 v, u32 edge) { return (u32)__
 // gfx950 runs global loads in unaligned mode.
 // `first` (in/out): the centre is still the FIRST maximum of its window after the rows seen so far — strictly greater
 // than the window pixels before it in row-major order, not smaller than those after it (np.argmax, localize.py:128).
-template <int H, int K0, int K1>
-__device__ __forceinline__ float exact_ng_rows(const uint16_t *__restrict__ base, const uint16_t *__restrict__ row0w,
+template <int H, int K0, int K1, int PT>
+__device__ __forceinline__ float exact_ng_rows(const typename Px<PT>::T *__restrict__ base, const typename Px<PT>::T *__restrict__ row0w,
                                                int64_t X, int c0w, float ng, float &vc, bool &first_max)
 {
+    typedef typename Px<PT>::T PX;
     // base = &src[i - H - 1][j - H]: neighbourhood row t, column 1;  row0w = &src[wrapped first row][j - H];
     // c0w = (wrapped first column) - (j - H): offset of the neighbourhood's column 0 from column 1 (-1 unless it wraps)
     constexpr int BOX = 2 * H + 1, W = 2 * H + 3, NP = (W - 1) / 2;   // W is odd: one single pixel + NP pairs
     constexpr int R0 = K0, NR = K1 - K0 + 2;                           // window rows K0..K1-1 need neighbourhood rows K0..K1+1
     struct __attribute__((packed, aligned(2))) Pairs { u32 v[NP]; };
+    struct __attribute__((packed, aligned(1))) BytePairs { unsigned short v[NP]; };
     u32 pk[NR][NP];
     u32 first[NR];
 #pragma unroll
     for (int r = 0; r < NR; r++) {
-        const uint16_t *row = (R0 + r == 0) ? row0w : base + (int64_t)(R0 + r) * X;
-        const Pairs t = *reinterpret_cast<const Pairs *>(row);
+        const PX *row = (R0 + r == 0) ? row0w : base + (int64_t)(R0 + r) * X;
+        if constexpr (PT == PT_U8) {
+            const BytePairs t = *reinterpret_cast<const BytePairs *>(row);
 #pragma unroll
-        for (int q = 0; q < NP; q++) pk[r][q] = t.v[q];
-        first[r] = row[c0w];
+            for (int q = 0; q < NP; q++) pk[r][q] = ((u32)t.v[q] & 0xffu) | (((u32)t.v[q] & 0xff00u) << 8);
+        } else {
+            const Pairs t = *reinterpret_cast<const Pairs *>(row);
+#pragma unroll
+            for (int q = 0; q < NP; q++) pk[r][q] = PT == PT_I16 ? t.v[q] ^ 0x80008000u : t.v[q];
+        }
+        first[r] = PT == PT_I16 ? (u32)row[c0w] ^ 0x8000u : (u32)row[c0w];
     }
     auto px = [&](int r, int b) -> float {
         r -= R0;
@@ -225,21 +250,22 @@ __device__ __forceinline__ float exact_ng_rows(const uint16_t *__restrict__ base
     return ng;
 }
 
-template <int H>
-__device__ __forceinline__ float exact_ng(const uint16_t *__restrict__ src, int64_t X, int cy, int cx, int i, int j, bool &first_max)
+template <int H, int PT>
+__device__ __forceinline__ float exact_ng(const typename Px<PT>::T *__restrict__ src, int64_t X, int cy, int cx, int i, int j, bool &first_max)
 {
+    typedef typename Px<PT>::T PX;
     constexpr int BOX = 2 * H + 1, KM = (BOX + 1) / 2;
-    const uint16_t *base = src + (int64_t)(i - H - 1) * X + (j - H);
+    const PX *base = src + (int64_t)(i - H - 1) * X + (j - H);
     const int r0 = i - H - 1 < 0 ? i - H - 1 + cy : i - H - 1;          // numba negative-index wrap
-    const uint16_t *row0w = src + (int64_t)r0 * X + (j - H);
+    const PX *row0w = src + (int64_t)r0 * X + (j - H);
     int c0w = j - H - 1 < 0 ? cx - 1 - (j - H) : -1;
     float vc = 0.0f;
     first_max = true;
-    float ng = exact_ng_rows<H, 0, KM>(base, row0w, X, c0w, 0.0f, vc, first_max);
+    float ng = exact_ng_rows<H, 0, KM, PT>(base, row0w, X, c0w, 0.0f, vc, first_max);
     // the second batch starts only when the first sum is done (keeps its loads from being hoisted
     // above the first batch, which would double the live registers)
     asm volatile("" : "+v"(ng), "+v"(base), "+v"(c0w));
-    return exact_ng_rows<H, KM, BOX>(base, row0w, X, c0w, ng, vc, first_max);
+    return exact_ng_rows<H, KM, BOX, PT>(base, row0w, X, c0w, ng, vc, first_max);
 }
 
 // One wavefront per workgroup, persistent: it owns p.upw consecutive UNITS.  A unit is rbu rows x 512 columns of one
@@ -259,11 +285,13 @@ __device__ __forceinline__ float exact_ng(const uint16_t *__restrict__ src, int6
 // the last rows (own columns and the neighbour lanes'), the right-hand side becomes a packed u16 floor that joins
 // the first-maximum threshold with one v_pk_max_u16 per pixel pair, and the shot-noise maxima (2 % of all pixels,
 // 20 x more than there are emitters) never reach the list.
-template <int H, int D, int P = 1>
+template <int H, int D, int P = 1, int PT = PT_U16>
 __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_fast_kernel(
     FastParams p, const float *__restrict__ uxy, Record *__restrict__ recs, long long cap,
     unsigned long long *__restrict__ shard_cnt, int *__restrict__ frame_count)
 {
+    typedef typename Px<PT>::T PX;
+    constexpr int PXB = (int)sizeof(PX);                   // bytes per pixel
     constexpr int BOX = 2 * H + 1;
     constexpr int NL = 64 / P;                             // lanes per sub-band
     static_assert(P == 1 || P == 2 || P == 4 || P == 8, "sub-bands split the wavefront evenly");
@@ -302,7 +330,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
     const int nch = (xoff + p.cx + 7) >> 3;           // 8-pixel chunks per row
     typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
     typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-    const unsigned pitch = (unsigned)p.X * 2u;         // Y * pitch < 2^31 on this path
+    const unsigned pitch = (unsigned)p.X * (unsigned)PXB;    // Y * pitch < 2^31 on this path
     const float *sux = s_u, *suy = s_u + BOX * BOX;
 
     int head = 0, tail = 0;                            // candidate ring (wave-uniform)
@@ -312,6 +340,14 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
     // chip would send its 64 x (2H+3) scattered row fetches to HBM in the same few microseconds.  Without the floor
     // filter (min_ng <= 0) 2 % of the pixels are candidates and the ring is drained only when nearly full.
     const bool filter = p.filt_t >= 0.0f && !(p.dbg & 4);
+    // The floor assumes that no pixel a candidate's neighbourhood can reach lies below `cfloor` (the minimum the lane's
+    // columns showed in the chunk before, less half the margin t = min_ng / P_box): with p' = p - cfloor >= 0 the bound is
+    //     v > alpha * min + (1 - alpha) * cfloor + t,
+    // which is what makes it independent of the camera offset (without it a baseline of a few hundred counts eats the
+    // whole margin).  The assumption is CHECKED when the chunk is done — the minimum of every row it streamed, per
+    // lane window — and a chunk that saw a lower pixel is run again: with four times the slack first, then without.
+    u32 cfloor = 0u;
+    bool redo = false;
     int trigger = filter ? 8 + (FAST_ROUND / 8) * (int)(blockIdx.x % 7u) : THRESH;
 
     // ---- results: buffered in registers, appended KBUF rounds at a time with ONE slot-allocating atomic per flush
@@ -328,6 +364,18 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
 #pragma unroll
         for (int k = 0; k < KBUF; k++) { bal[k] = __ballot(k < nbuf); total += __popcll(bal[k]); }
         if (total) {
+            // per-frame counts: one atomic per distinct frame of a round (a round holds candidates of one frame, two
+            // when it straddles a unit boundary) — one per lane means up to 64 atomics on one address, serialised in L2
+#pragma unroll
+            for (int k = 0; k < KBUF; k++) {
+                unsigned long long rest = bal[k];
+                while (rest) {
+                    const int f0 = __builtin_amdgcn_readlane(buf_f[k], (int)__builtin_ctzll(rest));
+                    const unsigned long long same = __ballot(k < nbuf && buf_f[k] == f0) & rest;
+                    if (lane == (int)__builtin_ctzll(rest)) atomicAdd(&frame_count[f0], (int)__popcll(same));
+                    rest &= ~same;
+                }
+            }
             unsigned long long basepos = 0;
             if (lane == 0) basepos = atomicAdd(&shard_cnt[shard], (unsigned long long)total);
             basepos = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(basepos >> 32)) << 32) |
@@ -337,7 +385,6 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             for (int k = 0; k < KBUF; k++) {
                 if (k < nbuf) {
                     const long long pos = (long long)basepos + off + __popcll(bal[k] & ((1ull << lane) - 1ull));
-                    atomicAdd(&frame_count[buf_f[k]], 1);          // a round can hold candidates of two frames
                     if (pos < cap) {
                         Record rec;
                         rec.frame = (int32_t)(p.f_lo + buf_f[k] + p.label_off);
@@ -359,18 +406,18 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             nbuf++;
         }
     };
-    auto frame_src = [&](int fi) -> const uint16_t * {
-        return p.movie + ((int64_t)(p.f_lo + fi) * p.Y + p.y0) * p.X + p.x0;
+    auto frame_src = [&](int fi) -> const PX * {
+        return (const PX *)p.movie + ((int64_t)(p.f_lo + fi) * p.Y + p.y0) * p.X + p.x0;
     };
     // slow exact path: overflow rescans (a plateau of equal pixels flooded the ring)
-    auto process_slow = [&](const uint16_t *src, int fi, int i, int j, bool recheck) {
-        const float v = (float)src[(int64_t)i * p.X + j];
+    auto process_slow = [&](const PX *src, int fi, int i, int j, bool recheck) {
+        const float v = px_float<PT>(src[(int64_t)i * p.X + j]);
         if (recheck) {
 #pragma unroll 1
             for (int k = -H; k <= H; k++)
 #pragma unroll 1
                 for (int l = -H; l <= H; l++) {
-                    float o = (float)src[(int64_t)(i + k) * p.X + (j + l)];
+                    float o = px_float<PT>(src[(int64_t)(i + k) * p.X + (j + l)]);
                     if ((k < 0 || (k == 0 && l < 0)) ? !(v > o) : !(v >= o)) return;
                 }
         }
@@ -379,16 +426,16 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
         for (int k = 0; k < BOX; k++) {
             const int rk = i - H + k;
             const int rm = rk - 1 < 0 ? rk - 1 + p.cy : rk - 1;          // numba negative-index wrap
-            const uint16_t *rowm = src + (int64_t)rm * p.X;
-            const uint16_t *row0 = src + (int64_t)rk * p.X;
-            const uint16_t *rowp = src + (int64_t)(rk + 1) * p.X;
+            const PX *rowm = src + (int64_t)rm * p.X;
+            const PX *row0 = src + (int64_t)rk * p.X;
+            const PX *rowp = src + (int64_t)(rk + 1) * p.X;
 #pragma unroll 1
             for (int l = 0; l < BOX; l++) {
                 if (k == H && l == H) continue;
                 const int cl = j - H + l;
                 const int clm = cl - 1 < 0 ? cl - 1 + p.cx : cl - 1;
-                float gy = sub_rn((float)rowp[cl], (float)rowm[cl]);
-                float gx = sub_rn((float)row0[cl + 1], (float)row0[clm]);
+                float gy = sub_rn(px_float<PT>(rowp[cl]), px_float<PT>(rowm[cl]));
+                float gx = sub_rn(px_float<PT>(row0[cl + 1]), px_float<PT>(row0[clm]));
                 float sacc = add_rn(mul_rn(gy, suy[k * BOX + l]), mul_rn(gx, sux[k * BOX + l]));
                 ng = add_rn(ng, sacc);
             }
@@ -402,11 +449,11 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             const unsigned e = s_pos[q];
             const int fi = (int)s_fi[q];
             const int i = (int)(e >> 16), j = (int)(e & 0xffffu) - xoff;
-            const uint16_t *src = frame_src(fi);
+            const PX *src = frame_src(fi);
             if (p.dbg & 1) append(fi, i, j, (e & 7) == 0 ? 1e9f : 0.0f);
             else {
                 bool first_max;
-                const float ng = exact_ng<H>(src, p.X, p.cy, p.cx, i, j, first_max);
+                const float ng = exact_ng<H, PT>(src, p.X, p.cy, p.cx, i, j, first_max);
                 if (first_max) append(fi, i, j, ng);
             }
         }
@@ -423,7 +470,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
         const int c8 = P > 1 ? lane % NL : seg * 64 + lane;
         const bool lane_valid = c8 < nch;
         const int cm = min(c8, nch - 1);
-        const uint16_t *src = frame_src(fi);
+        const PX *src = frame_src(fi);
         const int col_m = cm * 8;
         const int col_l = cm > 0 ? col_m - NB : col_m;                // clamped copies feed invalid pixels only
         const int col_r = cm + 1 < nch ? col_m + 8 : col_m + 8 - NB;
@@ -442,15 +489,17 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             colmask *= 0x1111u;
         }
         // lanes whose stencils reach columns no lane of this wave holds take no floor
-        const bool no_floor = wrapcol || (P == 1 && ((seg > 0 && lane < NWL) || (seg + 1 < p.segs && lane >= 64 - NWL)));
+        // (the 4 or 8 pixels the edge lanes hold from beyond the wave cover a stencil's reach of H + 1 for every box but 9 and 17)
+        constexpr bool EDGE_COVERED = (H <= 4 ? 4 : 8) >= H + 1;
+        const bool no_floor = wrapcol || (P == 1 && !EDGE_COVERED && ((seg > 0 && lane < NWL) || (seg + 1 < p.segs && lane >= 64 - NWL)));
 
         // per-lane byte offsets inside a row (32-bit) + a wave-uniform row base: the loads use
         // SGPR-base + VGPR-offset addressing, no 64-bit vector address arithmetic per row.
         // Neighbour pixels come from the adjacent lanes' registers (DPP), not from memory: overlapping
         // 8-byte loads next to the 16-byte ones doubled the HBM-side traffic (requests to a line whose
         // fill is still in flight are not merged).  Only lanes 0 and 63 load the 4 pixels beyond the wave.
-        const unsigned off_m = (unsigned)col_m * 2u;
-        const unsigned off_e = (unsigned)(lane == 0 ? col_l : col_r) * 2u;
+        const unsigned off_m = (unsigned)col_m * (unsigned)PXB;
+        const unsigned off_e = (unsigned)(lane == 0 ? col_l : col_r) * (unsigned)PXB;
         // a sub-band's row lies wholly inside its lanes, and so does the row of a frame at most 512 pixels wide: the
         // pixels lanes 0 and 63 would take from beyond the wave then only feed masked positions
         const bool any_edge = P == 1 && p.segs > 1;
@@ -458,9 +507,9 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
         // num_records bounds the descriptor at the end of the frames of this call: when the width is not a
         // multiple of 8 the last chunk of a row reads into the next row (masked columns), and on the very last
         // row it would read past the movie — the buffer unit returns 0 there instead
-        const long long remaining = ((long long)(p.nframes - fi) * p.Y * p.X - ((long long)p.y0 * p.X + p.x0 - xoff)) * 2;
+        const long long remaining = ((long long)(p.nframes - fi) * p.Y * p.X - ((long long)p.y0 * p.X + p.x0 - xoff)) * PXB;
         const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
-            const_cast<uint16_t *>(src - xoff), 0, (int)(remaining < 0x7fffffffLL ? remaining : 0x7fffffffLL),
+            const_cast<PX *>(src - xoff), 0, (int)(remaining < 0x7fffffffLL ? remaining : 0x7fffffffLL),
             0x00020000 /* raw 32-bit buffer, gfx94x/gfx950 */);
 
         const int b0 = band * (p.rbu * P);                 // first row of sub-band 0
@@ -470,7 +519,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             // ---- one chunk: rows [clo, clo + len) of every sub-band (len shrinks if the ring fills up) ----
             const int clo = b0 + o, len = unit_rows - o;
             const int rs0 = clo - H - 1;
-            const int nr = len + 2 * H + 1;                // pipeline rows: one row above the stencils of row clo .. H below the last row
+            const int nr = len + 2 * H + 2;                // pipeline rows: the stencils of rows clo .. clo + len - 1 (H + 1 rows above and below)
             // rows that may hold a maximum, in sub-band 0's numbering
             const int lo_rel = max(clo + sub_rows, H) - sub_rows;
             const int hi_rel = min(min(clo + len, b0 + p.rbu) + sub_rows, min(p.cy, p.cy - H - 1)) - sub_rows;
@@ -478,28 +527,46 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             const bool interior = P == 1 && rs0 >= 0 && rs0 + nr + U_ + D <= p.cy;
             auto load_row = [&](int r) -> RowRegs {
                 RowRegs ro;
-                unsigned soff = 0;
-                u32x4_t m;
+                unsigned soff = 0, voff = off_m;
                 if constexpr (P > 1) {
                     // every sub-band clamps its own row: the row offset joins the lane's column offset
                     const int rl = min(max(r + sub_rows, 0), p.cy - 1);
-                    m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off_m + (unsigned)rl * pitch), 0, 0);
+                    voff = off_m + (unsigned)rl * pitch;
                 } else {
                     const int rc = interior ? r : min(max(r, 0), p.cy - 1);
                     soff = (unsigned)rc * pitch;
-                    m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_m, (int)soff, 0);
                 }
-                ro.m = make_uint4(m.x, m.y, m.z, m.w);
+                if constexpr (PT == PT_U8) {
+                    // 8 pixels = 8 bytes; bytes (b0, b1) -> the u16 pair b0 | b1 << 16 (selector 0x0c = constant zero)
+                    const u32x2_t m = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)soff, 0);
+                    ro.m = make_uint4(__builtin_amdgcn_perm(0u, m.x, 0x0c010c00u), __builtin_amdgcn_perm(0u, m.x, 0x0c030c02u),
+                                      __builtin_amdgcn_perm(0u, m.y, 0x0c010c00u), __builtin_amdgcn_perm(0u, m.y, 0x0c030c02u));
+                } else {
+                    const u32x4_t m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+                    ro.m = make_uint4(m.x, m.y, m.z, m.w);
+                    if constexpr (PT == PT_I16) { ro.m.x ^= 0x80008000u; ro.m.y ^= 0x80008000u; ro.m.z ^= 0x80008000u; ro.m.w ^= 0x80008000u; }
+                }
                 // only lanes 0 and 63 ever read `e` (as the DPP fill value): the other lanes leave it undefined
                 // instead of spending two or four v_mov per row on zeros
                 asm("" : "=v"(ro.e.x), "=v"(ro.e.y), "=v"(ro.e.z), "=v"(ro.e.w));
                 if (any_edge && edge_lane) {
-                    if constexpr (WIDE) {
+                    if constexpr (PT == PT_U8) {
+                        if constexpr (WIDE) {
+                            const u32x2_t e = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off_e, (int)soff, 0);
+                            ro.e = make_uint4(__builtin_amdgcn_perm(0u, e.x, 0x0c010c00u), __builtin_amdgcn_perm(0u, e.x, 0x0c030c02u),
+                                              __builtin_amdgcn_perm(0u, e.y, 0x0c010c00u), __builtin_amdgcn_perm(0u, e.y, 0x0c030c02u));
+                        } else {
+                            const unsigned e = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off_e, (int)soff, 0);
+                            ro.e.x = __builtin_amdgcn_perm(0u, e, 0x0c010c00u); ro.e.y = __builtin_amdgcn_perm(0u, e, 0x0c030c02u);
+                        }
+                    } else if constexpr (WIDE) {
                         const u32x4_t e = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_e, (int)soff, 0);
                         ro.e = make_uint4(e.x, e.y, e.z, e.w);
+                        if constexpr (PT == PT_I16) { ro.e.x ^= 0x80008000u; ro.e.y ^= 0x80008000u; ro.e.z ^= 0x80008000u; ro.e.w ^= 0x80008000u; }
                     } else {
                         const u32x2_t e = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off_e, (int)soff, 0);
                         ro.e.x = e.x; ro.e.y = e.y;
+                        if constexpr (PT == PT_I16) { ro.e.x ^= 0x80008000u; ro.e.y ^= 0x80008000u; }
                     }
                 }
                 return ro;
@@ -521,6 +588,9 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             u32 acc = 0;                                      // "failed the test" bits of up to four rows
             const int tail0 = tail;                           // ring state at the start of the chunk
             int added = 0;                                    // candidates of this chunk, counted even when the ring is full
+            int tail_lf = tail, rd_lf = clo;                  // ring state before, and first row of, the latest flush group
+            u32 cmin = 0xffffffffu;                           // minimum of every pixel this lane streamed in the chunk (both halves)
+            const float beta = fmaf(1.0f - p.filt_alpha, (float)cfloor, p.filt_t);
 
             RowRegs pf[D];
 #pragma unroll
@@ -548,6 +618,10 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
 #pragma unroll
                     for (int k = 1; k < NA; k++) Bp[k] = __builtin_amdgcn_alignbit(A[k], A[k - 1], 16);
                     mn = pk_min(pk_min(mn, pk_min(A[OWN], A[OWN + 1])), pk_min(A[OWN + 2], A[OWN + 3]));
+                    if (any_edge) {        // rows wider than the wave: the neighbour pixels count too (lanes 0 / 63: from beyond the wave)
+#pragma unroll
+                        for (int k = 0; k < OWN; k++) mn = pk_min(mn, pk_min(A[k], A[NA - 1 - k]));
+                    }
 
                     // Row r - H holds a candidate where its pixel equals the maximum of its (2H+1)^2 window (rows
                     // r - 2H .. r) and reaches the floor.  np.argmax takes the FIRST maximum of the window
@@ -624,6 +698,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
                             if (rd0 + tt >= lo_rel && rd0 + tt < hi_rel) rowmask |= 0x000f000fu << (4 * tt);
                         u32 pass = ~acc & rowmask & colmask;
                         acc = 0;
+                        tail_lf = tail; rd_lf = rd0;
                         // Append to the wave's ring: every round each lane that still has a candidate emits its
                         // lowest one, slots come from a ballot prefix count and the ring state stays in scalar
                         // registers.  (An LDS atomicAdd per lane is turned into a serial per-lane scan by the
@@ -654,6 +729,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
 #pragma unroll
                             for (int t = H - 1; t > 0; t--) gring[t] = gring[t - 1];
                             gring[0] = gm;
+                            cmin = pk_min(cmin, gm);
                             mn = 0xffffffffu;
                             u32 wl = wmin, wr = wmin;
 #pragma unroll
@@ -664,20 +740,43 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
                             // the next group decides rows r - H + 1 .. r - H + 4 (r = this row); the row with index H
                             // reads its upper ring row from the LAST row (wrap): no floor then
                             const int rnext = rs0 + st + 1 - H + sub_rows;
-                            const float fl = fmaf(p.filt_alpha, (float)(wmin & 0xffffu), p.filt_t);
+                            const float fl = fmaf(p.filt_alpha, (float)(wmin & 0xffffu), beta);
                             u32 fi_ = (u32)fminf(fl, 65535.0f);                                    // fl >= 0
                             fi_ = (no_floor || (rnext <= H && rnext + 3 >= H)) ? 0u : fi_;
                             F = fi_ | (fi_ << 16);
                         }
                     }
                 }
-                if (tail - head >= trigger || added > LIST - 64) { sb += U_; break; }
+                if ((tail - head >= trigger && rd_lf > clo) || added > LIST - 64) { sb += U_; break; }
             }
-            // rows decided: every row whose decision step lies before sb
-            const int dn = min(len, sb - 2 * H - 1);
+            // Rows decided: every row whose decision step lies before sb.  A chunk that ends early (sb < nr) keeps
+            // only the rows before its latest flush group: the neighbourhoods of those have streamed in completely,
+            // so the check of the floor's assumption below covers them.
+            const bool flooded = added > LIST - (tail0 - head);
+            int dn = min(len, sb - 2 * H - 1);
+            if (sb < nr && !flooded) { tail = tail_lf; dn = rd_lf - clo; }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
-            if (added > LIST - (tail0 - head)) {
+            if (filter && !flooded) {
+                u32 cw = cmin, wl = cmin, wr = cmin;
+#pragma unroll
+                for (int t = 0; t < NWL; t++) {
+                    wl = from_lane_below(wl, 0xffffffffu); wr = from_lane_above(wr, 0xffffffffu);
+                    cw = pk_min(cw, pk_min(wl, wr));
+                }
+                cw &= 0xffffu;
+                const bool broken = cw < cfloor;               // a pixel below the assumed floor: the decisions of this chunk are void
+                const u32 slack = (u32)p.filt_slack;
+                cfloor = cw > slack ? cw - slack : 0u;
+                if (__any(broken)) {                           // run the chunk again; a second failure in a row drops the assumption
+                    tail = tail0;
+                    cfloor = (redo || cw <= 4u * slack) ? 0u : cw - 4u * slack;
+                    redo = true;
+                    continue;
+                }
+                redo = false;
+            }
+            if (flooded) {
                 // More candidates than the ring holds: a plateau of equal pixels above the floor (saturation) — every
                 // one of them equals its window maximum.  Drop this chunk's entries and rescan its rows pixel by
                 // pixel with the exact test (slow, rare).
@@ -712,13 +811,15 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
 }
 
 template <int H, int D, int P = 1>
-static int launch_fast(const FastParams &p, const float *d_tab, Record *recs, long long cap,
+static int launch_fast(const FastParams &p, int pt, const float *d_tab, Record *recs, long long cap,
                        unsigned long long *shard_cnt, int *frame_count, hipStream_t s)
 {
     const long long blocks = (p.units + p.upw - 1) / p.upw;
     if (blocks > 0x7fffffffLL) { set_error("identify: too many blocks (%lld)", blocks); return PMI_ERR_ARG; }
-    hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P>), dim3((unsigned)blocks), dim3(64), 0, s,
-                       p, d_tab, recs, cap, shard_cnt, frame_count);
+    const dim3 g((unsigned)blocks), b(64);
+    if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_U8>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+    else if (pt == PT_I16) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_I16>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+    else hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_U16>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
     PMI_HIP(hipGetLastError());
     return PMI_OK;
 }
@@ -748,7 +849,7 @@ static bool unit_vectors_match()
 static int g_fast_cus = 0;
 
 // Returns PMI_OK and sets *handled when the fast path applies.
-int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
+int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
                          int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
                          long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled)
 {
@@ -758,8 +859,13 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     const int h = box / 2;
     if (h < 1 || h > 8) return PMI_OK;
     if (!unit_vectors_match()) return PMI_OK;          // never expected; the generic kernel uses the runtime table
-    if ((X & 1) || cx < 16 || ((uintptr_t)d_movie & 3)) return PMI_OK;       // rows must start 4-byte aligned (buffer loads); the crop may not
-    if (cy > 65535 || cx > 65520 || X > 65535 || Y * X * 2 >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets, 16-bit list columns
+    // uint16, uint8 and int16 movies (see Px); rows need no alignment beyond the pixel's own: gfx950 runs buffer and
+    // global loads in unaligned mode, so odd widths only cost the loads that straddle a 64-byte boundary
+    const int pt = dtype == PMI_U16 ? PT_U16 : (dtype == PMI_U8 ? PT_U8 : (dtype == PMI_I16 ? PT_I16 : -1));
+    if (pt < 0) return PMI_OK;
+    const int pxb = pt == PT_U8 ? 1 : 2;
+    if (cx < 16 || ((uintptr_t)d_movie & (uintptr_t)(pxb - 1))) return PMI_OK;
+    if (cy > 65535 || cx > 65520 || X > 65535 || Y * X * pxb >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets, 16-bit list columns
     if (!g_fast_cus) {
         int dev = 0;
         PMI_HIP(hipGetDevice(&dev));
@@ -775,7 +881,7 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
         else if (nch <= 32) pack = 2;
     }
     FastParams p;
-    p.movie = (const uint16_t *)d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;
+    p.movie = d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;
     p.f_lo = f_lo; p.label_off = label_off; p.nframes = nframes; p.box = box; p.min_ng = min_ng;
     p.segs = pack > 1 ? 1 : (nch + 63) / 64;
     // Rows per unit: long units amortise the 2H + 2 pipeline rows a unit spends on its halo, short ones balance the
@@ -825,40 +931,41 @@ int launch_scan_u16_fast(const void *d_movie, int64_t Y, int64_t X, int y0, int 
     if (min_ng > 0.0 && std::isfinite(min_ng)) {
         p.filt_alpha = (float)(N_K / P_box * 0.998);
         p.filt_t = (float)std::max(0.0, min_ng / (P_box * 1.001) - 1.0);     // one count of slack for the float32 evaluation
+        p.filt_slack = (int)std::min(65535.0, std::max(2.0, std::ceil(0.5 * min_ng / P_box)));
     } else {
-        p.filt_alpha = 0.0f; p.filt_t = -1.0f;
+        p.filt_alpha = 0.0f; p.filt_t = -1.0f; p.filt_slack = 0;
     }
     static const int dbg = getenv("PMI_IDENTIFY_DBG") ? atoi(getenv("PMI_IDENTIFY_DBG")) : 0;
     p.dbg = dbg;
     int rc;
     switch (h) {
-    case 1: rc = launch_fast<1, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 1: rc = launch_fast<1, 2>(p, pt, d_tab, recs, cap, n_total, frame_count, s); break;
     case 2:
-        if (pack == 4) rc = launch_fast<2, 2, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 2) rc = launch_fast<2, 2, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else rc = launch_fast<2, FAST_D_H2>(p, d_tab, recs, cap, n_total, frame_count, s);
+        if (pack == 4) rc = launch_fast<2, 2, 4>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 2) rc = launch_fast<2, 2, 2>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<2, FAST_D_H2>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
         break;
     case 3:
-        if (pack == 8) rc = launch_fast<3, FAST_D_H3, 8>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 4) rc = launch_fast<3, FAST_D_H3, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 2) rc = launch_fast<3, FAST_D_H3, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else rc = launch_fast<3, FAST_D_H3>(p, d_tab, recs, cap, n_total, frame_count, s);
+        if (pack == 8) rc = launch_fast<3, FAST_D_H3, 8>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 4) rc = launch_fast<3, FAST_D_H3, 4>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 2) rc = launch_fast<3, FAST_D_H3, 2>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<3, FAST_D_H3>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
         break;
     case 4:
-        if (pack == 4) rc = launch_fast<4, 4, 4>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else if (pack == 2) rc = launch_fast<4, 4, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else rc = launch_fast<4, FAST_D_H4>(p, d_tab, recs, cap, n_total, frame_count, s);
+        if (pack == 4) rc = launch_fast<4, 4, 4>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
+        else if (pack == 2) rc = launch_fast<4, 4, 2>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<4, FAST_D_H4>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
         break;
     case 5:
-        if (pack == 2) rc = launch_fast<5, 2, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else rc = launch_fast<5, FAST_D_H5>(p, d_tab, recs, cap, n_total, frame_count, s);
+        if (pack == 2) rc = launch_fast<5, 2, 2>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<5, FAST_D_H5>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
         break;
     case 6:
-        if (pack == 2) rc = launch_fast<6, 3, 2>(p, d_tab, recs, cap, n_total, frame_count, s);
-        else rc = launch_fast<6, FAST_D_H6>(p, d_tab, recs, cap, n_total, frame_count, s);
+        if (pack == 2) rc = launch_fast<6, 3, 2>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
+        else rc = launch_fast<6, FAST_D_H6>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
         break;
-    case 7: rc = launch_fast<7, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
-    default: rc = launch_fast<8, 2>(p, d_tab, recs, cap, n_total, frame_count, s); break;
+    case 7: rc = launch_fast<7, 2>(p, pt, d_tab, recs, cap, n_total, frame_count, s); break;
+    default: rc = launch_fast<8, 2>(p, pt, d_tab, recs, cap, n_total, frame_count, s); break;
     }
     if (rc == PMI_OK) *handled = true;
     return rc;

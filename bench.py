@@ -144,10 +144,42 @@ def main():
     pending = [None] * nbuf
     table, d_n = tables[0], d_ns[0]
 
+    # The all-gather is the library's own (pmi_allgather_locs: RCCL called from C on a side stream of ours); if that
+    # communicator cannot be made the step falls back to torch.distributed's collectives and says so in the line.
+    gather_impl, comm, gstream = "none", None, None
+    if grouped:
+        try:
+            if os.environ.get("PMI_BENCH_TORCH_GATHER"):
+                raise RuntimeError("PMI_BENCH_TORCH_GATHER set")
+            from picasso_amd.dist import NativeComm
+            comm = NativeComm.for_group(None)
+            gstream = torch.cuda.Stream(device=dev)
+            gather_impl = "pmi_allgather_locs (RCCL from libpicasso_hip.so)"
+        except Exception as exc:      # noqa: BLE001 - any failure to set up the native communicator
+            comm = None
+            gather_impl = f"torch.distributed all_gather_into_tensor (native communicator unavailable: {exc})"
+    g_stream_ptr = ctypes.c_void_p(gstream.cuda_stream) if gstream is not None else None
+
+    def native_gather(k):
+        """gather set k on the side stream, after the kernels queued so far; returns the event that marks its end"""
+        ready = torch.cuda.Event()
+        ready.record(torch.cuda.current_stream(dev))
+        gstream.wait_event(ready)
+        rc = L.pmi_allgather_locs(comm._h, ctypes.c_void_p(tables[k].data_ptr()), _lib.PMI_LOC_COLUMNS, cap,
+                                  ctypes.c_void_p(d_ns[k].data_ptr()), ctypes.c_void_p(gathered[k].data_ptr()),
+                                  ctypes.c_void_p(gathered_n[k].data_ptr()), g_stream_ptr)
+        _lib.check(rc, "pmi_allgather_locs")
+        done = torch.cuda.Event()
+        done.record(gstream)
+        return done
+
     def drain(k):
         if pending[k] is not None:
-            for w in pending[k]:
-                w.wait()                 # the compute stream waits for that gather; the host does not block
+            if comm is not None:
+                torch.cuda.current_stream(dev).wait_event(pending[k])
+            else:
+                for w in pending[k]:
+                    w.wait()             # the compute stream waits for that gather; the host does not block
             pending[k] = None
 
     def step(i):
@@ -155,7 +187,11 @@ def main():
         drain(k)
         run(tables[k], d_ns[k], cap)
         if grouped:        # localization table of every shard on every GPU (RCCL over xGMI)
-            if nbuf == 1:
+            if comm is not None:
+                pending[k] = native_gather(k)
+                if nbuf == 1:
+                    drain(k)
+            elif nbuf == 1:
                 dist.all_gather_into_tensor(gathered_n[0], d_ns[0])
                 dist.all_gather_into_tensor(gathered[0], tables[0])
             else:
@@ -253,6 +289,7 @@ def main():
                        "frames": F, "height": H, "width": W, "box": box, "min_net_gradient": args.min_ng,
                        "eps": 1e-3, "max_it": 100, "localizations_total": n_total,
                        "mle_mode": mle_mode, "refit_margin": mle_margin, "refit_spots_rank0": refit,
+                       "all_gather": gather_impl,
                        "sharding": f"frames x{world}"},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -288,6 +288,27 @@ int pmi_rcc_pair_list(const double *segments, int64_t n_seg, int64_t Y, int64_t 
                       const int32_t *pairs, int64_t n_pairs, int32_t *peak_yx, int32_t *valid,
                       double *fit_rois, int32_t *crop_yx);
 
+/* ---- the sharded path: every rank's localization table on every GPU ---- *
+ * The reference has no distributed code; its workers split the movie frame by frame inside one process
+ * (picasso/localize.py:438-454).  Here each GPU (one process per GPU) localizes a contiguous frame range and the
+ * tables are all-gathered with RCCL, called from this library (loaded at the first pmi_comm_* call).
+ *   pmi_comm_unique_id  rank 0 fills a 128-byte id, which the HOST hands to every rank (file, socket, MPI, ...);
+ *   pmi_comm_init       every rank, on its own device (pmi_set_device first);
+ *   pmi_allgather_locs  d_table: this rank's ncols x cap column-major table of 4-byte cells (PMI_LOC_COLUMNS or
+ *                       PMI_LQ_COLUMNS columns, the same cap on every rank), d_n its device row count;
+ *                       d_all_tables receives world x ncols x cap cells (rank-major), d_all_counts world counts.
+ *                       One grouped submission on `stream`, asynchronous, no host synchronisation;
+ *   pmi_compact_gathered_dev  the gathered tables as ONE ncols x table_cap column-major table, rows in rank order
+ *                       (= frame order for contiguous frame shards, picasso/gaussmle.py:1036), total in *d_total.  */
+int pmi_comm_unique_id(void *id128);
+int pmi_comm_init(const void *id128, int world, int rank, void **comm);
+int pmi_comm_info(void *comm, int *world, int *rank);
+int pmi_comm_destroy(void *comm);
+int pmi_allgather_locs(void *comm, const void *d_table, int ncols, int64_t cap, const int64_t *d_n,
+                       void *d_all_tables, int64_t *d_all_counts, void *stream);
+int pmi_compact_gathered_dev(const void *d_all_tables, const int64_t *d_all_counts, int world, int ncols, int64_t cap,
+                             void *d_table, int64_t table_cap, int64_t *d_total, void *stream);
+
 /* ---- timing hooks for bench.py (HIP events on the given stream) ------- */
 int pmi_event_create(void **event);
 int pmi_event_record(void *event, void *stream);

@@ -80,6 +80,12 @@ SYMBOLS = {
     "pmi_xcorr": (_i32, [_p, _p, _i64, _i64, _p]),
     "pmi_rcc_pairs": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p]),
     "pmi_rcc_pair_list": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _i64, _p, _p, _p, _p]),
+    "pmi_comm_unique_id": (_i32, [_p]),
+    "pmi_comm_init": (_i32, [_p, _i32, _i32, _p]),
+    "pmi_comm_info": (_i32, [_p, _p, _p]),
+    "pmi_comm_destroy": (_i32, [_p]),
+    "pmi_allgather_locs": (_i32, [_p, _p, _i32, _i64, _p, _p, _p, _p]),
+    "pmi_compact_gathered_dev": (_i32, [_p, _p, _i32, _i32, _i64, _p, _i64, _p, _p]),
     "pmi_event_create": (_i32, [_p]),
     "pmi_event_record": (_i32, [_p, _p]),
     "pmi_event_elapsed_ms": (_i32, [_p, _p, _p]),

@@ -29,14 +29,97 @@ def shard_frames(n_frames: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, hi
 
 
+class NativeComm:
+    """RCCL communicator owned by libpicasso_hip.so (pmi_comm_init): the all-gather of the localization tables
+    runs inside the library (pmi_allgather_locs + pmi_compact_gathered_dev), torch.distributed only carries the
+    128-byte id from rank 0 to the others — the part a host without torch does with a file or a socket."""
+
+    _cache = {}
+
+    def __init__(self, world: int, rank: int, id_bytes: bytes):
+        import ctypes
+
+        from . import _lib
+        self.world, self.rank = int(world), int(rank)
+        self._h = ctypes.c_void_p()
+        buf = ctypes.create_string_buffer(id_bytes, 128)
+        _lib.check(_lib.load().pmi_comm_init(buf, self.world, self.rank, ctypes.byref(self._h)), "pmi_comm_init")
+
+    @staticmethod
+    def unique_id() -> bytes:
+        import ctypes
+
+        from . import _lib
+        buf = ctypes.create_string_buffer(128)
+        _lib.check(_lib.load().pmi_comm_unique_id(buf), "pmi_comm_unique_id")
+        return buf.raw
+
+    @classmethod
+    def for_group(cls, group=None):
+        """The communicator that mirrors a torch.distributed group (made once per group)."""
+        key = id(group)
+        if key not in cls._cache:
+            world, rank = dist.get_world_size(group), dist.get_rank(group)
+            box = [cls.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            cls._cache[key] = cls(world, rank, box[0])
+        return cls._cache[key]
+
+    def allgather_table(self, table: torch.Tensor, d_n: torch.Tensor, stream=None):
+        """table: (C, cap) int32 on the GPU, the same cap on every rank; d_n: its device row count (int64).
+        Returns (gathered (world, C, cap), counts (world,) int64), both on the device; asynchronous."""
+        import ctypes
+
+        from . import _lib
+        C, cap = table.shape
+        allt = torch.empty((self.world, C, cap), dtype=torch.int32, device=table.device)
+        counts = torch.empty((self.world,), dtype=torch.int64, device=table.device)
+        s = ctypes.c_void_p(stream if stream is not None else torch.cuda.current_stream(table.device).cuda_stream)
+        _lib.check(_lib.load().pmi_allgather_locs(self._h, ctypes.c_void_p(table.data_ptr()), C, cap,
+                                                  ctypes.c_void_p(d_n.data_ptr()), ctypes.c_void_p(allt.data_ptr()),
+                                                  ctypes.c_void_p(counts.data_ptr()), s), "pmi_allgather_locs")
+        return allt, counts
+
+    def compact(self, allt: torch.Tensor, counts: torch.Tensor, stream=None):
+        """(world, C, cap) padded tables -> ((C, world * cap) table, device total): rows in rank order."""
+        import ctypes
+
+        from . import _lib
+        world, C, cap = allt.shape
+        out = torch.empty((C, world * cap), dtype=torch.int32, device=allt.device)
+        total = torch.zeros((1,), dtype=torch.int64, device=allt.device)
+        s = ctypes.c_void_p(stream if stream is not None else torch.cuda.current_stream(allt.device).cuda_stream)
+        _lib.check(_lib.load().pmi_compact_gathered_dev(ctypes.c_void_p(allt.data_ptr()), ctypes.c_void_p(counts.data_ptr()),
+                                                        world, C, cap, ctypes.c_void_p(out.data_ptr()), world * cap,
+                                                        ctypes.c_void_p(total.data_ptr()), s), "pmi_compact_gathered_dev")
+        return out, total
+
+    def close(self):
+        from . import _lib
+        if self._h:
+            _lib.load().pmi_comm_destroy(self._h)
+            self._h = None
+
+
 def allgather_table(table: torch.Tensor, n_rows, group=None) -> torch.Tensor:
     """All-gather a column-major table (C columns x capacity, 4-byte cells, first
     `n_rows` of each column valid) from every rank.  Returns a (C, total) tensor
     on every rank, rows in rank order.  Without a process group (one process, one GPU) it is
-    the identity on the valid rows."""
+    the identity on the valid rows.  On the GPU the exchange is the library's own (pmi_allgather_locs, RCCL called
+    from C); host tensors (the gloo tests) go through torch.distributed."""
     if not (dist.is_available() and dist.is_initialized()):
         return table[:, : int(n_rows)].clone()
     world = dist.get_world_size(group)
+    if table.is_cuda:
+        comm = NativeComm.for_group(group)
+        cap = _all_reduce_max_int(max(int(n_rows), 1), table.device, group)      # the same padded width on every rank
+        send = torch.zeros((table.shape[0], cap), dtype=torch.int32, device=table.device)
+        send[:, : int(n_rows)] = table[:, : int(n_rows)].view(torch.int32) if table.dtype != torch.int32 else table[:, : int(n_rows)]
+        d_n = torch.tensor([int(n_rows)], dtype=torch.int64, device=table.device)
+        allt, counts = comm.allgather_table(send, d_n)
+        out, total = comm.compact(allt, counts)
+        res = out[:, : int(total.item())]
+        return res if table.dtype == torch.int32 else res.view(table.dtype)
     C = table.shape[0]
     n = torch.as_tensor([int(n_rows)], dtype=torch.int64, device=table.device)
     counts = torch.empty(world, dtype=torch.int64, device=table.device)

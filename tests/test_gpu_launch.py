@@ -64,3 +64,50 @@ def test_bench_starts_its_own_ranks():
     else:
         assert out.returncode != 0
         assert "only 1 GPU(s) visible" in out.stderr and "2-rank launch failed" in out.stderr
+
+
+def test_bench_under_the_launcher_uses_the_native_all_gather():
+    """One rank under torch.distributed.run: the step ends with pmi_allgather_locs (RCCL called from the library) and
+    the gathered table is checked against the local one inside bench.py."""
+    small = ["--steps", "2", "--warmup", "1", "--frames", "400", "--cpu-seconds", "0", "--profile-steps", "0"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small
+    out = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["config"]["all_gather"].startswith("pmi_allgather_locs"), line["config"]["all_gather"]
+
+
+def test_native_communicator_one_rank():
+    """pmi_comm_unique_id / pmi_comm_init / pmi_allgather_locs / pmi_compact_gathered_dev through raw ctypes, no
+    torch.distributed anywhere: what a torch-free host would do."""
+    import ctypes
+
+    import numpy as np
+    import torch
+    from picasso_amd import _lib
+    L = _lib.load()
+    _lib.require_gpu()
+    idb = ctypes.create_string_buffer(128)
+    _lib.check(L.pmi_comm_unique_id(idb), "pmi_comm_unique_id")
+    comm = ctypes.c_void_p()
+    _lib.check(L.pmi_comm_init(idb, 1, 0, ctypes.byref(comm)), "pmi_comm_init")
+    w, r = ctypes.c_int(-1), ctypes.c_int(-1)
+    _lib.check(L.pmi_comm_info(comm, ctypes.byref(w), ctypes.byref(r)))
+    assert (w.value, r.value) == (1, 0)
+    C, cap, n = _lib.PMI_LOC_COLUMNS, 1000, 617
+    t = torch.arange(C * cap, dtype=torch.int32, device="cuda").view(C, cap)
+    d_n = torch.tensor([n], dtype=torch.int64, device="cuda")
+    allt = torch.empty((1, C, cap), dtype=torch.int32, device="cuda")
+    counts = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _lib.check(L.pmi_allgather_locs(comm, ctypes.c_void_p(t.data_ptr()), C, cap, ctypes.c_void_p(d_n.data_ptr()),
+                                    ctypes.c_void_p(allt.data_ptr()), ctypes.c_void_p(counts.data_ptr()), None))
+    out = torch.full((C, cap), -1, dtype=torch.int32, device="cuda")
+    total = torch.zeros(1, dtype=torch.int64, device="cuda")
+    _lib.check(L.pmi_compact_gathered_dev(ctypes.c_void_p(allt.data_ptr()), ctypes.c_void_p(counts.data_ptr()), 1, C, cap,
+                                          ctypes.c_void_p(out.data_ptr()), cap, ctypes.c_void_p(total.data_ptr()), None))
+    torch.cuda.synchronize()
+    assert int(counts.item()) == n and int(total.item()) == n
+    assert np.array_equal(out[:, :n].cpu().numpy(), t[:, :n].cpu().numpy()) and int(out[:, n:].max().item()) == -1
+    assert L.pmi_allgather_locs(comm, None, C, cap, None, None, None, None) != 0
+    _lib.check(L.pmi_comm_destroy(comm))

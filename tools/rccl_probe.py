@@ -17,6 +17,14 @@ dev = torch.device("cuda", torch.cuda.current_device())
 t = torch.arange(len(LOC_COLUMNS) * 10, dtype=torch.int32, device=dev).view(len(LOC_COLUMNS), 10)
 out = pdist.allgather_table(t, 7)
 assert out.shape == (len(LOC_COLUMNS), 7) and torch.equal(out, t[:, :7])
+# the library's own communicator (RCCL called from C): padded gather + device-side compaction
+comm = pdist.NativeComm.for_group(None)
+d_n = torch.tensor([7], dtype=torch.int64, device=dev)
+allt, counts = comm.allgather_table(t.contiguous(), d_n)
+packed, total = comm.compact(allt, counts)
+torch.cuda.synchronize()
+assert counts.tolist() == [7] * dist.get_world_size() and int(total.item()) == 7 * dist.get_world_size()
+assert torch.equal(packed[:, :7], t[:, :7])
 a = pdist._all_reduce_sum(np.ones((3, 4)), dev)
 assert np.array_equal(a, np.ones((3, 4)))
 g = torch.empty((1,), dtype=torch.int64, device=dev)

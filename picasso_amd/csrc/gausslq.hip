@@ -474,17 +474,38 @@ __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], 
     wa1[j] = -ajnorm;
 }
 
+// ---- the fit as two kernels per outer iteration ----------------------------------------------------------------
+// lmdif alternates two kinds of work: (a) residuals, forward-difference Jacobian and its pivoted QR factorisation —
+// m x 6 data, done by a GROUP of lanes per spot (DPP reductions, the Jacobian columns in registers); (b) the
+// Levenberg-Marquardt step on the 6 x 6 factor (lmpar / qrsolv: serial chains of float64 divisions and square roots),
+// the trial evaluation and the accept / reject logic — scalar work per spot.  Run inside the group kernel, (b) is
+// executed identically by all 16 lanes of a group (6 % of the lanes do distinct work) and its unrolled code (235 KB,
+// 63 spilled registers) was most of the kernel.  Here (b) runs ONE SPOT PER LANE in its own kernel, the state of a
+// fit travels through a scratch record (LqState), and the spots that need another Jacobian are compacted into the
+// list of the next round.
+constexpr int LQ_NSD = 64, LQ_NSI = 9;          // doubles / ints of state per spot
+struct LqState {                                 // structure of arrays, stride = spots of the batch
+    double *d;                                   // [0..5] x  [6..11] diag  12 fnorm  13 delta  14 par  15 xnorm
+                                                 // [16..51] R (row-major 6x6, upper)  [52..57] qtf  [58..63] acnorm
+    int32_t *i;                                  // [0..5] ipvt  6 iter  7 nfev  8 info (-1 fresh, 0 running, > 0 done)
+    int64_t stride, first;                       // state index of spot s = s - first
+};
+#define LQD(st, f, ls) (st).d[(int64_t)(f) * (st).stride + (ls)]
+#define LQI(st, f, ls) (st).i[(int64_t)(f) * (st).stride + (ls)]
+
+// (a): residuals at x, Jacobian, QR.  list == nullptr: spots [first, min(first + count, n)).
 template <int GS, int E, bool FROM_MOVIE>
-__global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_fit_kernel(Params p)
+__global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kernel(Params p, LqState st, const int32_t *__restrict__ list,
+                                                                      const unsigned *__restrict__ list_n, int64_t count)
 {
     constexpr int NGRP = 64 / GS;                              // spots per wavefront
-    __shared__ double s_R[GS < 64 ? LQ_WAVES * NGRP * 36 : 1];
     const int lane = (threadIdx.x & 63) % GS;                  // lane inside the group
     const int grp = (threadIdx.x & 63) / GS;
     const int64_t wave0 = (int64_t)blockIdx.x * LQ_WAVES + (threadIdx.x >> 6);
     const int64_t nwaves = (int64_t)gridDim.x * LQ_WAVES;
     int64_t n = p.N;
     if (p.d_n) { const int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+    int64_t items = list ? (int64_t)*list_n : (st.first + count < n ? count : n - st.first);
     const int size = p.box, m = size * size, hsz = size / 2;
     int ri[E], rj[E];
     bool act[E];
@@ -496,14 +517,15 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_fit_kernel(Par
         ri[e] = rr / size;
         rj[e] = rr - ri[e] * size;
     }
-    const double ftol = 1e-2, xtol = 1e-2, gtol = 0.0, factor = 100.0;
-    const int maxfev = 200 * (6 + 1);
     const double eps = sqrt(1.1920928955078125e-07);     // sqrt(max(epsfcn, epsmch)), epsfcn = float32 eps
 
-    for (int64_t s0 = wave0 * NGRP; s0 < n; s0 += nwaves * NGRP) {
-        // a group past the end refits the last spot and does not store (keeps the groups in lockstep)
-        const bool store = s0 + grp < n;
-        const int64_t s = store ? s0 + grp : n - 1;
+    for (int64_t w0 = wave0 * NGRP; w0 < items; w0 += nwaves * NGRP) {
+        // a group past the end repeats the last item and does not store (keeps the groups in lockstep)
+        const bool store = w0 + grp < items;
+        const int64_t w = store ? w0 + grp : items - 1;
+        const int64_t s = list ? (int64_t)list[w] : st.first + w;
+        const int64_t ls = s - st.first;
+        const bool fresh = LQI(st, 8, ls) < 0;
         // ---- the spot: rows of this lane ----
         float sp[E];
         if (FROM_MOVIE) {
@@ -521,9 +543,9 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_fit_kernel(Par
             for (int e = 0; e < E; e++) sp[e] = act[e] ? p.spots[s * m + lane + GS * e] : 0.f;
         }
 
-        // ---- initial parameters (gausslq.py:95-112) ----
         double x[6];
-        {
+        if (Grp<GS>::any(fresh)) {
+            // ---- initial parameters (gausslq.py:95-112) ----
             float mn = __builtin_inff();
             bool anynan = false;
 #pragma unroll
@@ -559,196 +581,354 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_fit_kernel(Par
             x[0] = (double)t0; x[1] = (double)t1; x[2] = (double)t2; x[3] = (double)mn;
             x[4] = (double)t4; x[5] = (double)t5;
         }
-
-        // ---- lmdif ----
-        double a[6][E], fv[E], w4[E];
-        // the 6x6 factor: LDS for the 16-lane groups (frees 72 registers of a kernel capped at 256 for two
-        // waves per SIMD; every lane of the group writes the same values), registers for whole-wave groups
-        double R_regs[36];
-        double *R = GS < 64 ? s_R + (size_t)((threadIdx.x >> 6) * NGRP + grp) * 36 : R_regs;
-        double diag[6], qtf[6], wa1[6], wa2[6], wa3[6];
-        int ipvt[6];
-        int info = 0, nfev = 1, iter = 1;
-        double par = 0, delta = 0, xnorm = 0, gnorm = 0, fnorm, fnorm1, actred, prered, dirder, ratio, pnorm;
-        residuals<GS, E>(x, sp, ri, rj, act, size, lane, fv);
-        fnorm = enorm_rows<GS, E>(fv, lane, 0, m);
-        for (;;) {
-            // fdjac2
+        if (!fresh) {
 #pragma unroll
-            for (int j = 0; j < 6; j++) {
-                const double temp = x[j];
-                double hstep = eps * fabs(temp);
-                if (hstep == 0) hstep = eps;
-                x[j] = temp + hstep;
-                residuals<GS, E>(x, sp, ri, rj, act, size, lane, w4);
-                x[j] = temp;
-#pragma unroll
-                for (int e = 0; e < E; e++) a[j][e] = (w4[e] - fv[e]) / hstep;
-            }
-            nfev += 6;
-            // qrfac with column pivoting: rdiag = wa1, acnorm = wa2, wa = wa3
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                wa2[j] = enorm_rows<GS, E>(a[j], lane, 0, m);
-                wa1[j] = wa2[j];
-                wa3[j] = wa1[j];
-                ipvt[j] = j;
-            }
-            qrfac_step<GS, E, 0>(a, wa1, wa3, ipvt, lane, m);
-            qrfac_step<GS, E, 1>(a, wa1, wa3, ipvt, lane, m);
-            qrfac_step<GS, E, 2>(a, wa1, wa3, ipvt, lane, m);
-            qrfac_step<GS, E, 3>(a, wa1, wa3, ipvt, lane, m);
-            qrfac_step<GS, E, 4>(a, wa1, wa3, ipvt, lane, m);
-            qrfac_step<GS, E, 5>(a, wa1, wa3, ipvt, lane, m);
-            if (iter == 1) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) { diag[j] = wa2[j]; if (wa2[j] == 0) diag[j] = 1; }
-#pragma unroll
-                for (int j = 0; j < 6; j++) wa3[j] = diag[j] * x[j];
-                xnorm = enorm6(wa3);
-                delta = factor * xnorm;
-                if (delta == 0) delta = factor;
-            }
-            // (Q^T fvec)[0..6) and R
-#pragma unroll
-            for (int e = 0; e < E; e++) w4[e] = fv[e];
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                const double ajj = Grp<GS>::bcast_d(a[j][0], j);
-                if (ajj != 0) {
-                    double sum = 0;
-#pragma unroll
-                    for (int e = 0; e < E; e++)
-                        if (e > 0 || lane >= j) sum += a[j][e] * w4[e];
-                    sum = Grp<GS>::sum_d(sum);
-                    const double temp = -sum / ajj;
-#pragma unroll
-                    for (int e = 0; e < E; e++)
-                        if (e > 0 || lane >= j) w4[e] += a[j][e] * temp;
-                }
-                if (lane == j) a[j][0] = wa1[j];
-                qtf[j] = Grp<GS>::bcast_d(w4[0], j);
-            }
-#pragma unroll
-            for (int j = 0; j < 6; j++)
-#pragma unroll
-                for (int i = 0; i < 6; i++) R[(i) * 6 + (j)] = (i <= j) ? Grp<GS>::bcast_d(a[j][0], i) : 0.0;
-            gnorm = 0;
-            if (fnorm != 0) {
-#pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    const double w2l = get6(wa2, ipvt[j]);
-                    if (w2l != 0) {
-                        double sum = 0;
-#pragma unroll
-                        for (int i = 0; i <= j; i++) sum += R[(i) * 6 + (j)] * (qtf[i] / fnorm);
-                        const double g = fabs(sum / w2l);
-                        if (g > gnorm) gnorm = g;
-                    }
-                }
-            }
-            if (gnorm <= gtol) { info = 4; break; }
-#pragma unroll
-            for (int j = 0; j < 6; j++)
-                if (wa2[j] > diag[j]) diag[j] = wa2[j];
-            for (;;) {
-                lmpar(R, ipvt, diag, qtf, delta, par, wa1, wa2);
-#pragma unroll
-                for (int j = 0; j < 6; j++) { wa1[j] = -wa1[j]; wa2[j] = x[j] + wa1[j]; wa3[j] = diag[j] * wa1[j]; }
-                pnorm = enorm6(wa3);
-                if (iter == 1 && pnorm < delta) delta = pnorm;
-                residuals<GS, E>(wa2, sp, ri, rj, act, size, lane, w4);
-                nfev++;
-                fnorm1 = enorm_rows<GS, E>(w4, lane, 0, m);
-                actred = -1;
-                if (0.1 * fnorm1 < fnorm) { const double r = fnorm1 / fnorm; actred = 1 - r * r; }
-#pragma unroll
-                for (int j = 0; j < 6; j++) wa3[j] = 0;
-#pragma unroll
-                for (int j = 0; j < 6; j++) {
-                    const double temp = get6(wa1, ipvt[j]);
-#pragma unroll
-                    for (int i = 0; i <= j; i++) wa3[i] += R[(i) * 6 + (j)] * temp;
-                }
-                const double temp1 = enorm6(wa3) / fnorm, temp2 = (sqrt(par) * pnorm) / fnorm;
-                prered = temp1 * temp1 + temp2 * temp2 / 0.5;
-                dirder = -(temp1 * temp1 + temp2 * temp2);
-                ratio = 0;
-                if (prered != 0) ratio = actred / prered;
-                if (ratio <= 0.25) {
-                    double temp = 0.5;
-                    if (actred < 0) temp = 0.5 * dirder / (dirder + 0.5 * actred);
-                    if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
-                    const double pd = pnorm / 0.1;
-                    delta = temp * (delta < pd ? delta : pd);
-                    par = par / temp;
-                } else if (par == 0 || ratio >= 0.75) {
-                    delta = pnorm / 0.5;
-                    par = 0.5 * par;
-                }
-                if (ratio >= 1e-4) {
-#pragma unroll
-                    for (int j = 0; j < 6; j++) { x[j] = wa2[j]; wa2[j] = diag[j] * x[j]; }
-#pragma unroll
-                    for (int e = 0; e < E; e++) fv[e] = w4[e];
-                    xnorm = enorm6(wa2);
-                    fnorm = fnorm1;
-                    iter++;
-                }
-                if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1) info = 1;
-                if (delta <= xtol * xnorm) info = 2;
-                if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1 && info == 2) info = 3;
-                if (info != 0) break;
-                if (nfev >= maxfev) info = 5;
-                if (fabs(actred) <= EPSMCH && prered <= EPSMCH && 0.5 * ratio <= 1) info = 6;
-                if (delta <= EPSMCH * xnorm) info = 7;
-                if (gnorm <= EPSMCH) info = 8;
-                if (info != 0) break;
-                if (ratio >= 1e-4) break;
-            }
-            if (info != 0) break;
+            for (int j = 0; j < 6; j++) x[j] = LQD(st, j, ls);
         }
-        if (store && lane < 6) p.thetas[s * 6 + lane] = (float)get6(x, lane);
-        if (store && lane == 0) {
-            if (p.info) p.info[s] = info;
-            if (p.nfev) p.nfev[s] = nfev;
+
+        double a[6][E], fv[E], w4[E];
+        double wa1[6], wa2[6], wa3[6];
+        int ipvt[6];
+        residuals<GS, E>(x, sp, ri, rj, act, size, lane, fv);
+        // fdjac2
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const double temp = x[j];
+            double hstep = eps * fabs(temp);
+            if (hstep == 0) hstep = eps;
+            x[j] = temp + hstep;
+            residuals<GS, E>(x, sp, ri, rj, act, size, lane, w4);
+            x[j] = temp;
+#pragma unroll
+            for (int e = 0; e < E; e++) a[j][e] = (w4[e] - fv[e]) / hstep;
+        }
+        // qrfac with column pivoting: rdiag = wa1, acnorm = wa2, wa = wa3
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            wa2[j] = enorm_rows<GS, E>(a[j], lane, 0, m);
+            wa1[j] = wa2[j];
+            wa3[j] = wa1[j];
+            ipvt[j] = j;
+        }
+        qrfac_step<GS, E, 0>(a, wa1, wa3, ipvt, lane, m);
+        qrfac_step<GS, E, 1>(a, wa1, wa3, ipvt, lane, m);
+        qrfac_step<GS, E, 2>(a, wa1, wa3, ipvt, lane, m);
+        qrfac_step<GS, E, 3>(a, wa1, wa3, ipvt, lane, m);
+        qrfac_step<GS, E, 4>(a, wa1, wa3, ipvt, lane, m);
+        qrfac_step<GS, E, 5>(a, wa1, wa3, ipvt, lane, m);
+        // (Q^T fvec)[0..6): row j of the transformed vector ends in lane j; R: row i in lane i
+#pragma unroll
+        for (int e = 0; e < E; e++) w4[e] = fv[e];
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const double ajj = Grp<GS>::bcast_d(a[j][0], j);
+            if (ajj != 0) {
+                double sum = 0;
+#pragma unroll
+                for (int e = 0; e < E; e++)
+                    if (e > 0 || lane >= j) sum += a[j][e] * w4[e];
+                sum = Grp<GS>::sum_d(sum);
+                const double temp = -sum / ajj;
+#pragma unroll
+                for (int e = 0; e < E; e++)
+                    if (e > 0 || lane >= j) w4[e] += a[j][e] * temp;
+            }
+            if (lane == j) a[j][0] = wa1[j];
+        }
+        if (store && lane < 6) {
+#pragma unroll
+            for (int j = 0; j < 6; j++) LQD(st, 16 + lane * 6 + j, ls) = lane <= j ? a[j][0] : 0.0;
+            LQD(st, 52 + lane, ls) = w4[0];
+            LQD(st, 58 + lane, ls) = get6(wa2, lane);
+            LQI(st, lane, ls) = lane == 0 ? ipvt[0] : (lane == 1 ? ipvt[1] : (lane == 2 ? ipvt[2] : (lane == 3 ? ipvt[3] : (lane == 4 ? ipvt[4] : ipvt[5]))));
+            if (fresh) LQD(st, lane, ls) = get6(x, lane);
         }
     }
 }
 
+// MINPACK enorm, one component at a time in the published order (the trial residuals are never stored)
+struct EnormAcc {
+    double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0, agiant;
+    __device__ __forceinline__ explicit EnormAcc(int n) : agiant(RGIANT / (double)n) {}
+    __device__ __forceinline__ void add(double xv)
+    {
+        const double xabs = fabs(xv);
+        if (xabs > RDWARF && xabs < agiant) { s2 += xabs * xabs; }
+        else if (xabs <= RDWARF) {
+            if (xabs > x3max) { double r = x3max / xabs; s3 = 1 + s3 * r * r; x3max = xabs; }
+            else if (xabs != 0) { double r = xabs / x3max; s3 += r * r; }
+        } else {
+            if (xabs > x1max) { double r = x1max / xabs; s1 = 1 + s1 * r * r; x1max = xabs; }
+            else { double r = xabs / x1max; s1 += r * r; }
+        }
+    }
+    __device__ __forceinline__ double norm() const
+    {
+        if (s1 != 0) return x1max * sqrt(s1 + (s2 / x1max) / x1max);
+        if (s2 != 0) {
+            if (s2 >= x3max) return sqrt(s2 * (1 + (x3max / s2) * (x3max * s3)));
+            return sqrt(x3max * ((s2 / x3max) + (x3max * s3)));
+        }
+        return x3max * sqrt(s3);
+    }
+};
+
+constexpr int LQ_STEP_NT = 128;
+
+// (b): one spot per lane — the Levenberg-Marquardt step(s) on the factor lq_jacobian_kernel left, until the fit ends
+// or needs a new Jacobian.  Spots that go on are appended to next_list.
 template <bool FROM_MOVIE>
-static int launch(const Params &p, hipStream_t s)
+__global__ __launch_bounds__(LQ_STEP_NT) void lq_step_kernel(Params p, LqState st, const int32_t *__restrict__ list,
+                                                             const unsigned *__restrict__ list_n, int64_t count,
+                                                             int32_t *__restrict__ next_list, unsigned *__restrict__ next_n)
+{
+    __shared__ float s_px[PMI_MAX_BOX][LQ_STEP_NT];           // the x profile of the current evaluation, per thread
+    int64_t n = p.N;
+    if (p.d_n) { const int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+    const int64_t items = list ? (int64_t)*list_n : (st.first + count < n ? count : n - st.first);
+    const int64_t w = (int64_t)blockIdx.x * LQ_STEP_NT + threadIdx.x;
+    if (w >= items) return;
+    const int64_t s = list ? (int64_t)list[w] : st.first + w;
+    const int64_t ls = s - st.first;
+    int info = LQI(st, 8, ls);
+    if (info > 0) return;
+    const int size = p.box, m = size * size, hsz = size / 2;
+    const int tid = threadIdx.x;
+    const double ftol = 1e-2, xtol = 1e-2, gtol = 0.0, factor = 100.0;
+    const int maxfev = 200 * (6 + 1);
+    int64_t fr = 0, y0 = 0, x0 = 0;
+    if (FROM_MOVIE) { fr = p.frame[s]; y0 = p.y[s] - hsz; x0 = p.x[s] - hsz; }
+
+    // norm of the residuals of the float32-stored model (gausslq.py:151-203) at th
+    auto fnorm_at = [&](const double (&th)[6]) -> double {
+        const double nx = 0.3989422804014327 / th[4], ny = 0.3989422804014327 / th[5];
+        for (int j = 0; j < size; j++) {
+            const double t = ((double)(float)(j - hsz) - th[0]) / th[4];
+            s_px[j][tid] = (float)(nx * exp(-0.5 * (t * t)));
+        }
+        EnormAcc acc(m);
+        for (int i = 0; i < size; i++) {
+            const double t = ((double)(float)(i - hsz) - th[1]) / th[5];
+            const float myv = (float)(ny * exp(-0.5 * (t * t)));
+            for (int j = 0; j < size; j++) {
+                float spv;
+                if (FROM_MOVIE) {
+                    const float raw = load_movie_px(p.movie, p.dtype, (fr * p.Y + (y0 + i)) * p.X + (x0 + j));
+                    spv = div_const((raw - p.baseline) * p.sensitivity, p.gdiv);
+                } else {
+                    spv = p.spots[s * m + i * size + j];
+                }
+                const float model = (float)(th[2] * (double)myv * (double)s_px[j][tid] + th[3]);
+                const float res = spv - model;
+                acc.add((double)res);
+            }
+        }
+        return acc.norm();
+    };
+
+    double x[6], diag[6], qtf[6], wa1[6], wa2[6], wa3[6], R[36];
+    int ipvt[6];
+#pragma unroll
+    for (int j = 0; j < 6; j++) x[j] = LQD(st, j, ls);
+    int nfev, iter;
+    double par, delta, xnorm, fnorm;
+    if (info < 0) {
+        fnorm = fnorm_at(x);
+        nfev = 1; iter = 1; par = 0; delta = 0; xnorm = 0;
+#pragma unroll
+        for (int j = 0; j < 6; j++) diag[j] = 0;
+        info = 0;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) diag[j] = LQD(st, 6 + j, ls);
+        fnorm = LQD(st, 12, ls); delta = LQD(st, 13, ls); par = LQD(st, 14, ls); xnorm = LQD(st, 15, ls);
+        iter = LQI(st, 6, ls); nfev = LQI(st, 7, ls);
+    }
+#pragma unroll
+    for (int k = 0; k < 36; k++) R[k] = LQD(st, 16 + k, ls);
+#pragma unroll
+    for (int j = 0; j < 6; j++) { qtf[j] = LQD(st, 52 + j, ls); wa2[j] = LQD(st, 58 + j, ls); ipvt[j] = LQI(st, j, ls); }
+    nfev += 6;                                                 // the forward differences of this round
+    double gnorm = 0, fnorm1, actred, prered, dirder, ratio, pnorm;
+    if (iter == 1) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) { diag[j] = wa2[j]; if (wa2[j] == 0) diag[j] = 1; }
+#pragma unroll
+        for (int j = 0; j < 6; j++) wa3[j] = diag[j] * x[j];
+        xnorm = enorm6(wa3);
+        delta = factor * xnorm;
+        if (delta == 0) delta = factor;
+    }
+    if (fnorm != 0) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) {
+            const double w2l = get6(wa2, ipvt[j]);
+            if (w2l != 0) {
+                double sum = 0;
+#pragma unroll
+                for (int i = 0; i <= j; i++) sum += R[(i) * 6 + (j)] * (qtf[i] / fnorm);
+                const double g = fabs(sum / w2l);
+                if (g > gnorm) gnorm = g;
+            }
+        }
+    }
+    if (gnorm <= gtol) info = 4;
+    if (info == 0) {
+#pragma unroll
+        for (int j = 0; j < 6; j++)
+            if (wa2[j] > diag[j]) diag[j] = wa2[j];
+        for (;;) {
+            lmpar(R, ipvt, diag, qtf, delta, par, wa1, wa2);
+#pragma unroll
+            for (int j = 0; j < 6; j++) { wa1[j] = -wa1[j]; wa2[j] = x[j] + wa1[j]; wa3[j] = diag[j] * wa1[j]; }
+            pnorm = enorm6(wa3);
+            if (iter == 1 && pnorm < delta) delta = pnorm;
+            fnorm1 = fnorm_at(wa2);
+            nfev++;
+            actred = -1;
+            if (0.1 * fnorm1 < fnorm) { const double r = fnorm1 / fnorm; actred = 1 - r * r; }
+#pragma unroll
+            for (int j = 0; j < 6; j++) wa3[j] = 0;
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                const double temp = get6(wa1, ipvt[j]);
+#pragma unroll
+                for (int i = 0; i <= j; i++) wa3[i] += R[(i) * 6 + (j)] * temp;
+            }
+            const double temp1 = enorm6(wa3) / fnorm, temp2 = (sqrt(par) * pnorm) / fnorm;
+            prered = temp1 * temp1 + temp2 * temp2 / 0.5;
+            dirder = -(temp1 * temp1 + temp2 * temp2);
+            ratio = 0;
+            if (prered != 0) ratio = actred / prered;
+            if (ratio <= 0.25) {
+                double temp = 0.5;
+                if (actred < 0) temp = 0.5 * dirder / (dirder + 0.5 * actred);
+                if (0.1 * fnorm1 >= fnorm || temp < 0.1) temp = 0.1;
+                const double pd = pnorm / 0.1;
+                delta = temp * (delta < pd ? delta : pd);
+                par = par / temp;
+            } else if (par == 0 || ratio >= 0.75) {
+                delta = pnorm / 0.5;
+                par = 0.5 * par;
+            }
+            if (ratio >= 1e-4) {
+#pragma unroll
+                for (int j = 0; j < 6; j++) { x[j] = wa2[j]; wa2[j] = diag[j] * x[j]; }
+                xnorm = enorm6(wa2);
+                fnorm = fnorm1;
+                iter++;
+            }
+            if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1) info = 1;
+            if (delta <= xtol * xnorm) info = 2;
+            if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1 && info == 2) info = 3;
+            if (info != 0) break;
+            if (nfev >= maxfev) info = 5;
+            if (fabs(actred) <= EPSMCH && prered <= EPSMCH && 0.5 * ratio <= 1) info = 6;
+            if (delta <= EPSMCH * xnorm) info = 7;
+            if (gnorm <= EPSMCH) info = 8;
+            if (info != 0) break;
+            if (ratio >= 1e-4) break;
+        }
+    }
+    if (info != 0) {
+#pragma unroll
+        for (int j = 0; j < 6; j++) p.thetas[s * 6 + j] = (float)x[j];
+        if (p.info) p.info[s] = info;
+        if (p.nfev) p.nfev[s] = nfev;
+        LQI(st, 8, ls) = info;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) { LQD(st, j, ls) = x[j]; LQD(st, 6 + j, ls) = diag[j]; }
+        LQD(st, 12, ls) = fnorm; LQD(st, 13, ls) = delta; LQD(st, 14, ls) = par; LQD(st, 15, ls) = xnorm;
+        LQI(st, 6, ls) = iter; LQI(st, 7, ls) = nfev; LQI(st, 8, ls) = 0;
+        next_list[atomicAdd(next_n, 1u)] = (int32_t)s;
+    }
+}
+
+template <bool FROM_MOVIE>
+static void launch_jacobian(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count,
+                            int cus, hipStream_t s)
+{
+    const int m = p.box * p.box;
+    dim3 block(LQ_WAVES * 64);
+    auto grid_for = [&](int spots_per_wave) {
+        const int64_t waves = (count + spots_per_wave - 1) / spots_per_wave;
+        return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
+    };
+    if (p.box <= 7) {
+        // four spots per wavefront (2 * box <= 16 lanes evaluate the two profiles of a residual evaluation)
+        const dim3 grid = grid_for(4);
+        if (m <= 16) hipLaunchKernelGGL((lq_jacobian_kernel<16, 1, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+        else if (m <= 32) hipLaunchKernelGGL((lq_jacobian_kernel<16, 2, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+        else hipLaunchKernelGGL((lq_jacobian_kernel<16, 4, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+    } else if (p.box <= 15) {
+        const dim3 grid = grid_for(2);
+        if (m <= 96) hipLaunchKernelGGL((lq_jacobian_kernel<32, 3, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+        else if (m <= 128) hipLaunchKernelGGL((lq_jacobian_kernel<32, 4, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+        else if (m <= 192) hipLaunchKernelGGL((lq_jacobian_kernel<32, 6, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+        else hipLaunchKernelGGL((lq_jacobian_kernel<32, 8, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+    } else {
+        const int e = (m + 63) / 64;
+        const dim3 grid = grid_for(1);
+        if (e <= 5) hipLaunchKernelGGL((lq_jacobian_kernel<64, 5, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+        else hipLaunchKernelGGL((lq_jacobian_kernel<64, 7, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+    }
+}
+
+// Rounds of (Jacobian + QR, step) over the spots still running.  The first LQ_ROUNDS rounds are queued without
+// looking at the device; then the stream is synchronised once to read how many spots go on (on photon data: none —
+// a fit takes 2-4 outer iterations) and the stragglers get rounds of their own size until none is left.
+#ifndef LQ_ROUNDS
+#define LQ_ROUNDS 5
+#endif
+template <bool FROM_MOVIE>
+static int launch(Params p, hipStream_t s)
 {
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int m = p.box * p.box;
-    dim3 block(LQ_WAVES * 64);
-    if (p.box <= 7) {
-        // four spots per wavefront (2 * box <= 16 lanes evaluate the two profiles of a residual evaluation)
-        const int64_t waves = (p.N + 3) / 4;
-        dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
-        if (m <= 16) hipLaunchKernelGGL((lq_fit_kernel<16, 1, FROM_MOVIE>), grid, block, 0, s, p);
-        else if (m <= 32) hipLaunchKernelGGL((lq_fit_kernel<16, 2, FROM_MOVIE>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((lq_fit_kernel<16, 4, FROM_MOVIE>), grid, block, 0, s, p);
-    } else if (p.box <= 15 && !getenv("PMI_LQ_WAVE_PER_SPOT")) {
-        // two spots per wavefront (2 * box <= 32 profile lanes): the 6x6 stage, which costs a wavefront the same
-        // whatever the group size, is shared by two fits
-        const int64_t waves = (p.N + 1) / 2;
-        dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
-        if (m <= 96) hipLaunchKernelGGL((lq_fit_kernel<32, 3, FROM_MOVIE>), grid, block, 0, s, p);
-        else if (m <= 128) hipLaunchKernelGGL((lq_fit_kernel<32, 4, FROM_MOVIE>), grid, block, 0, s, p);
-        else if (m <= 192) hipLaunchKernelGGL((lq_fit_kernel<32, 6, FROM_MOVIE>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((lq_fit_kernel<32, 8, FROM_MOVIE>), grid, block, 0, s, p);
-    } else {
-        const int e = (m + 63) / 64;
-        dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((p.N + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
-        if (e <= 2) hipLaunchKernelGGL((lq_fit_kernel<64, 2, FROM_MOVIE>), grid, block, 0, s, p);
-        else if (e <= 3) hipLaunchKernelGGL((lq_fit_kernel<64, 3, FROM_MOVIE>), grid, block, 0, s, p);
-        else if (e <= 4) hipLaunchKernelGGL((lq_fit_kernel<64, 4, FROM_MOVIE>), grid, block, 0, s, p);
-        else hipLaunchKernelGGL((lq_fit_kernel<64, 7, FROM_MOVIE>), grid, block, 0, s, p);
+    const int64_t BATCH = 1 << 19;
+    const int64_t Ntotal = p.N;
+    const int64_t cap = std::min<int64_t>(Ntotal, BATCH);
+    void *ptr = nullptr;
+    int rc;
+    const size_t bytes = (size_t)cap * (LQ_NSD * sizeof(double) + LQ_NSI * sizeof(int32_t) + 2 * sizeof(int32_t)) + 1024;
+    if ((rc = scratch(SCR_STAGE_D, bytes, &ptr)) != PMI_OK) return rc;
+    LqState st;
+    st.d = (double *)ptr;
+    st.i = (int32_t *)(st.d + (size_t)cap * LQ_NSD);
+    st.stride = cap;
+    int32_t *lists[2] = {st.i + (size_t)cap * LQ_NSI, st.i + (size_t)cap * (LQ_NSI + 1)};
+    unsigned *counters = (unsigned *)(lists[1] + cap);           // one per round, zeroed per batch
+    constexpr int NCTR = 64;
+    for (int64_t first = 0; first < Ntotal; first += BATCH) {
+        const int64_t count = std::min<int64_t>(BATCH, Ntotal - first);
+        st.first = first;
+        PMI_HIP(hipMemsetAsync(st.i + (size_t)8 * cap, 0xff, (size_t)cap * sizeof(int32_t), s));      // info = -1: fresh
+        PMI_HIP(hipMemsetAsync(counters, 0, NCTR * sizeof(unsigned), s));
+        const int32_t *cur = nullptr;
+        const unsigned *cur_n = nullptr;
+        int64_t bound = count;                                   // spots the next round may hold
+        int round = 0;
+        for (;;) {
+            int32_t *nxt = lists[round & 1];
+            unsigned *nxt_n = counters + (round % NCTR);
+            if (round >= NCTR) PMI_HIP(hipMemsetAsync(nxt_n, 0, sizeof(unsigned), s));
+            launch_jacobian<FROM_MOVIE>(p, st, cur, cur_n, bound, cus, s);
+            const unsigned sb = (unsigned)((bound + LQ_STEP_NT - 1) / LQ_STEP_NT);
+            hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE>), dim3(sb), dim3(LQ_STEP_NT), 0, s, p, st, cur, cur_n, bound, nxt, nxt_n);
+            PMI_HIP(hipGetLastError());
+            cur = nxt; cur_n = nxt_n;
+            round++;
+            if (round >= LQ_ROUNDS) {
+                unsigned left = 0;
+                PMI_HIP(hipMemcpyAsync(&left, cur_n, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+                PMI_HIP(hipStreamSynchronize(s));
+                if (left == 0) break;
+                bound = left;
+            }
+        }
     }
-    PMI_HIP(hipGetLastError());
     return PMI_OK;
 }
 

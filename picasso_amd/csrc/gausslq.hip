@@ -105,6 +105,34 @@ template <> struct Grp<16> {
         return ((b >> ((threadIdx.x & 63u) & ~15u)) & 0xffffull) != 0;
     }
 };
+template <> struct Grp<8> {           // half a DPP row: eight spots per wavefront (boxes up to 7x7: 49 residuals = 7 per lane)
+    static __device__ __forceinline__ double sum_d(double v)
+    {
+        v += dpp_d<0xB1>(v);          // quad_perm [1,0,3,2]
+        v += dpp_d<0x4E>(v);          // quad_perm [2,3,0,1]
+        v += dpp_d<0x141>(v);         // row_half_mirror: every lane of the half row holds its sum
+        return v;
+    }
+    static __device__ __forceinline__ double max_d(double v)
+    {
+        for (int off = 4; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+        return v;
+    }
+    static __device__ __forceinline__ float min_f(float v)
+    {
+        for (int off = 4; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
+        return v;
+    }
+    static __device__ __forceinline__ double bcast_d(double v, int k)
+    {
+        return __shfl(v, (int)((threadIdx.x & 63u) & ~7u) + k);
+    }
+    static __device__ __forceinline__ bool any(bool c)
+    {
+        const unsigned long long b = __builtin_amdgcn_ballot_w64(c);
+        return ((b >> ((threadIdx.x & 63u) & ~7u)) & 0xffull) != 0;
+    }
+};
 template <> struct Grp<32> {          // half a wavefront: two DPP rows, the partner row through bpermute
     static __device__ __forceinline__ double sum_d(double v)
     {
@@ -227,31 +255,44 @@ __device__ __forceinline__ double enorm_rows(const double (&v)[E], int lane, int
     return x3max * sqrt(s3);
 }
 
-// Residuals of the float32-stored model (gausslq.py:151-203).  Lanes [0, size)
-// evaluate the x profile, lanes [size, 2 size) the y profile; every row then
-// fetches its two factors.
+// Residuals of the float32-stored model (gausslq.py:151-203).  The 2 * size profile values of an evaluation (x
+// profile at flat index f < size, y profile at f - size) are spread over the lanes of the group, NPROF per lane
+// (one, except for the 8-lane groups: 14 values on 8 lanes); every row then fetches its two factors.
 template <int GS, int E>
 __device__ __forceinline__ void residuals(const double (&th)[6], const float (&sp)[E], const int (&ri)[E],
                                           const int (&rj)[E], const bool (&act)[E], int size, int lane,
-                                          double (&out)[E])
+                                          float (&out)[E])
 {
+    constexpr int NPROF = GS == 8 ? 2 : 1;
     const int hsz = size / 2;
-    const bool isy = lane >= size;
-    const int idx = isy ? lane - size : lane;
     const double th0 = th[0], th1 = th[1], th4 = th[4], th5 = th[5];   // values, not an lvalue select
-    const double mu = isy ? th1 : th0, sg = isy ? th5 : th4;
-    const double g = (double)(float)(idx - hsz);
-    const double t = (g - mu) / sg;
-    const double nrm = 0.3989422804014327 / sg;
-    const float prof = (float)(nrm * exp(-0.5 * (t * t)));
+    float prof[NPROF];
+#pragma unroll
+    for (int k = 0; k < NPROF; k++) {
+        const int f = lane + GS * k;
+        const bool isy = f >= size;
+        const int idx = isy ? f - size : f;
+        const double mu = isy ? th1 : th0, sg = isy ? th5 : th4;
+        const double g = (double)(float)(idx - hsz);
+        const double t = (g - mu) / sg;
+        const double nrm = 0.3989422804014327 / sg;
+        prof[k] = (float)(nrm * exp(-0.5 * (t * t)));
+    }
+    const int gbase = GS == 64 ? 0 : (int)((threadIdx.x & 63u) & ~(unsigned)(GS - 1));     // first lane of this group
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int gbase = GS == 64 ? 0 : (int)((threadIdx.x & 63u) & ~(unsigned)(GS - 1));     // first lane of this group
-        const float mxv = __shfl(prof, gbase + rj[e]);
-        const float myv = __shfl(prof, gbase + size + ri[e]);
+        const int fx = rj[e], fy = size + ri[e];
+        float mxv = __shfl(prof[0], gbase + (fx & (GS - 1)));
+        float myv = __shfl(prof[0], gbase + (fy & (GS - 1)));
+        if (NPROF > 1) {
+            const float mx1 = __shfl(prof[NPROF - 1], gbase + (fx & (GS - 1)));
+            const float my1 = __shfl(prof[NPROF - 1], gbase + (fy & (GS - 1)));
+            mxv = fx >= GS ? mx1 : mxv;
+            myv = fy >= GS ? my1 : myv;
+        }
         const float model = (float)(th[2] * (double)myv * (double)mxv + th[3]);
         const float res = sp[e] - model;
-        out[e] = act[e] ? (double)res : 0.0;
+        out[e] = act[e] ? res : 0.0f;          // a float32 value: the callers widen it where MINPACK works in float64
     }
 }
 
@@ -525,7 +566,6 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kerne
         const int64_t w = store ? w0 + grp : items - 1;
         const int64_t s = list ? (int64_t)list[w] : st.first + w;
         const int64_t ls = s - st.first;
-        const bool fresh = LQI(st, 8, ls) < 0;
         // ---- the spot: rows of this lane ----
         float sp[E];
         if (FROM_MOVIE) {
@@ -544,49 +584,11 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kerne
         }
 
         double x[6];
-        if (Grp<GS>::any(fresh)) {
-            // ---- initial parameters (gausslq.py:95-112) ----
-            float mn = __builtin_inff();
-            bool anynan = false;
 #pragma unroll
-            for (int e = 0; e < E; e++)
-                if (act[e]) { mn = fminf(mn, sp[e]); anynan |= sp[e] != sp[e]; }
-            mn = Grp<GS>::min_f(mn);
-            if (Grp<GS>::any(anynan)) mn = __builtin_nanf("");
-            double sy = 0, sx = 0, sum = 0;
-            double v[E];
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                v[e] = act[e] ? (double)(float)(sp[e] - mn) : 0.0;
-                sy += v[e] * (double)ri[e];
-                sx += v[e] * (double)rj[e];
-                sum += v[e];
-            }
-            sy = Grp<GS>::sum_d(sy); sx = Grp<GS>::sum_d(sx); sum = Grp<GS>::sum_d(sum);
-            if (sum <= 0.0) { sum = 0.01; sy = (size - 1) / 2.0; sx = (size - 1) / 2.0; }
-            else { sy /= sum; sx /= sum; }
-            float t1 = (float)sy, t0 = (float)sx;
-            const float t2 = (float)(1.0 > sum ? 1.0 : sum);
-            double sdy = 0, sdx = 0;
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                const double dy = (double)ri[e] - (double)t1, dx = (double)rj[e] - (double)t0;
-                sdy += v[e] * (dy * dy);
-                sdx += v[e] * (dx * dx);
-            }
-            sdy = Grp<GS>::sum_d(sdy); sdx = Grp<GS>::sum_d(sdx);
-            const float t5 = (float)sqrt(sdy / sum), t4 = (float)sqrt(sdx / sum);
-            t0 = t0 - (float)hsz;
-            t1 = t1 - (float)hsz;
-            x[0] = (double)t0; x[1] = (double)t1; x[2] = (double)t2; x[3] = (double)mn;
-            x[4] = (double)t4; x[5] = (double)t5;
-        }
-        if (!fresh) {
-#pragma unroll
-            for (int j = 0; j < 6; j++) x[j] = LQD(st, j, ls);
-        }
+        for (int j = 0; j < 6; j++) x[j] = LQD(st, j, ls);
 
-        double a[6][E], fv[E], w4[E];
+        double a[6][E], w4[E];
+        float fv[E], fp[E];                   // residuals at x and at the perturbed x (float32 values, gausslq.py:203)
         double wa1[6], wa2[6], wa3[6];
         int ipvt[6];
         residuals<GS, E>(x, sp, ri, rj, act, size, lane, fv);
@@ -597,10 +599,10 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kerne
             double hstep = eps * fabs(temp);
             if (hstep == 0) hstep = eps;
             x[j] = temp + hstep;
-            residuals<GS, E>(x, sp, ri, rj, act, size, lane, w4);
+            residuals<GS, E>(x, sp, ri, rj, act, size, lane, fp);
             x[j] = temp;
 #pragma unroll
-            for (int e = 0; e < E; e++) a[j][e] = (w4[e] - fv[e]) / hstep;
+            for (int e = 0; e < E; e++) a[j][e] = ((double)fp[e] - (double)fv[e]) / hstep;
         }
         // qrfac with column pivoting: rdiag = wa1, acnorm = wa2, wa = wa3
 #pragma unroll
@@ -618,7 +620,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kerne
         qrfac_step<GS, E, 5>(a, wa1, wa3, ipvt, lane, m);
         // (Q^T fvec)[0..6): row j of the transformed vector ends in lane j; R: row i in lane i
 #pragma unroll
-        for (int e = 0; e < E; e++) w4[e] = fv[e];
+        for (int e = 0; e < E; e++) w4[e] = (double)fv[e];
 #pragma unroll
         for (int j = 0; j < 6; j++) {
             const double ajj = Grp<GS>::bcast_d(a[j][0], j);
@@ -641,9 +643,112 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kerne
             LQD(st, 52 + lane, ls) = w4[0];
             LQD(st, 58 + lane, ls) = get6(wa2, lane);
             LQI(st, lane, ls) = lane == 0 ? ipvt[0] : (lane == 1 ? ipvt[1] : (lane == 2 ? ipvt[2] : (lane == 3 ? ipvt[3] : (lane == 4 ? ipvt[4] : ipvt[5]))));
-            if (fresh) LQD(st, lane, ls) = get6(x, lane);
         }
     }
+}
+
+// The one-spot-per-lane kernels read a spot many times (start values: three passes; every trial evaluation: one).
+// Lane-strided reads of (N, box, box) — or of the movie — touch a cache line per lane and instruction, so the
+// spots of a workgroup are first copied, converted to photons (localize.py:1101-1112), into an LDS tile with a
+// coalesced sweep; boxes above 9x9 (tile too large) read from memory.
+constexpr int LQ_TILE_MAXPIX = 81;
+template <bool FROM_MOVIE, int NT>
+__device__ __forceinline__ void stage_spots(const Params &p, const int64_t (&sidx)[NT], float *tile, int m, int size)
+{
+    const int hsz = size / 2;
+    for (int q = threadIdx.x; q < NT * m; q += NT) {
+        const int t = q / m, k = q - t * m;
+        const int64_t s = sidx[t];
+        float v = 0.f;
+        if (s >= 0) {
+            if (FROM_MOVIE) {
+                const int i = k / size, j = k - i * size;
+                const float raw = load_movie_px(p.movie, p.dtype, ((int64_t)p.frame[s] * p.Y + (p.y[s] - hsz + i)) * p.X + (p.x[s] - hsz + j));
+                v = div_const((raw - p.baseline) * p.sensitivity, p.gdiv);
+            } else {
+                v = p.spots[s * m + k];
+            }
+        }
+        tile[q] = v;
+    }
+}
+
+// The fit reads a spot once per round in each of its kernels.  Gathering 7 x 14 bytes from the movie every time costs
+// more than the arithmetic, so the fused path cuts the ROIs of a batch ONCE (localize.py:917-931, :1101-1112) into a
+// scratch (count, box, box) float32 array — what get_spots returns — and the rounds read that.
+__global__ void lq_cut_kernel(Params p, int64_t first, int64_t count, float *__restrict__ out)
+{
+    int64_t n = p.N;
+    if (p.d_n) { const int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+    const int size = p.box, m = size * size, hsz = size / 2;
+    const int64_t rows = first + count < n ? count : n - first;
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < rows * m; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t w = t / m;
+        const int k = (int)(t - w * m);
+        const int i = k / size, j = k - i * size;
+        const int64_t s = first + w;
+        const float raw = load_movie_px(p.movie, p.dtype, ((int64_t)p.frame[s] * p.Y + (p.y[s] - hsz + i)) * p.X + (p.x[s] - hsz + j));
+        out[t] = div_const((raw - p.baseline) * p.sensitivity, p.gdiv);
+    }
+}
+
+// start values (gausslq.py:95-112), one spot per lane, float64 sums in the reference's row-major order
+template <bool FROM_MOVIE>
+__global__ __launch_bounds__(256) void lq_init_kernel(Params p, LqState st, int64_t count)
+{
+    int64_t n = p.N;
+    if (p.d_n) { const int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];      // [256] spot indices, then the tile of 256 x m floats
+    int64_t (&s_idx)[256] = *reinterpret_cast<int64_t (*)[256]>(s_dyn);
+    float *s_tile = reinterpret_cast<float *>(s_dyn + 256 * sizeof(int64_t));
+    const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t s = st.first + w;
+    const bool mine = w < count && s < n;
+    const int size = p.box, m = size * size, hsz = size / 2;
+    const bool staged = m <= LQ_TILE_MAXPIX;
+    s_idx[threadIdx.x] = mine ? s : -1;
+    __syncthreads();
+    if (staged) { stage_spots<FROM_MOVIE, 256>(p, s_idx, s_tile, m, size); __syncthreads(); }
+    if (!mine) return;
+    int64_t fr = 0, y0 = 0, x0 = 0;
+    if (FROM_MOVIE) { fr = p.frame[s]; y0 = p.y[s] - hsz; x0 = p.x[s] - hsz; }
+    const float *mytile = s_tile + (size_t)threadIdx.x * m;
+    auto px = [&](int i, int j) -> float {
+        if (staged) return mytile[i * size + j];
+        if (FROM_MOVIE) {
+            const float raw = load_movie_px(p.movie, p.dtype, (fr * p.Y + (y0 + i)) * p.X + (x0 + j));
+            return div_const((raw - p.baseline) * p.sensitivity, p.gdiv);
+        }
+        return p.spots[s * m + i * size + j];
+    };
+    float mn = px(0, 0);
+    for (int i = 0; i < size; i++)
+        for (int j = 0; j < size; j++) { const float v = px(i, j); if (mn == mn && (v < mn || v != v)) mn = v; }   // np.min: NaN propagates
+    double sy = 0, sx = 0, sum = 0;
+    for (int i = 0; i < size; i++)
+        for (int j = 0; j < size; j++) {
+            const double v = (double)(float)(px(i, j) - mn);
+            sy += v * (double)i; sx += v * (double)j; sum += v;
+        }
+    if (sum <= 0.0) { sum = 0.01; sy = (size - 1) / 2.0; sx = (size - 1) / 2.0; }
+    else { sy /= sum; sx /= sum; }
+    float t1 = (float)sy, t0 = (float)sx;
+    const float t2 = (float)(1.0 > sum ? 1.0 : sum);
+    double sdy = 0, sdx = 0;
+    for (int i = 0; i < size; i++)
+        for (int j = 0; j < size; j++) {
+            const double v = (double)(float)(px(i, j) - mn);
+            const double dy = (double)i - (double)t1, dx = (double)j - (double)t0;
+            sdy += v * (dy * dy);
+            sdx += v * (dx * dx);
+        }
+    const float t5 = (float)sqrt(sdy / sum), t4 = (float)sqrt(sdx / sum);
+    t0 = t0 - (float)hsz;
+    t1 = t1 - (float)hsz;
+    const int64_t ls = w;
+    LQD(st, 0, ls) = (double)t0; LQD(st, 1, ls) = (double)t1; LQD(st, 2, ls) = (double)t2; LQD(st, 3, ls) = (double)mn;
+    LQD(st, 4, ls) = (double)t4; LQD(st, 5, ls) = (double)t5;
+    LQI(st, 8, ls) = -1;                                        // fresh: lq_step_kernel starts its counters
 }
 
 // MINPACK enorm, one component at a time in the published order (the trial residuals are never stored)
@@ -682,18 +787,27 @@ __global__ __launch_bounds__(LQ_STEP_NT) void lq_step_kernel(Params p, LqState s
                                                              const unsigned *__restrict__ list_n, int64_t count,
                                                              int32_t *__restrict__ next_list, unsigned *__restrict__ next_n)
 {
-    __shared__ float s_px[PMI_MAX_BOX][LQ_STEP_NT];           // the x profile of the current evaluation, per thread
+    // dynamic LDS: [NT] spot indices, the x profile of the current evaluation (box x NT floats), the tile of NT x m floats
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+    int64_t (&s_idx)[LQ_STEP_NT] = *reinterpret_cast<int64_t (*)[LQ_STEP_NT]>(s_dyn);
+    float (*s_px)[LQ_STEP_NT] = reinterpret_cast<float (*)[LQ_STEP_NT]>(s_dyn + LQ_STEP_NT * sizeof(int64_t));
+    float *s_tile = reinterpret_cast<float *>(s_dyn + LQ_STEP_NT * sizeof(int64_t) + (size_t)p.box * LQ_STEP_NT * sizeof(float));
     int64_t n = p.N;
     if (p.d_n) { const int64_t dn = *p.d_n; n = dn < n ? dn : n; }
     const int64_t items = list ? (int64_t)*list_n : (st.first + count < n ? count : n - st.first);
     const int64_t w = (int64_t)blockIdx.x * LQ_STEP_NT + threadIdx.x;
-    if (w >= items) return;
-    const int64_t s = list ? (int64_t)list[w] : st.first + w;
-    const int64_t ls = s - st.first;
-    int info = LQI(st, 8, ls);
-    if (info > 0) return;
+    if ((int64_t)blockIdx.x * LQ_STEP_NT >= items) return;   // the whole workgroup is past the list
     const int size = p.box, m = size * size, hsz = size / 2;
     const int tid = threadIdx.x;
+    const bool staged = m <= LQ_TILE_MAXPIX;
+    const int64_t s = w < items ? (list ? (int64_t)list[w] : st.first + w) : -1;
+    const int64_t ls = s - st.first;
+    int info = s >= 0 ? LQI(st, 8, ls) : 1;
+    s_idx[tid] = info > 0 ? -1 : s;
+    __syncthreads();
+    if (staged) { stage_spots<FROM_MOVIE, LQ_STEP_NT>(p, s_idx, s_tile, m, size); __syncthreads(); }
+    if (info > 0) return;
+    const float *mytile = s_tile + (size_t)tid * m;
     const double ftol = 1e-2, xtol = 1e-2, gtol = 0.0, factor = 100.0;
     const int maxfev = 200 * (6 + 1);
     int64_t fr = 0, y0 = 0, x0 = 0;
@@ -712,7 +826,9 @@ __global__ __launch_bounds__(LQ_STEP_NT) void lq_step_kernel(Params p, LqState s
             const float myv = (float)(ny * exp(-0.5 * (t * t)));
             for (int j = 0; j < size; j++) {
                 float spv;
-                if (FROM_MOVIE) {
+                if (staged) {
+                    spv = mytile[i * size + j];
+                } else if (FROM_MOVIE) {
                     const float raw = load_movie_px(p.movie, p.dtype, (fr * p.Y + (y0 + i)) * p.X + (x0 + j));
                     spv = div_const((raw - p.baseline) * p.sensitivity, p.gdiv);
                 } else {
@@ -855,8 +971,15 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
         const int64_t waves = (count + spots_per_wave - 1) / spots_per_wave;
         return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
     };
-    if (p.box <= 7) {
-        // four spots per wavefront (2 * box <= 16 lanes evaluate the two profiles of a residual evaluation)
+    static const bool g16 = getenv("PMI_LQ_GROUP16") != nullptr;      // A/B: the 16-lane groups for boxes up to 7
+    if (p.box <= 7 && !g16) {
+        // eight spots per wavefront: the scalar chains of the factorisation (norm updates, Householder scalings:
+        // float64 divisions and square roots every lane of a group repeats) are shared by twice as many fits
+        const dim3 grid = grid_for(8);
+        if (m <= 16) hipLaunchKernelGGL((lq_jacobian_kernel<8, 2, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+        else if (m <= 32) hipLaunchKernelGGL((lq_jacobian_kernel<8, 4, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+        else hipLaunchKernelGGL((lq_jacobian_kernel<8, 7, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+    } else if (p.box <= 7) {
         const dim3 grid = grid_for(4);
         if (m <= 16) hipLaunchKernelGGL((lq_jacobian_kernel<16, 1, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
         else if (m <= 32) hipLaunchKernelGGL((lq_jacobian_kernel<16, 2, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
@@ -881,9 +1004,10 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
 #ifndef LQ_ROUNDS
 #define LQ_ROUNDS 5
 #endif
-template <bool FROM_MOVIE>
+template <bool FROM_MOVIE_IN>
 static int launch(Params p, hipStream_t s)
 {
+    constexpr bool FROM_MOVIE = false;             // the rounds always read (N, box, box) float32 spots (lq_cut_kernel)
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -901,11 +1025,24 @@ static int launch(Params p, hipStream_t s)
     int32_t *lists[2] = {st.i + (size_t)cap * LQ_NSI, st.i + (size_t)cap * (LQ_NSI + 1)};
     unsigned *counters = (unsigned *)(lists[1] + cap);           // one per round, zeroed per batch
     constexpr int NCTR = 64;
+    float *cut = nullptr;
+    const int mpix = p.box * p.box;
+    if (FROM_MOVIE_IN) {
+        void *cptr = nullptr;
+        if ((rc = scratch(SCR_STAGE_C, (size_t)cap * mpix * sizeof(float), &cptr)) != PMI_OK) return rc;
+        cut = (float *)cptr;
+    }
     for (int64_t first = 0; first < Ntotal; first += BATCH) {
         const int64_t count = std::min<int64_t>(BATCH, Ntotal - first);
         st.first = first;
-        PMI_HIP(hipMemsetAsync(st.i + (size_t)8 * cap, 0xff, (size_t)cap * sizeof(int32_t), s));      // info = -1: fresh
+        if (FROM_MOVIE_IN) {
+            const unsigned cb = (unsigned)std::min<int64_t>((count * mpix + 255) / 256, 65536);
+            hipLaunchKernelGGL(lq_cut_kernel, dim3(cb), dim3(256), 0, s, p, first, count, cut);
+            p.spots = cut - first * mpix;          // indexed by the absolute spot number
+        }
         PMI_HIP(hipMemsetAsync(counters, 0, NCTR * sizeof(unsigned), s));
+        const size_t init_lds = 256 * sizeof(int64_t) + (mpix <= LQ_TILE_MAXPIX ? (size_t)256 * mpix * sizeof(float) : 0);
+        hipLaunchKernelGGL((lq_init_kernel<FROM_MOVIE>), dim3((unsigned)((count + 255) / 256)), dim3(256), init_lds, s, p, st, count);
         const int32_t *cur = nullptr;
         const unsigned *cur_n = nullptr;
         int64_t bound = count;                                   // spots the next round may hold
@@ -916,7 +1053,9 @@ static int launch(Params p, hipStream_t s)
             if (round >= NCTR) PMI_HIP(hipMemsetAsync(nxt_n, 0, sizeof(unsigned), s));
             launch_jacobian<FROM_MOVIE>(p, st, cur, cur_n, bound, cus, s);
             const unsigned sb = (unsigned)((bound + LQ_STEP_NT - 1) / LQ_STEP_NT);
-            hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE>), dim3(sb), dim3(LQ_STEP_NT), 0, s, p, st, cur, cur_n, bound, nxt, nxt_n);
+            const size_t step_lds = LQ_STEP_NT * sizeof(int64_t) + (size_t)p.box * LQ_STEP_NT * sizeof(float) +
+                                    (mpix <= LQ_TILE_MAXPIX ? (size_t)LQ_STEP_NT * mpix * sizeof(float) : 0);
+            hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, cur, cur_n, bound, nxt, nxt_n);
             PMI_HIP(hipGetLastError());
             cur = nxt; cur_n = nxt_n;
             round++;

@@ -2,7 +2,7 @@
 """The other single-GPU workloads of BASELINE.json, timed resident in HBM (bench.py measures configs[1]):
 
   config 3: same 10k x 512 x 512 movie, gausslq least-squares path + Gaussian render at oversampling 10
-  config 5: 13x13 ROI astigmatic MLE fit + zfit on a simulated z-stack (10k frames here, ~1e6 spots)
+  config 5: 13x13 ROI astigmatic MLE fit + zfit on a simulated z-stack (50k frames, ~5e6 spots, as BASELINE.json names it)
 
 One JSON line per config (same vocabulary as bench.py; value = localizations/s of the whole chain).
 usage: python tools/bench_configs.py [--frames 10000] [--steps 5] [--cpu-seconds 8]
@@ -22,6 +22,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=10000)
+    ap.add_argument("--frames5", type=int, default=50000, help="frames of config 5 (50 000 x 512 x 512 = 26 GB resident, ~5e6 spots)")
+    ap.add_argument("--only", type=int, default=0, help="3 or 5: just that config")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
     args = ap.parse_args()
@@ -41,7 +43,36 @@ def main():
             t0 = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
         return float(np.median(ts))
 
+    def kernel_ms(fn):
+        """HIP-event time of the scan kernel and of the fit stage inside the library, mean of 3 instrumented calls"""
+        L.pmi_set_kernel_timing(1)
+        a, b = ctypes.c_float(0), ctypes.c_float(0)
+        sa, sb = [], []
+        for _ in range(3):
+            fn(); torch.cuda.synchronize()
+            L.pmi_last_kernel_ms(ctypes.byref(a), ctypes.byref(b))
+            sa.append(a.value); sb.append(b.value)
+        L.pmi_set_kernel_timing(0)
+        return float(np.mean(sa)), float(np.mean(sb))
+
+    def roofline(movie_bytes, scan_ms, fit_ms, n_spots, fit_name, fit_bound, bytes_per_spot):
+        ach = movie_bytes / (scan_ms * 1e-3) / 1e9
+        return {"bound": "hbm", "kernel": "identify_scan_u16_fast_kernel", "achieved": ach, "peak": 8000.0, "unit": "GB/s",
+                "frac": ach / 8000.0, "traffic": None,
+                "kernels": {"identify_scan": {"ms": scan_ms, "algorithmic_bytes": movie_bytes, "GB/s": ach},
+                            fit_name: {"ms": fit_ms, "spots_per_s": n_spots / (fit_ms * 1e-3), "bound": fit_bound,
+                                       "algorithmic_bytes": bytes_per_spot * n_spots,
+                                       "GB/s": bytes_per_spot * n_spots / (fit_ms * 1e-3) / 1e9}}}
+
     # ---------------- config 3 ----------------
+    if args.only in (0, 3):
+        config3(args, torch, orc, L, _lib, synth, cam, threads, timed, kernel_ms, roofline)
+    if args.only in (0, 5):
+        config5(args, torch, orc, L, _lib, synth, cam, threads, timed, kernel_ms, roofline)
+
+
+def config3(args, torch, orc, L, _lib, synth, cam, threads, timed, kernel_ms, roofline):
+    F, H, W = args.frames, 512, 512
     movie = synth.simulate_movie(F, H, W, emitters_per_frame=116, device="cuda")
     torch.cuda.synchronize()
     cap = 140 * F
@@ -58,6 +89,7 @@ def main():
 
     t_lq = timed(lq)
     n = int(d_n.item())
+    scan_ms, fit_ms = kernel_ms(lq)
 
     def rend():
         _lib.check(L.pmi_render_gaussian_dev(col(1), col(2), col(7), col(8), n, 10.0, 0.0, 0.0, float(H), float(W), 0.0, 0,
@@ -87,10 +119,16 @@ def main():
                       "config": {"workload": f"{F}-frame 512x512 uint16 movie, {n} spots, identify + fused cut + MINPACK lmdif fit + "
                                              "11-column table, then render to 5120x5120 float32", "frames": F, "box": 7},
                       "stages_ms": {"identify+gausslq+table": 1e3 * t_lq, "render_gaussian": 1e3 * t_r},
+                      "roofline": roofline(movie.numel() * 2, scan_ms, fit_ms, n, "gausslq_fit (cut + init + rounds of Jacobian/QR and LM step)",
+                                           "fp64 valu latency (MINPACK lmdif: serial divisions / square roots); 166 B/spot algorithmic", 166.0),
                       "cpu_baseline": cpu}), flush=True)
     del movie, table, image
 
-    # ---------------- config 5 ----------------
+
+def config5(args, torch, orc, L, _lib, synth, cam, threads, timed, kernel_ms, roofline):
+    F, H, W = args.frames5, 512, 512
+    cap = 140 * F
+    d_n = torch.zeros(1, dtype=torch.int64, device="cuda")
     movie = synth.simulate_movie(F, H, W, emitters_per_frame=116, device="cuda", sigma=(1.1, 2.4), astigmatic=True,
                                  photons=(3000.0, 9000.0), seed=synth.DEFAULT_SEED + 5)
     torch.cuda.synchronize()
@@ -107,6 +145,9 @@ def main():
 
     t_m = timed(mle13)
     n = int(d_n.item())
+    scan_ms, fit_ms = kernel_ms(mle13)
+    from picasso_amd import backend
+    refit = backend.last_refit_count()
 
     def zf():
         _lib.check(L.pmi_zfit_dev(col(4), col(5), n, None, ctypes.c_void_p(cx.data_ptr()), ctypes.c_void_p(cy.data_ptr()),
@@ -130,7 +171,11 @@ def main():
                       "higher_is_better": True, "dtype": "f32", "data": "synthetic",
                       "config": {"workload": f"{F}-frame 512x512 uint16 astigmatic movie, {n} spots, identify(box 13) + fused cut + "
                                              "MLE sigmaxy + 17-column table, then bounded-Brent zfit", "frames": F, "box": 13},
-                      "stages_ms": {"identify+gaussmle+table": 1e3 * t_m, "zfit": 1e3 * t_z}, "cpu_baseline": cpu}), flush=True)
+                      "stages_ms": {"identify+gaussmle+table": 1e3 * t_m, "zfit": 1e3 * t_z},
+                      "mle": {"mode": backend.get_mle_mode()[0], "refit_spots": refit},
+                      "roofline": roofline(movie.numel() * 2, scan_ms, fit_ms, n, "mle_fit_13x13 (g8 init/iterate/final + strict refit + crlb)",
+                                           "fp32 valu issue; 406 B/spot algorithmic", 406.0),
+                      "cpu_baseline": cpu}), flush=True)
 
 
 if __name__ == "__main__":

@@ -189,7 +189,10 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef G8_REFILL_K
 #define G8_REFILL_K 2
 #endif
-template <int GS> struct GLds { static constexpr int N = GS * 12 + GS * 12 + 8; };
+// + 16 (8 for the 16-lane groups): the stride of a group is then 16 banks (mod 64), so the 12-float rows that the
+// four groups of a half wave read in one ds_read_b64 of the reduction fall on disjoint banks (with a stride of
+// 8 banks neighbouring groups overlapped: 16 % of the LDS cycles were bank conflicts, profiles/r02_g8_iterate_pmc.txt)
+template <int GS> struct GLds { static constexpr int N = GS * 12 + GS * 12 + (GS == 8 ? 16 : 16); };
 
 struct LaneRole {          // what lane j does in the update stage: parameter j (j < NP)
     float ms;              // max_step of its parameter

@@ -6,7 +6,7 @@ from math import erf, sqrt
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from picasso_amd import _lib  # noqa: E402
 
 N = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20

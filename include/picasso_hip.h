@@ -309,6 +309,22 @@ int pmi_allgather_locs(void *comm, const void *d_table, int ncols, int64_t cap, 
 int pmi_compact_gathered_dev(const void *d_all_tables, const int64_t *d_all_counts, int world, int ncols, int64_t cap,
                              void *d_table, int64_t table_cap, int64_t *d_total, void *stream);
 
+/* ---- sub-pixel correlation peak (picasso/imageprocess.py:121-141) ---------------------------- *
+ * The reference fits a * exp(-0.5 ((x - xc)^2 + (y - yc)^2) / s^2) + b to the box x box window around
+ * the correlation maximum with scipy.optimize.curve_fit(p0 = [max, 0, 0, 1, min], bounds = ([0, -inf,
+ * -inf, 0, 0], inf)) = least_squares(method="trf", jac="2-point"): the Trust Region Reflective algorithm
+ * of scipy 1.15.3, restated for one thread per window (csrc/peakfit.hip).
+ * pmi_peak_fit: rois (n, box, box) float64 -> popt (n, 5) = a, xc, yc, s, b and scipy's termination
+ * status (1 gtol, 2 ftol, 3 xtol, 4 both, 0 max_nfev; -2: window minimum < 0, where curve_fit raises
+ * "x0 is infeasible").
+ * pmi_rcc_shifts: all of get_image_shift (:53-161) for a list of (i, j) pairs of the n_seg float64
+ * images — correlation, centre crop, first maximum, window, fit — -> shift_yx (n_pairs, 2) = (-yc, -xc);
+ * fit_status as above, or -1 where the reference returns (0, 0) without fitting (empty image, window
+ * truncated by the border).                                                                         */
+int pmi_peak_fit(const double *rois, int64_t n, int box, double *popt, int32_t *status);
+int pmi_rcc_shifts(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
+                   const int32_t *pairs, int64_t n_pairs, double *shift_yx, int32_t *fit_status);
+
 /* ---- timing hooks for bench.py (HIP events on the given stream) ------- */
 int pmi_event_create(void **event);
 int pmi_event_record(void *event, void *stream);

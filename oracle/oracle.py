@@ -49,6 +49,8 @@ def lib():
         L.orc_gaussmle.restype = i32
         L.orc_gaussmle_closeness.argtypes = [p, i64, i32, f64, i32, i32, p, p, p, p, p, i32]
         L.orc_gaussmle_closeness.restype = i32
+        L.orc_peak_fit.argtypes = [p, i32, p, p]
+        L.orc_peak_fit.restype = i32
         L.orc_initial_parameters.argtypes = [p, i64, i32, p]
         L.orc_initial_parameters.restype = i32
         L.orc_unit_vectors.argtypes = [i32, p, p]
@@ -164,6 +166,28 @@ def gaussmle_closeness(spots, eps, max_it, method="sigmaxy", threads=1):
     if rc != 0:
         raise ValueError(f"orc_gaussmle_closeness failed ({rc})")
     return thetas, crlbs, ll, it, close
+
+
+def peak_fit(roi):
+    """Bounded Gaussian fit of a (box, box) float64 correlation window, the reference's curve_fit call
+    (picasso/imageprocess.py:121-141) -> popt (a, xc, yc, s, b), scipy's termination status, nfev."""
+    roi = np.ascontiguousarray(roi, np.float64)
+    if roi.min() < 0:
+        raise ValueError("Initial guess is outside of provided bounds")      # what curve_fit raises for b0 < 0
+    popt = np.zeros(5, np.float64)
+    nfev = ctypes.c_int(0)
+    status = lib().orc_peak_fit(_ptr(roi), int(roi.shape[0]), _ptr(popt), ctypes.byref(nfev))
+    return popt, int(status), int(nfev.value)
+
+
+def image_shift_from_window(win, box, y_max_, x_max_, Y_, X_, Y, X):
+    """picasso/imageprocess.py:109-159 from the fit window on: -> (-yc, -xc)."""
+    popt, _, _ = peak_fit(win)
+    xc = popt[1] + X_ + x_max_
+    yc = popt[2] + Y_ + y_max_
+    xc -= np.floor(X / 2)
+    yc -= np.floor(Y / 2)
+    return -yc, -xc
 
 
 def initial_parameters(spots):

@@ -80,6 +80,8 @@ SYMBOLS = {
     "pmi_xcorr": (_i32, [_p, _p, _i64, _i64, _p]),
     "pmi_rcc_pairs": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p]),
     "pmi_rcc_pair_list": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _i64, _p, _p, _p, _p]),
+    "pmi_peak_fit": (_i32, [_p, _i64, _i32, _p, _p]),
+    "pmi_rcc_shifts": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _i64, _p, _p]),
     "pmi_comm_unique_id": (_i32, [_p]),
     "pmi_comm_init": (_i32, [_p, _i32, _i32, _p]),
     "pmi_comm_info": (_i32, [_p, _p, _p]),

@@ -293,6 +293,43 @@ def rcc_pairs_arrays(segments, roi, box: int, pairs=None):
     return peak, valid, rois, (int(crop[0]), int(crop[1]))
 
 
+def peak_fit_arrays(rois):
+    """(n, box, box) float64 correlation windows -> popt (n, 5) = a, xc, yc, s, b and the termination status of the
+    bounded Gaussian fit (pmi_peak_fit; scipy's curve_fit in the reference, picasso/imageprocess.py:121-141)."""
+    _lib.require_gpu()
+    rois = np.ascontiguousarray(rois, np.float64)
+    if rois.ndim != 3 or rois.shape[1] != rois.shape[2]:
+        raise ValueError("rois must have shape (n, box, box)")
+    n, box, _ = rois.shape
+    popt = np.zeros((n, 5), np.float64)
+    status = np.zeros(n, np.int32)
+    with _lib.lock():
+        rc = _lib.load().pmi_peak_fit(_lib.ptr(rois), n, int(box), _lib.ptr(popt), _lib.ptr(status))
+    _lib.check(rc, "pmi_peak_fit")
+    return popt, status
+
+
+def rcc_shifts_arrays(segments, roi, box: int, pairs=None):
+    """get_image_shift (picasso/imageprocess.py:53-161) for pairs (i, j) of the segment images (all i < j when
+    `pairs` is None), entirely on the device -> shifts (n_pairs, 2) = (-yc, -xc), fit status (n_pairs)."""
+    _lib.require_gpu()
+    seg = np.ascontiguousarray(segments, np.float64)
+    if seg.ndim != 3:
+        raise ValueError("segments must have shape (n, Y, X)")
+    n, Y, X = seg.shape
+    if pairs is None:
+        pairs = [(i, j) for i in range(n - 1) for j in range(i + 1, n)]
+    pairs = np.ascontiguousarray(np.asarray(pairs, np.int32).reshape(-1, 2))
+    n_pairs = len(pairs)
+    shifts = np.zeros((n_pairs, 2), np.float64)
+    status = np.zeros(n_pairs, np.int32)
+    with _lib.lock():
+        rc = _lib.load().pmi_rcc_shifts(_lib.ptr(seg), n, Y, X, int(roi) if roi is not None else 0, int(box), _lib.ptr(pairs),
+                                        n_pairs, _lib.ptr(shifts), _lib.ptr(status))
+    _lib.check(rc, "pmi_rcc_shifts")
+    return shifts, status
+
+
 class DeviceMovie:
     """A movie resident in HBM (pmi_malloc), for repeated calls without H2D."""
 

@@ -22,6 +22,8 @@
 #pragma clang fp contract(off)
 
 namespace pmi {
+int rcc_fit_peaks(const double *d_rois, const int32_t *h_peaks3, int64_t n_pairs, int box, int64_t Y, int64_t X, int64_t Y_,
+                  int64_t X_, double *h_shift_yx, int32_t *h_status);      // peakfit.hip
 namespace xc {
 
 struct Plans { hipfftHandle fwd, inv; };
@@ -238,6 +240,27 @@ int pmi_rcc_pair_list(const double *segments, int64_t n_seg, int64_t Y, int64_t 
         for (int k = 0; k < box * box; k++) fit_rois[p * box * box + k] = 0.0;
     }
     return PMI_OK;
+}
+
+// all of get_image_shift (imageprocess.py:53-161) for a list of pairs: correlation, crop, peak, window AND the bounded
+// Gaussian fit of the window (csrc/peakfit.hip), -> shift_yx (n_pairs, 2) = (-yc, -xc)
+int pmi_rcc_shifts(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
+                   const int32_t *pairs, int64_t n_pairs, double *shift_yx, int32_t *fit_status)
+{
+    using namespace pmi;
+    if (!shift_yx || !fit_status) { set_error("null pointer"); return PMI_ERR_ARG; }
+    std::vector<int32_t> peak((size_t)std::max<int64_t>(n_pairs, 1) * 2), valid((size_t)std::max<int64_t>(n_pairs, 1));
+    std::vector<double> rois((size_t)std::max<int64_t>(n_pairs, 1) * box * box);
+    int32_t crop[2] = {0, 0};
+    int rc = pmi_rcc_pair_list(segments, n_seg, Y, X, roi, box, pairs, n_pairs, peak.data(), valid.data(), rois.data(), crop);
+    if (rc != PMI_OK || n_pairs == 0) return rc;
+    // the windows are still resident where pmi_rcc_pair_list left them (SCR_STAGE_D)
+    void *d_out = nullptr;
+    if ((rc = scratch(SCR_STAGE_D, 1, &d_out)) != PMI_OK) return rc;
+    std::vector<int32_t> pk3((size_t)n_pairs * 3);
+    for (int64_t p = 0; p < n_pairs; p++) { pk3[(size_t)p * 3] = peak[(size_t)p * 2]; pk3[(size_t)p * 3 + 1] = peak[(size_t)p * 2 + 1]; pk3[(size_t)p * 3 + 2] = valid[(size_t)p]; }
+    // empty-image pairs were zeroed on the host only: their `valid` is -1 and the kernel does not read their windows
+    return rcc_fit_peaks((const double *)d_out, pk3.data(), n_pairs, box, Y, X, crop[0], crop[1], shift_yx, fit_status);
 }
 
 int pmi_rcc_pairs(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,

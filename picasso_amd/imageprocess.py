@@ -1,12 +1,12 @@
 """picasso.imageprocess surface for RCC drift correction (picasso/imageprocess.py:27-217):
-``xcorr``, ``get_image_shift``, ``rcc``.  The correlations, the centre crop, the peak search and
-the fit window come from csrc/xcorr.hip (hipFFT, float64); the 5-parameter peak fit of 25 numbers
-per pair is the reference's own scipy ``curve_fit`` call on the host.
+``xcorr``, ``get_image_shift``, ``rcc``.  The correlations, the centre crop, the peak search, the fit window
+(csrc/xcorr.hip, hipFFT, float64) and the bounded Gaussian fit of the window — the reference's scipy
+``curve_fit`` call, restated as a Trust Region Reflective solver with one thread per pair (csrc/peakfit.hip) —
+all run on the device.
 """
 from __future__ import annotations
 
 import numpy as np
-from scipy.optimize import curve_fit
 
 from . import backend, lib
 
@@ -16,38 +16,15 @@ def xcorr(imageA, imageB):
     return backend.xcorr_array(imageA, imageB)
 
 
-def _flat_2d_gaussian(coords, a, xc, yc, s, b):
-    x, y = coords
-    A = a * np.exp(-0.5 * ((x - xc) ** 2 + (y - yc) ** 2) / s**2) + b
-    return A.flatten()
-
-
-def _fit_peak(fit_roi, box, y_max_, x_max_, Y_, X_, Y, X):
-    """imageprocess.py:109-159 from the fit window on: -> (-yc, -xc)."""
-    fit_X = int(box / 2)
-    y, x = np.mgrid[-fit_X:fit_X + 1, -fit_X:fit_X + 1]
-    p0 = [fit_roi.max(), 0, 0, 1, fit_roi.min()]
-    bounds = ([0, -np.inf, -np.inf, 0, 0], [np.inf, np.inf, np.inf, np.inf, np.inf])
-    popt, _ = curve_fit(_flat_2d_gaussian, (x, y), fit_roi.flatten(), p0=p0, bounds=bounds)
-    xc = popt[1] + X_ + x_max_
-    yc = popt[2] + Y_ + y_max_
-    xc -= np.floor(X / 2)
-    yc -= np.floor(Y / 2)
-    return -yc, -xc
-
-
 def _shifts_of_pairs(segments, box, roi, pairs=None):
-    """(-yc, -xc) of every pair (all i < j when `pairs` is None)."""
+    """(-yc, -xc) of every pair (all i < j when `pairs` is None).  Pairs with an empty image (imageprocess.py:85-86)
+    or a fit window truncated by the border (:118-119) give (0, 0), as in the reference."""
     segments = np.asarray(segments)
-    _, Y, X = segments.shape
-    peak, valid, rois, (Y_, X_) = backend.rcc_pairs_arrays(segments, roi, box, pairs)
-    out = []
-    for p in range(len(valid)):
-        if valid[p] == 1:
-            out.append(_fit_peak(rois[p], box, int(peak[p, 0]), int(peak[p, 1]), Y_, X_, Y, X))
-        else:
-            out.append((0, 0))          # empty image (imageprocess.py:85-86) or truncated fit window (:118-119)
-    return out
+    shifts, status = backend.rcc_shifts_arrays(segments, roi, box, pairs)
+    if np.any(status == -2):
+        # curve_fit refuses a start value outside its bounds (b = window minimum < 0)
+        raise ValueError("Initial guess is outside of provided bounds")
+    return [(float(sy), float(sx)) if st != -1 else (0, 0) for (sy, sx), st in zip(shifts, status)]
 
 
 def get_image_shift(imageA, imageB, box: int, roi: int | None = None, display: bool = False):

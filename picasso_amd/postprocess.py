@@ -34,8 +34,20 @@ def segment(locs: pd.DataFrame, info, segmentation: int, kwargs: dict = {}, call
     frame = locs["frame"]
     if callback is not None:
         callback(0)
+    # A localization table is ordered by frame (picasso/gaussmle.py:1036): a segment is then a row range, found by
+    # bisection, and only the columns a render reads are taken — instead of a boolean mask over every row and a copy
+    # of all 17 columns per segment (4e7 rows x 25 segments on one rank of config 4: seconds).
+    cols = [c for c in ("x", "y", "lpx", "lpy") if c in locs.columns]
+    fr = frame.to_numpy()
+    ordered = len(fr) == 0 or bool(np.all(fr[1:] >= fr[:-1]))
+    views = {c: locs[c].to_numpy() for c in cols} if ordered else None
     for i, (lo, hi) in enumerate(zip(bounds[:-1], bounds[1:])):
-        stack[i] = render.render(locs[(frame >= lo) & (frame < hi)], info, **kwargs)[1]
+        if ordered:
+            a, b = np.searchsorted(fr, lo, side="left"), np.searchsorted(fr, hi, side="left")
+            part = pd.DataFrame({c: views[c][a:b] for c in cols}, copy=False)
+        else:
+            part = locs[(frame >= lo) & (frame < hi)]
+        stack[i] = render.render(part, info, **kwargs)[1]
         if callback is not None:
             callback(i + 1)
     return bounds, stack
@@ -75,7 +87,7 @@ def undrift(locs: pd.DataFrame, info, segmentation: int, display: bool = True, s
             rcc_callback=None):
     """RCC drift correction (postprocess.py:2900-2961) -> (drift DataFrame, undrifted copy of locs).
     ``display`` (a matplotlib plot in the reference) is ignored."""
-    locs = locs.copy()
+    locs = locs.copy(deep=False)          # the drift replaces the x / y columns of the copy; the others are shared
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", DeprecationWarning)       # render()'s oversampling notice, as in the reference call
         bounds, stack = segment(locs, info, segmentation, dict(_SEGMENT_RENDER), segmentation_callback)

@@ -79,10 +79,10 @@ def test_allgather_table_world2(counts):
 # RCC undrift over two frame shards == single-process undrift (same pair function)
 # ---------------------------------------------------------------------------
 def _cpu_pair_shifts(segments, box, roi, pairs=None):
-    """The reference's get_image_shift per pair with numpy's FFT (the oracle restatement) and the
-    backend's own host-side peak fit -- stands in for the GPU correlation in the gloo tests."""
+    """The reference's get_image_shift per pair with numpy's FFT and the bounded Gaussian fit of the oracle
+    (its restatement of scipy's TRF, pinned against scipy in test_oracle_golden.py) -- stands in for the GPU
+    correlation and fit in the gloo tests."""
     from oracle import oracle as orc
-    from picasso_amd import imageprocess
     n, Y, X = segments.shape
     if pairs is None:
         pairs = [(i, j) for i in range(n - 1) for j in range(i + 1, n)]
@@ -93,7 +93,7 @@ def _cpu_pair_shifts(segments, box, roi, pairs=None):
             out.append((0, 0))
         else:
             ym, xm, Y_, X_, win = w
-            out.append(imageprocess._fit_peak(win, box, ym, xm, Y_, X_, Y, X))
+            out.append(orc.image_shift_from_window(win, box, ym, xm, Y_, X_, Y, X))
     return out
 
 

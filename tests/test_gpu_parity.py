@@ -627,3 +627,48 @@ def test_fused_pipeline_capacity_overflow_is_clean(be, lq):
     for c in roomy:
         assert np.array_equal(roomy[c], retried[c], equal_nan=True), c
     dm.free()
+
+
+def test_peak_fit_device_vs_oracle(be, orc):
+    """The bounded Gaussian fit of the correlation window (scipy curve_fit in the reference,
+    picasso/imageprocess.py:129-135) on the device against the oracle's restatement, which is pinned against
+    scipy itself in test_oracle_golden.py: centres within 1e-7 px, same termination status."""
+    rng = np.random.default_rng(3)
+    for box in (5, 7, 9):
+        h = box // 2
+        y, x = np.mgrid[-h:h + 1, -h:h + 1]
+        rois = []
+        for t in range(200):
+            a = rng.uniform(5, 500); xc, yc = rng.uniform(-0.7, 0.7, 2); s = rng.uniform(0.6, 2.5)
+            b = rng.uniform(0, 50) if t % 3 else 0.0
+            roi = a * np.exp(-0.5 * ((x - xc) ** 2 + (y - yc) ** 2) / s ** 2) + b + rng.normal(0, 0.02 * a, (box, box))
+            rois.append(np.abs(roi) if t % 2 else np.maximum(roi, 0.0))
+        rois = np.array(rois)
+        popt, status = be.peak_fit_arrays(rois)
+        for k in range(len(rois)):
+            o, ost, _ = orc.peak_fit(rois[k])
+            assert status[k] == ost, (box, k, status[k], ost)
+            assert np.max(np.abs(popt[k, 1:3] - o[1:3])) < 1e-7 and abs(popt[k, 3] - o[3]) < 1e-6 * max(1.0, o[3])
+    neg = rois[:2].copy(); neg[1] -= neg[1].max()
+    popt, status = be.peak_fit_arrays(neg)
+    assert status[0] > 0 and status[1] == -2             # a negative window minimum: curve_fit raises, so does the wrapper
+
+
+def test_rcc_shifts_on_device_match_reference_goldens(be):
+    """get_image_shift end to end on the device (correlation, crop, peak, window, fit) against the shifts the
+    reference computed (tests/golden/undrift_rcc.npz): 1e-6 px."""
+    from picasso_amd import imageprocess
+    g = golden("undrift_rcc")
+    seg = g["segments"]
+    shifts, status = be.rcc_shifts_arrays(seg, 32, 5)
+    p = 0
+    for i in range(len(seg) - 1):
+        for j in range(i + 1, len(seg)):
+            assert status[p] > 0
+            assert abs(shifts[p, 0] - g["raw_shift_y"][i, j]) < 1e-6 and abs(shifts[p, 1] - g["raw_shift_x"][i, j]) < 1e-6
+            p += 1
+    sy, sx = imageprocess.rcc(list(seg), 32)
+    assert np.max(np.abs(sy - g["shift_y"])) < 1e-6 and np.max(np.abs(sx - g["shift_x"])) < 1e-6
+    empty = seg.copy(); empty[1] = 0
+    shifts, status = be.rcc_shifts_arrays(empty, 32, 5, [(0, 1), (0, 2)])
+    assert status[0] == -1 and np.all(shifts[0] == 0) and status[1] > 0

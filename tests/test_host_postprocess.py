@@ -35,6 +35,18 @@ def cpu_device_calls(monkeypatch):
                 valid[p] = 1; rois[p] = w[4]
         return peak, valid, rois, crop
 
+    def rcc_shifts_arrays(segments, roi, box, pairs=None):
+        segments = np.asarray(segments, np.float64)
+        _, Y, X = segments.shape
+        peak, valid, rois, (Y_, X_) = rcc_pairs_arrays(segments, roi, box, pairs)
+        shifts = np.zeros((len(valid), 2)); status = np.full(len(valid), -1, np.int32)
+        for p in range(len(valid)):
+            if valid[p] == 1:
+                shifts[p] = orc.image_shift_from_window(rois[p], box, int(peak[p, 0]), int(peak[p, 1]), Y_, X_, Y, X)
+                status[p] = 2
+        return shifts, status
+
+    monkeypatch.setattr(backend, "rcc_shifts_arrays", rcc_shifts_arrays)
     monkeypatch.setattr(backend, "render_arrays", render_arrays)
     monkeypatch.setattr(backend, "rcc_pairs_arrays", rcc_pairs_arrays)
     monkeypatch.setattr(backend, "xcorr_array", lambda a, b: orc.xcorr(a, b))

@@ -238,3 +238,45 @@ def test_oracle_net_gradient_standalone(tag, box):
     assert np.array_equal(ux[keep], g[f"{tag}_ux"][keep]) and np.array_equal(uy[keep], g[f"{tag}_uy"][keep])
     with pytest.raises(ValueError):
         orc.net_gradient(frame, [31 - box // 2], [10], box, uy, ux)
+
+
+# ---------------------------------------------------------------------------
+# RCC peak fit: the oracle's Trust Region Reflective restatement against scipy itself
+# ---------------------------------------------------------------------------
+def _peak_windows(n, box, seed):
+    rng = np.random.default_rng(seed)
+    h = box // 2
+    y, x = np.mgrid[-h:h + 1, -h:h + 1]
+    out = []
+    for t in range(n):
+        a = rng.uniform(5, 500); xc, yc = rng.uniform(-0.7, 0.7, 2); s = rng.uniform(0.6, 2.5)
+        b = rng.uniform(0, 50) if t % 3 else 0.0                      # every third window: background on its bound
+        roi = a * np.exp(-0.5 * ((x - xc) ** 2 + (y - yc) ** 2) / s ** 2) + b + rng.normal(0, 0.02 * a, (box, box))
+        out.append(np.abs(roi) if t % 2 else np.maximum(roi, 0.0))
+    return np.array(out)
+
+
+@pytest.mark.parametrize("box", [5, 7])
+def test_peak_fit_matches_scipy_curve_fit(box):
+    """orc_peak_fit restates scipy.optimize.curve_fit(bounds=...) = least_squares(method="trf") — third-party
+    arithmetic (scipy 1.15.3), call site picasso/imageprocess.py:129-135.  Same start, same bounds, same
+    tolerances: the fitted centre agrees with scipy's to 1e-7 px on every window, the termination status too."""
+    from scipy.optimize import curve_fit
+    from oracle import oracle as orc
+    h = box // 2
+    y, x = np.mgrid[-h:h + 1, -h:h + 1]
+
+    def flat(coords, a, xc, yc, s, b):
+        xx, yy = coords
+        return (a * np.exp(-0.5 * ((xx - xc) ** 2 + (yy - yc) ** 2) / s ** 2) + b).flatten()
+
+    rois = _peak_windows(120, box, 7 + box)
+    for roi in rois:
+        popt, _ = curve_fit(flat, (x, y), roi.flatten(), p0=[roi.max(), 0, 0, 1, roi.min()],
+                            bounds=([0, -np.inf, -np.inf, 0, 0], [np.inf] * 5))
+        got, status, nfev = orc.peak_fit(roi)
+        assert status in (1, 2, 3, 4) and nfev < 500
+        assert np.max(np.abs(got[1:3] - popt[1:3])) < 1e-7
+        assert abs(got[3] - popt[3]) < 1e-6 * max(1.0, popt[3]) and abs(got[0] - popt[0]) < 1e-6 * popt[0]
+    with pytest.raises(ValueError, match="outside of provided bounds"):
+        orc.peak_fit(rois[0] - rois[0].max())                         # curve_fit refuses b0 < 0

@@ -103,13 +103,32 @@ def main():
         locs = pd.DataFrame({name: table[c, :n].cpu().numpy().view(dt_) for c, (name, dt_) in enumerate(backend.LOC_COLUMNS)})
         t_d2h = time.perf_counter() - t0
         info = [{"Frames": F, "Height": H, "Width": W}, {"Pixelsize": 130}]
+        from picasso_amd import imageprocess
+        stages = {}
+
+        def timed(name, fn):
+            def wrapper(*a, **k):
+                t = time.perf_counter()
+                out = fn(*a, **k)
+                stages[name] = stages.get(name, 0.0) + time.perf_counter() - t
+                return out
+            return wrapper
+        postprocess.segment = timed("segment_renders_s", postprocess.segment)
+        imageprocess.rcc = timed("rcc_s", imageprocess.rcc)
+        postprocess.apply_drift = timed("apply_drift_s", postprocess.apply_drift)
+        t0 = time.perf_counter()
+        drift, und = postprocess.undrift(locs, info, args.segmentation, display=False)
+        t_first = time.perf_counter() - t0       # includes rocFFT's run-time compilation of the 2048 x 2048 float64 plans (once per process)
+        first_stages = dict(stages)
+        stages.clear()
         t0 = time.perf_counter()
         drift, und = postprocess.undrift(locs, info, args.segmentation, display=False)
         t_u = time.perf_counter() - t0
         d = np.asarray(drift[["x", "y"]] if hasattr(drift, "columns") else np.stack([drift["x"], drift["y"]], 1))
         print(json.dumps({"undrift": {"segmentation": args.segmentation, "segments": F // args.segmentation,
                                       "pairs": (F // args.segmentation) * (F // args.segmentation - 1) // 2,
-                                      "table_d2h_s": t_d2h, "undrift_s": t_u, "max_abs_drift_px": float(np.abs(d).max()),
+                                      "table_d2h_s": t_d2h, "undrift_s": t_u, "stages": stages,
+                                      "first_call_s": t_first, "first_call_stages": first_stages, "max_abs_drift_px": float(np.abs(d).max()),
                                       "rows": len(und), "columns": names[:3]}}), flush=True)
 
 

@@ -1,15 +1,15 @@
-// identify_fast.hip — the uint16 fast path of identify: a register-pipelined,
+// identify_fast.hip — the 16-bit fast path of identify (uint16 / int16 / uint8 movies): a register-pipelined,
 // packed-u16 first-argmax scan streaming rows straight from HBM (no LDS staging).
 //
 // Same semantics as identify_scan_kernel in identify.hip (picasso/localize.py:97-134
 // _local_maxima, :202-244 _net_gradient, :288 threshold); only the schedule differs:
 //
-//   * one wavefront owns a band of RB rows x 512 columns of one frame (frames at most 256 / 128 pixels wide:
-//     two / four consecutive bands side by side, template parameter P); lane l holds
-//     8 consecutive pixels of the current row as four packed u16x2 registers (one
-//     16-byte global load per row) plus the 4 pixels on either side, taken from the
-//     neighbouring lanes' registers by DPP wave_shr/wave_shl (lanes 0 and 63 load
-//     theirs with one masked 8-byte load);
+//   * persistent waves (one per workgroup, a few per CU): a wave takes UNITS of up to 256 rows x 512 columns of one
+//     frame, `upw` of them in sequence (frames at most 256 / 128 / 64 pixels wide: 2 / 4 / 8 units side by side,
+//     template parameter P); lane l holds 8 consecutive pixels of the current row as four packed u16x2 registers
+//     (one 16-byte buffer load per row, D rows in flight ahead of the pipeline) plus the 4 pixels on either side,
+//     taken from the neighbouring lanes' registers by DPP wave_shr/wave_shl (lanes 0 and 63 load theirs with one
+//     masked 8-byte load);
 //   * horizontal: Hrow = maximum of the 2h+1 pixels around each pixel, as v_pk_max_u16 on aligned / odd
 //     pixel pairs (odd pairs by v_alignbit), window by doubling;
 //   * vertical: U[r] = max(Hrow[r-h..r]) from a register ring; W[r'] = max(U[r'+h], U[r']) is the maximum of the

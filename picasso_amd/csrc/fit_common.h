@@ -18,22 +18,51 @@ constexpr int FIT_MAXPIX = PMI_MAX_BOX * PMI_MAX_BOX;
 // counts to photons: picasso/localize.py:1112 divides by Gain).  Markstein: with r = RN(1/g),
 // q = RN(x r), e = x - q g (exact in an FMA), RN(q + e r) is the correctly rounded quotient, barring
 // overflow / underflow — values outside a safe range take the real division.
-struct ConstDiv { float g, r; int fast; };
+struct ConstDiv { float g, r; int fast; };      // fast: 0 = always the real division, 1 = Markstein, 2 = g is 1 (x / 1 = x)
 inline ConstDiv make_const_div(float g)
 {
     ConstDiv c;
     c.g = g;
     c.r = (float)(1.0 / (double)g);                  // correctly rounded: double has more than 2*24+2 bits
     c.fast = (g == g) && fabsf(g) > 1e-15f && fabsf(g) < 1e15f;
+    if (g == 1.0f) c.fast = 2;
     return c;
 }
 __device__ __forceinline__ float div_const(float x, const ConstDiv &c)
 {
+    if (c.fast == 2) return x;
     const float ax = fabsf(x);
     if (!c.fast || !((ax > 1e-15f && ax < 1e15f) || x == 0.0f)) return x / c.g;
     const float q = x * c.r;
     const float e = __builtin_fmaf(-q, c.g, x);
     return __builtin_fmaf(e, c.r, q);
+}
+// The same for the B values a lane holds, with ONE branch: the range test is accumulated over the row (largest
+// magnitude, smallest non-zero magnitude, on the bit patterns) and the real divisions run for the whole row when any
+// value fails it.  A zero is safe in the short form (q = e = 0 with the sign of x / g); a NaN gives NaN either way.
+template <int B> __device__ __forceinline__ void div_const_row(float (&v)[B], const ConstDiv &c)
+{
+    if (c.fast == 2) return;
+    unsigned hi = 0u, lo = 0xffffffffu;
+#pragma unroll
+    for (int i = 0; i < B; i++) {
+        const unsigned u = __float_as_uint(v[i]) & 0x7fffffffu;
+        hi = u > hi ? u : hi;
+        const unsigned w = u - 1u;                      // zero wraps to the top: not "small"
+        lo = w < lo ? w : lo;
+    }
+    // 1e15f = 0x58635fa9, 1e-15f = 0x26901d7d
+    if (c.fast && hi < 0x58635fa9u && lo >= 0x26901d7du) {
+#pragma unroll
+        for (int i = 0; i < B; i++) {
+            const float q = v[i] * c.r;
+            const float e = __builtin_fmaf(-q, c.g, v[i]);
+            v[i] = __builtin_fmaf(e, c.r, q);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < B; i++) v[i] = v[i] / c.g;
+    }
 }
 
 struct FitParams {

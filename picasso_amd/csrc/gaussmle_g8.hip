@@ -166,7 +166,8 @@ __device__ __forceinline__ void load_row(const FitParams &p, int64_t sidx, int j
             }
 #pragma unroll
             for (int i = 0; i < B; i++)      // localize.py:1112: float32 sub, mul, div in this order
-                d[i] = div_const((raw[i] - p.baseline) * p.sensitivity, p.gdiv);
+                d[i] = (raw[i] - p.baseline) * p.sensitivity;
+            div_const_row<B>(d, p.gdiv);
         } else {
             const float *sp = p.spots + sidx * (B * B) + j * B;
 #pragma unroll
@@ -223,21 +224,28 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
     __threadfence_block();
 
     const float N_ = th[2], bg = th[3];
-    const float NEy = N_ * ty.E;
+    // (a lane beyond the last row holds a neighbour group's boundary in ty: its sums are never read, but its model
+    // must not trip the guard test below)
+    const float NEy = rowok ? N_ * ty.E : 0.f;
     f32x2 pA_E = {0.f, 0.f}, pS_A2 = {0.f, 0.f}, pS2_1 = {0.f, 0.f};      // cf * (Ax, Ex), (Sx, A2x), (S2x, 1)
     f32x2 qA_E = {0.f, 0.f}, qS_1 = {0.f, 0.f};                           // df * (Ax^2, Ex^2), (Sx^2, 1)
     float a_dSE = 0.f;
+    // The reference guards every pixel (gaussmle.py:831-838: cf = df = 0 unless model > 10e-3, both capped at 10e4).
+    // On real data no pixel of a wave ever needs either, so the sums are taken WITHOUT the guards (three instructions
+    // less per pixel) while one compare and one v_max3 per pixel watch for the need; if any lane saw it, the whole
+    // wave takes the sums again with the guards.  Where no guard acts the two forms are the same operations.
+    bool guard = false;
+    float top = 0.f;
 #pragma unroll
     for (int i = 0; i < B; i++) {
         const float4 *c = reinterpret_cast<const float4 *>(cols + i * 12);
         const float4 c0 = c[0], c1 = c[1], c2 = c[2];
-        const float model = NEy * c0.y + bg;
+        const float model = __builtin_fmaf(NEy, c0.y, bg);
         const float r = rcp_f32(model);
-        const float dr = d[i] * r;
-        const bool ok = model > 10e-3f;             // gaussmle.py:831: otherwise cf = df = 0
-        // plain fminf: a NaN can only enter through a NaN pixel, and then theta is NaN from g8_init on
-        const float cf = ok ? fminf(dr - 1.f, 10e4f) : 0.f;
-        const float df = ok ? fminf(dr * r, 10e4f) : 0.f;
+        const float cf = __builtin_fmaf(d[i], r, -1.f);
+        const float df = (d[i] * r) * r;
+        guard = guard || !(model > 10e-3f);          // also true for a NaN model
+        top = fmaxf(top, fmaxf(cf, df));
         const f32x2 cf2 = {cf, cf}, df2 = {df, df};
         pA_E = cf2 * (f32x2){c0.x, c0.y} + pA_E;
         pS_A2 = cf2 * (f32x2){c0.z, c0.w} + pS_A2;
@@ -245,6 +253,33 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
         qA_E = df2 * (f32x2){c1.z, c1.w} + qA_E;
         qS_1 = df2 * (f32x2){c2.x, c2.y} + qS_1;
         if (NP == 5) a_dSE += df * c2.z;
+    }
+    // (the sums are pinned here: left alone, the compiler sinks them behind the branch and keeps every cf, df and
+    // column value alive across it — 126 registers instead of 72)
+    asm volatile("" : "+v"(pA_E), "+v"(pS_A2), "+v"(pS2_1), "+v"(qA_E), "+v"(qS_1), "+v"(a_dSE));
+    if (__any(guard || !(top <= 10e4f))) {
+        asm volatile("" ::: "memory");      // read the columns again: keeping 21 registers of them alive for this path costs occupancy
+        pA_E = (f32x2){0.f, 0.f}; pS_A2 = (f32x2){0.f, 0.f}; pS2_1 = (f32x2){0.f, 0.f};
+        qA_E = (f32x2){0.f, 0.f}; qS_1 = (f32x2){0.f, 0.f};
+        a_dSE = 0.f;
+#pragma unroll
+        for (int i = 0; i < B; i++) {
+            const float4 *c = reinterpret_cast<const float4 *>(cols + i * 12);
+            const float4 c0 = c[0], c1 = c[1], c2 = c[2];
+            const float model = __builtin_fmaf(NEy, c0.y, bg);
+            const float r = rcp_f32(model);
+            const bool ok = model > 10e-3f;             // gaussmle.py:831: otherwise cf = df = 0
+            // plain fminf: a NaN can only enter through a NaN pixel, and then theta is NaN from g8_init on
+            const float cf = ok ? fminf(__builtin_fmaf(d[i], r, -1.f), 10e4f) : 0.f;
+            const float df = ok ? fminf((d[i] * r) * r, 10e4f) : 0.f;
+            const f32x2 cf2 = {cf, cf}, df2 = {df, df};
+            pA_E = cf2 * (f32x2){c0.x, c0.y} + pA_E;
+            pS_A2 = cf2 * (f32x2){c0.z, c0.w} + pS_A2;
+            pS2_1 = cf2 * (f32x2){c1.x, c1.y} + pS2_1;
+            qA_E = df2 * (f32x2){c1.z, c1.w} + qA_E;
+            qS_1 = df2 * (f32x2){c2.x, c2.y} + qS_1;
+            if (NP == 5) a_dSE += df * c2.z;
+        }
     }
     const float a_cA = pA_E.x, a_cE = pA_E.y, a_cS = pS_A2.x, a_cA2 = pS_A2.y, a_cS2 = pS2_1.x, a_c = pS2_1.y;
     const float a_dA = qA_E.x, a_dE = qA_E.y, a_dS = qS_1.x, a_d = qS_1.y;
@@ -264,11 +299,7 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
                  - (NEy * NEy * a_dS + 2.f * NEy * NSy * a_dSE + NSy * NSy * a_dE);
         num[5] = 0.f; den[5] = 0.f;
     }
-    if (!rowok) {
-#pragma unroll
-        for (int l = 0; l < 6; l++) { num[l] = 0.f; den[l] = 0.f; }
-    }
-    {
+    {   // lanes beyond the last row write their slot too; the sum below reads the B rows only
         float4 *ro = reinterpret_cast<float4 *>(red + j * 12);
         ro[0] = make_float4(num[0], den[0], num[1], den[1]);
         ro[1] = make_float4(num[2], den[2], num[3], den[3]);
@@ -280,7 +311,7 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
     const int l = j < 6 ? j : 5;
     f32x2 nd = {0.f, 0.f};
 #pragma unroll
-    for (int r = 0; r < GS; r++) {
+    for (int r = 0; r < B; r++) {
         const float2 v = *reinterpret_cast<const float2 *>(red + r * 12 + 2 * l);
         nd = nd + (f32x2){v.x, v.y};
     }

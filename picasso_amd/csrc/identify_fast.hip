@@ -130,6 +130,7 @@ struct FastParams {
     int box;
     double min_ng;
     float filt_alpha, filt_t;  // floor filter: a maximum v can only reach min_ng if v > alpha * (minimum above it) + t; t < 0: off
+    float filt_kr, filt_kc, filt_krc;   // the same for stencils that wrap through index -1 (row, column, both): v > k * cfloor + t
     int filt_slack;            // counts by which later pixels may undercut the minimum seen so far before a chunk is run again
     int dbg;                   // PMI_IDENTIFY_DBG: 1 = skip the exact net gradient, 2 = skip the record append, 4 = no floor filter (timing only)
 };
@@ -150,7 +151,7 @@ struct FastParams {
 #define FAST_D_H6 3
 #endif
 #ifndef FAST_ROUND
-#define FAST_ROUND 32         // candidates per in-loop round of exact net gradients (lanes busy vs. rows still in the Infinity Cache)
+#define FAST_ROUND 64         // candidates per in-loop round of exact net gradients (lanes busy vs. rows still in the Infinity Cache)
 #endif
 #ifndef FAST_MIN_WAVES
 #define FAST_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for
@@ -491,7 +492,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
         // lanes whose stencils reach columns no lane of this wave holds take no floor
         // (the 4 or 8 pixels the edge lanes hold from beyond the wave cover a stencil's reach of H + 1 for every box but 9 and 17)
         constexpr bool EDGE_COVERED = (H <= 4 ? 4 : 8) >= H + 1;
-        const bool no_floor = wrapcol || (P == 1 && !EDGE_COVERED && ((seg > 0 && lane < NWL) || (seg + 1 < p.segs && lane >= 64 - NWL)));
+        const bool no_floor = P == 1 && !EDGE_COVERED && ((seg > 0 && lane < NWL) || (seg + 1 < p.segs && lane >= 64 - NWL));
 
         // per-lane byte offsets inside a row (32-bit) + a wave-uniform row base: the loads use
         // SGPR-base + VGPR-offset addressing, no 64-bit vector address arithmetic per row.
@@ -591,6 +592,13 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             int tail_lf = tail, rd_lf = clo;                  // ring state before, and first row of, the latest flush group
             u32 cmin = 0xffffffffu;                           // minimum of every pixel this lane streamed in the chunk (both halves)
             const float beta = fmaf(1.0f - p.filt_alpha, (float)cfloor, p.filt_t);
+            // A maximum in row H (column H) has the first row (column) of its neighbourhood at index -1, i.e. in the LAST
+            // row (column) of the frame (numba wraps; localize.py:233-243).  Those pixels are not among the ones the
+            // running minimum or the cfloor check see — but they carry negative weights only (N_wrap in total) and are
+            // >= 0, so they can be dropped from the bound: with every OTHER pixel >= cfloor,
+            //     ng <= P_box (v - cfloor) + cfloor N_wrap,   i.e.   v > (1 - N_wrap / P_box) cfloor + t.
+            const float beta_r = fmaf(p.filt_kr, (float)cfloor, p.filt_t), beta_c = fmaf(p.filt_kc, (float)cfloor, p.filt_t),
+                        beta_rc = fmaf(p.filt_krc, (float)cfloor, p.filt_t);
 
             RowRegs pf[D];
 #pragma unroll
@@ -740,9 +748,11 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
                             // the next group decides rows r - H + 1 .. r - H + 4 (r = this row); the row with index H
                             // reads its upper ring row from the LAST row (wrap): no floor then
                             const int rnext = rs0 + st + 1 - H + sub_rows;
-                            const float fl = fmaf(p.filt_alpha, (float)(wmin & 0xffffu), beta);
+                            const bool wraprow = rnext <= H && rnext + 3 >= H;
+                            const float flw = wrapcol ? (wraprow ? beta_rc : beta_c) : beta_r;
+                            const float fl = (wrapcol || wraprow) ? flw : fmaf(p.filt_alpha, (float)(wmin & 0xffffu), beta);
                             u32 fi_ = (u32)fminf(fl, 65535.0f);                                    // fl >= 0
-                            fi_ = (no_floor || (rnext <= H && rnext + 3 >= H)) ? 0u : fi_;
+                            fi_ = no_floor ? 0u : fi_;
                             F = fi_ | (fi_ << 16);
                         }
                     }
@@ -799,7 +809,10 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
                 while (tail - head >= 64) exact_round(64);
                 if (filter) {
                     if (tail - head >= FAST_ROUND || (trigger < FAST_ROUND && tail > head)) exact_round(tail - head);
-                    trigger = FAST_ROUND;
+                    // A threshold so low that most maxima pass the floor (two and more candidates per row): ending the
+                    // chunk every FAST_ROUND candidates would replay the 2H + 2 halo rows every dozen rows — the ring
+                    // is then drained only when nearly full, as without a floor.
+                    trigger = (dn > 0 && added >= 2 * dn) ? THRESH : FAST_ROUND;
                 }
             }
             o += dn;
@@ -910,7 +923,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     // weights (total P_box) inside the box only.  N_K = negative weight in the rows a <= 2H - 3 of the neighbourhood,
     // the ones certainly behind the scan when it decides (a flush group is at most 4 rows).  Double precision;
     // 0.1 % margin for the float32 rounding of the reference's own summation.
-    double P_box = 0.0, N_K = 0.0;
+    double P_box = 0.0, N_K = 0.0, N_row0 = 0.0, N_col0 = 0.0;
     {
         const int n = 2 * h + 3;
         std::vector<double> wgt((size_t)n * n, 0.0);
@@ -926,14 +939,20 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
                 const double v = wgt[(size_t)a * n + b];
                 if (v > 0) P_box += v;
                 else if (a <= 2 * h - 3) N_K -= v;
+                if (a == 0) N_row0 -= v;               // first row / first column of the neighbourhood: negative weights only
+                if (b == 0) N_col0 -= v;
             }
     }
     if (min_ng > 0.0 && std::isfinite(min_ng)) {
         p.filt_alpha = (float)(N_K / P_box * 0.998);
         p.filt_t = (float)std::max(0.0, min_ng / (P_box * 1.001) - 1.0);     // one count of slack for the float32 evaluation
         p.filt_slack = (int)std::min(65535.0, std::max(2.0, std::ceil(0.5 * min_ng / P_box)));
+        p.filt_kr = (float)std::max(0.0, (1.0 - N_row0 / P_box) * 0.998);
+        p.filt_kc = (float)std::max(0.0, (1.0 - N_col0 / P_box) * 0.998);
+        p.filt_krc = (float)std::max(0.0, (1.0 - (N_row0 + N_col0) / P_box) * 0.998);
     } else {
         p.filt_alpha = 0.0f; p.filt_t = -1.0f; p.filt_slack = 0;
+        p.filt_kr = p.filt_kc = p.filt_krc = 0.0f;
     }
     static const int dbg = getenv("PMI_IDENTIFY_DBG") ? atoi(getenv("PMI_IDENTIFY_DBG")) : 0;
     p.dbg = dbg;

@@ -158,6 +158,13 @@ def main():
         except Exception as exc:      # noqa: BLE001 - any failure to set up the native communicator
             comm = None
             gather_impl = f"torch.distributed all_gather_into_tensor (native communicator unavailable: {exc})"
+        # every rank takes the same path: one rank without the native communicator puts all of them on torch's
+        okt = torch.tensor([1 if comm is not None else 0], dtype=torch.int32, device=dev)
+        dist.all_reduce(okt, op=dist.ReduceOp.MIN)
+        if int(okt.item()) == 0 and comm is not None:
+            comm.close()
+            comm, gstream = None, None
+            gather_impl = "torch.distributed all_gather_into_tensor (native communicator unavailable on another rank)"
     g_stream_ptr = ctypes.c_void_p(gstream.cuda_stream) if gstream is not None else None
 
     def native_gather(k):

@@ -90,6 +90,9 @@ int pmi_stream_create(void **stream);
 int pmi_stream_destroy(void *stream);
 int pmi_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int pmi_release_scratch(void);               /* frees the library's cached scratch buffers */
+/* Scratch of the calls that follow comes from bank 0 (default) or 1: a caller that keeps two pipelines in flight on two
+ * streams (the fit of one frame range beside the scan of the next) selects a bank before queueing each. */
+int pmi_scratch_bank(int bank);
 
 /* ---- identify --------------------------------------------------------- *
  * movie: (F, Y, X) pixels of `dtype`.  roi4 = {y0, x0, y1, x1} already

@@ -46,6 +46,7 @@ SYMBOLS = {
     "pmi_stream_destroy": (_i32, [_p]),
     "pmi_memcpy_d2h_async": (_i32, [_p, _p, _sz, _p]),
     "pmi_release_scratch": (_i32, []),
+    "pmi_scratch_bank": (_i32, [_i32]),
     "pmi_identify": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
     "pmi_identify_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _p]),
     "pmi_net_gradient": (_i32, [_p, _i64, _i64, _p, _p, _i64, _i32, _p, _p, _p]),

@@ -26,13 +26,17 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 }
 
 struct ScratchBuf { void *p = nullptr; size_t bytes = 0; };
-static ScratchBuf g_scratch[SCR_NUM];
+// Two banks: a caller that keeps two pipelines in flight on two streams (frame range A fitting while range B is
+// scanned) gives each its own scratch (pmi_scratch_bank); everything else lives in bank 0.
+constexpr int SCR_BANKS = 2;
+static ScratchBuf g_scratch_banks[SCR_BANKS][SCR_NUM];
+static int g_scratch_bank = 0;
 static std::mutex g_scratch_mu;
 
 int scratch(int slot, size_t bytes, void **ptr)
 {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    ScratchBuf &b = g_scratch[slot];
+    ScratchBuf &b = g_scratch_banks[g_scratch_bank][slot];
     if (b.bytes < bytes) {
         if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
         size_t want = bytes + bytes / 4 + 4096;   // headroom so repeated calls stop reallocating
@@ -46,8 +50,16 @@ int scratch(int slot, size_t bytes, void **ptr)
 int scratch_release_all()
 {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    for (auto &b : g_scratch)
-        if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    for (auto &bank : g_scratch_banks)
+        for (auto &b : bank)
+            if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+    return PMI_OK;
+}
+int scratch_select_bank(int bank)
+{
+    if (bank < 0 || bank >= SCR_BANKS) { set_error("scratch bank %d out of range", bank); return PMI_ERR_ARG; }
+    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    g_scratch_bank = bank;
     return PMI_OK;
 }
 
@@ -124,6 +136,7 @@ int pmi_memcpy_d2h_async(void *h, const void *d, size_t bytes, void *stream)
     return PMI_OK;
 }
 int pmi_release_scratch(void) { pmi::release_fft_plans(); return pmi::scratch_release_all(); }
+int pmi_scratch_bank(int bank) { return pmi::scratch_select_bank(bank); }
 
 int pmi_event_create(void **event)
 {

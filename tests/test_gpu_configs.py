@@ -184,3 +184,47 @@ def test_config4_geometry_shard_in_miniature(be, orc):
     drift, und = postprocess.undrift(locs, [{"Frames": F, "Height": H, "Width": W}, {"Pixelsize": 130}], 8, display=False)
     assert len(und) == len(locs) and len(drift) == F and float(np.abs(drift.to_numpy()).max()) < 0.2
     del movie
+
+
+def test_two_pipelines_in_flight_give_the_rows_of_one_pass():
+    """pmi_scratch_bank: two frame ranges queued on two streams, each with its own scratch bank (the fit of range A
+    runs beside the scan of range B), produce — concatenated — exactly the table of one pass over all frames."""
+    import torch
+    from picasso_amd import _lib, synth
+    L = _lib.load()
+    F, half = 400, 200
+    movie = synth.simulate_movie(F, 256, 256, emitters_per_frame=40, seed=11, device="cuda")
+    torch.cuda.synchronize()
+    cap = 200 * F
+    px = 256 * 256 * 2
+
+    def run(ptr, frames, table, d_n, stream, bank):
+        _lib.check(L.pmi_scratch_bank(bank), "pmi_scratch_bank")
+        rc = L.pmi_localize_mle_dev(ctypes.c_void_p(ptr), 0, frames, 256, 256, 7, 5000.0, None, 0, frames - 1, 100.0, 1.0, 1.0,
+                                    1e-3, 100, _lib.MLE_METHODS["sigmaxy"], ctypes.c_void_p(table.data_ptr()), cap,
+                                    ctypes.c_void_p(d_n.data_ptr()), ctypes.c_void_p(stream.cuda_stream))
+        _lib.check(rc, "pmi_localize_mle_dev")
+
+    try:
+        whole = torch.zeros((_lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device="cuda")
+        n_whole = torch.zeros(1, dtype=torch.int64, device="cuda")
+        run(movie.data_ptr(), F, whole, n_whole, torch.cuda.current_stream(), 0)
+        torch.cuda.synchronize()
+        streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+        parts = [torch.zeros((_lib.PMI_LOC_COLUMNS, cap), dtype=torch.int32, device="cuda") for _ in range(2)]
+        ns = [torch.zeros(1, dtype=torch.int64, device="cuda") for _ in range(2)]
+        for rep in range(3):                  # repeated: the two pipelines really overlap from the second pass on
+            for k in range(2):
+                run(movie.data_ptr() + k * half * px, half, parts[k], ns[k], streams[k], k)
+        torch.cuda.synchronize()
+    finally:
+        _lib.check(L.pmi_scratch_bank(0), "pmi_scratch_bank")
+    n = int(n_whole.item())
+    na, nb = int(ns[0].item()), int(ns[1].item())
+    assert n > 10000 and na + nb == n
+    w = whole[:, :n].cpu().numpy()
+    a, b = parts[0][:, :na].cpu().numpy().copy(), parts[1][:, :nb].cpu().numpy().copy()
+    b[0] += half                              # column 0 = frame (uint32 cells): range B counts from its own first frame
+    both = np.concatenate([a, b], axis=1)
+    assert np.array_equal(both, w)
+    assert L.pmi_scratch_bank(2) != 0         # only banks 0 and 1 exist

@@ -705,6 +705,17 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
                         for (int tt = 0; tt <= t4; tt++)
                             if (rd0 + tt >= lo_rel && rd0 + tt < hi_rel) rowmask |= 0x000f000fu << (4 * tt);
                         u32 pass = ~acc & rowmask & colmask;
+                        {
+                            // Two candidates side by side, or one above the other, hold the same value (each is the
+                            // maximum of a window that contains the other), and np.argmax takes the first: the right-hand
+                            // / lower one cannot be it.  Dropped here — within the lane's 8 pixels and the group's rows —
+                            // a plateau of equal pixels (a saturated fiducial) sends its upper-left rim to the ring
+                            // instead of every pixel.
+                            const u32 c = pass;
+                            pass &= ~((c & 0x0000ffffu) << 16);                    // odd pixel, left neighbour = the even pixel of its pair
+                            pass &= ~(((c >> 16) << 1) & 0x0000eeeeu);             // even pixel 2q (q > 0), left neighbour = odd pixel of pair q - 1
+                            pass &= ~((c & 0x0fff0fffu) << 4);                     // same pixel, one row up (previous row slot)
+                        }
                         acc = 0;
                         tail_lf = tail; rd_lf = rd0;
                         // Append to the wave's ring: every round each lane that still has a candidate emits its

@@ -334,6 +334,30 @@ def test_identify_fast_path_all_zero_and_all_saturated(be, orc):
     assert all(np.array_equal(p, q) for p, q in zip(a, b)) and len(a[0]) >= 3
 
 
+@pytest.mark.parametrize("dtype,box", [(np.uint16, 7), (np.uint16, 9), (np.uint16, 13), (np.uint8, 7), (np.int16, 5)])
+def test_identify_plateaus_and_saturated_fiducials(be, orc, dtype, box):
+    """Plateaus of equal pixels (a saturated fiducial, flat regions of every shape, equal pixels side by side and one
+    above the other across lane and flush-group boundaries): np.argmax takes the FIRST maximum of a window, the scan drops
+    right-hand / lower neighbours of a candidate before the exact test, the result stays the reference's."""
+    rng = np.random.default_rng(box * 7 + np.dtype(dtype).itemsize)
+    top = {np.uint16: 65535, np.uint8: 255, np.int16: 32767}[dtype]
+    base = rng.poisson(30, size=(6, 200, 512)).astype(np.int64) + (0 if dtype != np.int16 else -200)
+    mov = np.clip(base, np.iinfo(dtype).min, top).astype(dtype)
+    mov[:, 40:90, 100:170] = top                               # saturated square, lane-unaligned
+    mov[:, 120:123, 5:507] = top // 2                          # a long flat bar over every lane
+    mov[0:3, 150:190, 300:303] = top // 3                      # a tall narrow one
+    mov[3:, 20:28, 7:9] = top                                  # pairs side by side at a lane boundary (columns 7 | 8)
+    mov[:, 99:101, 400] = top - 1                              # one above the other
+    for f in range(6):                                         # plateaus with a brighter pixel inside / at the rim
+        mov[f, 60, 130 + f] = top if dtype != np.uint16 else top
+        mov[f, 160 + f, 301] = top // 3 + 5
+    for min_ng in (-1e9, 200.0, 0.3 * float(top)):
+        a = be.identify_arrays(mov, min_ng, box)
+        b = orc.identify(mov, min_ng, box, threads=4)
+        assert all(np.array_equal(p, q) for p, q in zip(a, b)), (dtype, box, min_ng, len(a[0]), len(b[0]))
+    assert len(b[0]) > 0
+
+
 def test_identify_capacity_retry(be, orc, testdata_movie):
     """More rows than the first capacity guess: PMI_ERR_CAPACITY -> retry with the exact count."""
     rng = np.random.default_rng(5)

@@ -97,6 +97,7 @@ enum { FIT_STAGE_NEWTON = 1, FIT_STAGE_FINAL = 2 };
 // a fit that takes more iterations than this is re-fitted whatever its steps were: it spent dozens of iterations
 // within a few percent of eps and the float32 loop has drifted (config 2: four spots in ten thousand)
 constexpr int FIT_SLOW_ITERATIONS = 32;
+constexpr float FIT_NARROW_SIGMA = 0.3f;      // a fitted width below this (px) sends the spot to the re-fit
 
 // ---- DPP wave reductions -------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xf>

@@ -200,7 +200,7 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p, int stages
                 const float dx = fabsf(old_x - th[0]), dy = fabsf(old_y - th[1]), dsx_ = fabsf(old_sx - th[4]), dsy_ = fabsf(old_sy - th[5]);
                 const float D = __uint_as_float(max(max(__float_as_uint(dx), __float_as_uint(dy)), max(__float_as_uint(dsx_), __float_as_uint(dsy_))));
                 conv = (double)D < p.eps;
-                flagged = flagged || borderline(D, kk, p.eps_lo, p.eps_hi);
+                flagged = flagged || borderline(D, kk, p.eps_lo, p.eps_hi) || th[4] < FIT_NARROW_SIGMA || th[5] < FIT_NARROW_SIGMA;
                 if (conv) break;
                 old_x = th[0]; old_y = th[1]; old_sx = th[4]; old_sy = th[5];
             } else {                                        // gaussmle.py:647-670
@@ -216,7 +216,7 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p, int stages
                 const float dx = fabsf(old_x - th[0]), dy = fabsf(old_y - th[1]);
                 const float D = __uint_as_float(max(__float_as_uint(dx), __float_as_uint(dy)));
                 conv = (double)D < p.eps;
-                flagged = flagged || borderline(D, kk, p.eps_lo, p.eps_hi);
+                flagged = flagged || borderline(D, kk, p.eps_lo, p.eps_hi) || th[4] < FIT_NARROW_SIGMA;
                 if (conv) break;
                 old_x = th[0]; old_y = th[1];
             }

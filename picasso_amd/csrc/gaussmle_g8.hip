@@ -334,7 +334,10 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
     // parameter — the update then runs uphill or into its clamp and the trajectory is chaotic in any arithmetic
     const float wide = fmaxf(1.0f, (float)kk * 0.0625f);
     const float epsf = 0.5f * (eps_lo + eps_hi), epsm = 0.5f * (eps_hi - eps_lo) * wide;
-    flagged = flagged || (active && ((D >= epsf - epsm && D < epsf + epsm) || (j < NP && denl >= 0.0f) || kk >= FIT_SLOW_ITERATIONS));
+    // ... and spots whose width collapses below a third of a pixel (a single hot pixel in a small box): the likelihood
+    // is then flat in the position inside the pixel and the two arithmetics end up to 1e-2 px apart on equal counts
+    const bool narrow = (j == 4 || (NP == 6 && j == 5)) && nt < FIT_NARROW_SIGMA;
+    flagged = flagged || (active && ((D >= epsf - epsm && D < epsf + epsm) || (j < NP && denl >= 0.0f) || narrow || kk >= FIT_SLOW_ITERATIONS));
     // the previous-iteration values the reference compares with ARE th (old_x = theta after every pass);
     // finished groups keep their state
     role.th = active ? nt : role.th;

@@ -1,5 +1,5 @@
 """Randomised differential test: GPU path vs the CPU oracle over random shapes, boxes, dtypes, ROIs,
-frame bounds and thresholds (identify: bit-exact), random spots (gaussmle / gausslq: tolerances of
+frame bounds and thresholds (identify: bit-exact), random spots (gaussmle: every row on the oracle's iteration count and within 1e-3 px; gausslq: tolerances of
 tests/test_gpu_parity.py) and random tables (render: ordered sums).  Prints every mismatch.
 usage: python tools/fuzz_parity.py [seconds] [seed]"""
 import sys
@@ -7,7 +7,7 @@ import time
 
 import numpy as np
 
-sys.path.insert(0, ".")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 from oracle import oracle as orc  # noqa: E402
 from picasso_amd import backend as be  # noqa: E402
 
@@ -91,13 +91,13 @@ while time.time() < t_end:
             oth, ocr, oll, oit = orc.gaussmle(spots, eps, max_it, method, threads=4)
             counts["mle"] += 1
             same = it == oit
-            # only fits that converged: a fit that runs into max_it (diverging on a spot without a peak) is
-            # chaotic, any rounding difference sends it elsewhere -- also between numba and NumPy
-            fin = np.all(np.isfinite(oth), axis=1) & same & (oit < max_it)
+            # every row: the iteration count is the oracle's (borderline / chaotic fits are re-fitted on the device in the
+            # reference's arithmetic), and where the oracle converged x, y, sigma agree to 1e-3 px
+            fin = np.all(np.isfinite(oth), axis=1) & (oit < max_it)
             bad = 0
-            if same.mean() < 0.85:
+            if not same.all():
                 bad = 1
-            if fin.any() and np.max(np.abs(th[fin][:, [0, 1, 4, 5]] - oth[fin][:, [0, 1, 4, 5]])) > 2e-3:
+            if fin.any() and np.max(np.abs(th[fin][:, [0, 1, 4, 5]] - oth[fin][:, [0, 1, 4, 5]])) > 1e-3:
                 bad = 2
             if bad:
                 fails += 1

@@ -669,7 +669,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_final_kernel(FitParams p)
                 if (e >= 0 && e < 7) {
                     double acc = 0.0;
 #pragma unroll
-                    for (int r = 0; r < GS; r++) acc += red[r * 7 + e];
+                    for (int r = 0; r < B; r++) acc += red[r * 7 + e];      // rows beyond the box hold zeros
                     mine[t] = acc;
                 }
             }

@@ -47,6 +47,7 @@ struct IdParams {
     int box;
     int tiles_y, tiles_x;
     double min_ng;
+    const int *gate;     // optional device flag: the launch does nothing if it is 0 (the packed scan took these frames)
 };
 
 template <typename T>
@@ -72,6 +73,7 @@ __global__ __launch_bounds__(ID_NT) void identify_scan_kernel(
     const int ty = t / p.tiles_x, tx = t - ty * p.tiles_x;
     const T *src = movie + ((int64_t)(p.f_lo + fi) * p.Y + p.y0) * p.X + p.x0;
 
+    if (p.gate && *p.gate == 0) return;
     if (tid == 0) ncand = 0;
     for (int idx = tid; idx < LH * LW; idx += ID_NT) {
         int r = idx / LW, c = idx - r * LW;
@@ -352,7 +354,42 @@ static int launch_scan(const void *d_movie, const IdParams &p, const float *d_ta
 
 int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
                          int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
-                         long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled);
+                         long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled,
+                         const int *gate = nullptr);
+
+// float32 / int32 / uint32 movies that hold 16-bit counts (a camera's counts saved wide): the frames are narrowed to
+// uint16 — exactly, or not at all: any pixel that is not an integer in 0..65535 raises the chunk's flag — and take the
+// packed scan; a flagged chunk takes the generic kernel.  Both launches are queued, each looks at the flag.
+template <typename T>
+__global__ __launch_bounds__(256) void narrow_to_u16_kernel(const T *__restrict__ src, long long n, uint16_t *__restrict__ dst,
+                                                            int *__restrict__ flag)
+{
+    bool bad = false;
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+        T v[4];
+        const bool full = i + 4 <= n;
+        if (full) { const uint4 q = *reinterpret_cast<const uint4 *>(src + i); __builtin_memcpy(v, &q, 16); }
+        else for (int k = 0; k < 4; k++) v[k] = i + k < n ? src[i + k] : (T)0;
+        uint16_t o[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            if constexpr (sizeof(T) == 4 && !std::is_integral<T>::value) {
+                const float f = (float)v[k];
+                bad = bad || !(f >= 0.0f && f <= 65535.0f && f == __builtin_truncf(f));     // NaN fails every test
+                o[k] = (uint16_t)(int)f;
+            } else if constexpr (std::is_signed<T>::value) {
+                bad = bad || v[k] < 0 || v[k] > 65535;
+                o[k] = (uint16_t)v[k];
+            } else {
+                bad = bad || v[k] > 65535u;
+                o[k] = (uint16_t)v[k];
+            }
+        }
+        if (full) { uint2 w; w.x = o[0] | ((unsigned)o[1] << 16); w.y = o[2] | ((unsigned)o[3] << 16); *reinterpret_cast<uint2 *>(dst + i) = w; }
+        else for (int k = 0; k < 4 && i + k < n; k++) dst[i + k] = o[k];
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
 
 // d_movie points at frame 0 of a stack holding at least frames [f_lo, f_hi].
 // Labels written = frame index + label_offset.
@@ -408,6 +445,45 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
         // register-pipelined packed-u16 scan (identify_fast.hip: uint16, uint8, int16) when the layout allows
         rc = launch_scan_u16_fast(d_movie, dtype, Y, X, p.y0, p.x0, p.cy, p.cx, f_lo, label_offset, p.nframes, box, min_ng,
                                       d_tab, recs, cap, d_total, count, s, &fast);
+        p.gate = nullptr;
+        const bool wide = dtype == PMI_U32 || dtype == PMI_I32 || dtype == PMI_F32;
+        static const bool no_narrow = getenv("PMI_IDENTIFY_NO_NARROW") != nullptr;
+        if (rc == PMI_OK && !fast && wide && !no_narrow && ((uintptr_t)d_movie & 15) == 0 && ((Y * X) & 3) == 0) {
+            // chunks of frames through a uint16 copy of at most 1 GiB
+            const int64_t frame_px = Y * X;
+            const char *cenv = getenv("PMI_IDENTIFY_NARROW_CHUNK");             // frames per chunk (tests: several chunks on a small movie)
+            const int64_t chunk = cenv && atoll(cenv) > 0 ? atoll(cenv) : std::max<int64_t>(1, ((int64_t)1 << 29) / frame_px);
+            const int64_t nchunks = (nf + chunk - 1) / chunk;
+            void *tmp = nullptr, *gptr = nullptr;
+            if ((rc = scratch(SCR_NARROW, (size_t)std::min<int64_t>(nf, chunk) * frame_px * 2 + 64, &tmp)) != PMI_OK) return rc;
+            if ((rc = scratch(SCR_GATES, (size_t)nchunks * sizeof(int), &gptr)) != PMI_OK) return rc;
+            int *gates = (int *)gptr;
+            PMI_HIP(hipMemsetAsync(gates, 0, (size_t)nchunks * sizeof(int), s));
+            bool all_fast = true;
+            for (int64_t ci = 0; ci < nchunks && rc == PMI_OK; ci++) {
+                const int64_t c0 = ci * chunk, n = std::min<int64_t>(chunk, nf - c0);
+                const long long npx = (long long)n * frame_px;
+                const unsigned nb = (unsigned)std::min<long long>((npx / 4 + 255) / 256, 256 * 32);
+                const char *srcp = (const char *)d_movie + (size_t)(f_lo + c0) * frame_px * 4;
+                if (dtype == PMI_F32) hipLaunchKernelGGL(narrow_to_u16_kernel<float>, dim3(nb), dim3(256), 0, s, (const float *)srcp, npx, (uint16_t *)tmp, gates + ci);
+                else if (dtype == PMI_I32) hipLaunchKernelGGL(narrow_to_u16_kernel<int32_t>, dim3(nb), dim3(256), 0, s, (const int32_t *)srcp, npx, (uint16_t *)tmp, gates + ci);
+                else hipLaunchKernelGGL(narrow_to_u16_kernel<uint32_t>, dim3(nb), dim3(256), 0, s, (const uint32_t *)srcp, npx, (uint16_t *)tmp, gates + ci);
+                PMI_HIP(hipGetLastError());
+                bool f2 = false;
+                rc = launch_scan_u16_fast(tmp, PMI_U16, Y, X, p.y0, p.x0, p.cy, p.cx, 0, f_lo + label_offset + c0, (int)n, box, min_ng,
+                                          d_tab, recs, cap, d_total, count + c0, s, &f2, gates + ci);
+                if (rc != PMI_OK) return rc;
+                if (!f2) { all_fast = false; break; }          // the geometry rules the packed scan out: nothing was queued by it
+                IdParams pc = p;
+                pc.f_lo = f_lo + c0; pc.nframes = (int)n; pc.gate = gates + ci;
+                switch (dtype) {
+                case PMI_U32: rc = launch_scan<uint32_t>(d_movie, pc, d_tab, recs, cap, d_total, count + c0, s); break;
+                case PMI_I32: rc = launch_scan<int32_t>(d_movie, pc, d_tab, recs, cap, d_total, count + c0, s); break;
+                default: rc = launch_scan<float>(d_movie, pc, d_tab, recs, cap, d_total, count + c0, s); break;
+                }
+            }
+            fast = all_fast;
+        }
         if (rc == PMI_OK && !fast) switch (dtype) {
         case PMI_U16: rc = launch_scan<uint16_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;
         case PMI_U8:  rc = launch_scan<uint8_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;

@@ -132,6 +132,7 @@ struct FastParams {
     float filt_alpha, filt_t;  // floor filter: a maximum v can only reach min_ng if v > alpha * (minimum above it) + t; t < 0: off
     float filt_kr, filt_kc, filt_krc;   // the same for stencils that wrap through index -1 (row, column, both): v > k * cfloor + t
     int filt_slack;            // counts by which later pixels may undercut the minimum seen so far before a chunk is run again
+    const int *gate;           // optional device flag: the launch does nothing unless it is 0 (32-bit movies narrowed to uint16, identify.hip)
     int dbg;                   // PMI_IDENTIFY_DBG: 1 = skip the exact net gradient, 2 = skip the record append, 4 = no floor filter (timing only)
 };
 
@@ -319,6 +320,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
     const long long unit0 = (long long)blockIdx.x * p.upw;
     const long long unit1 = unit0 + p.upw < p.units ? unit0 + p.upw : p.units;
     if (unit0 >= unit1) return;
+    if (p.gate && *p.gate != 0) return;
     const int sub = P > 1 ? lane / NL : 0;                            // this lane's sub-band and its rows' offset
     const int sub_rows = sub * p.rbu;
 
@@ -875,7 +877,8 @@ static int g_fast_cus = 0;
 // Returns PMI_OK and sets *handled when the fast path applies.
 int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
                          int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
-                         long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled)
+                         long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled,
+                         const int *gate)
 {
     *handled = false;
     static const bool force_generic = getenv("PMI_IDENTIFY_GENERIC") != nullptr;
@@ -906,7 +909,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     }
     FastParams p;
     p.movie = d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;
-    p.f_lo = f_lo; p.label_off = label_off; p.nframes = nframes; p.box = box; p.min_ng = min_ng;
+    p.f_lo = f_lo; p.label_off = label_off; p.nframes = nframes; p.box = box; p.min_ng = min_ng; p.gate = gate;
     p.segs = pack > 1 ? 1 : (nch + 63) / 64;
     // Rows per unit: long units amortise the 2H + 2 pipeline rows a unit spends on its halo, short ones balance the
     // persistent waves (every wave runs ceil(units / waves) units).  Pick the length with the least total work.

@@ -33,6 +33,8 @@ enum ScratchSlot {
     SCR_STAGE_C,
     SCR_STAGE_D,
     SCR_ROWS,             // rows the fit stages of the fused pipelines may touch
+    SCR_NARROW,           // uint16 copy of a chunk of a 32-bit movie (identify)
+    SCR_GATES,            // per-chunk flags of that copy
     SCR_NUM
 };
 int scratch(int slot, size_t bytes, void **ptr);

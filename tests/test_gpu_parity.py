@@ -358,6 +358,39 @@ def test_identify_plateaus_and_saturated_fiducials(be, orc, dtype, box):
     assert len(b[0]) > 0
 
 
+@pytest.mark.parametrize("dtype", [np.float32, np.int32, np.uint32])
+def test_identify_wide_movies_holding_counts(be, orc, dtype, monkeypatch):
+    """32-bit movies whose pixels are 16-bit counts are narrowed to uint16 chunk by chunk and take the packed scan; a chunk
+    with one pixel that is not such a count (a fraction, a negative, 65536, NaN) takes the generic kernel — the table is
+    the reference's either way, chunk boundaries included."""
+    monkeypatch.setenv("PMI_IDENTIFY_NARROW_CHUNK", "3")
+    rng = np.random.default_rng(21)
+    base = rng.poisson(40, size=(11, 96, 272)).astype(np.float64)
+    for f in range(11):
+        for _ in range(6):
+            y, x = rng.integers(8, 88), rng.integers(8, 264)
+            yy, xx = np.mgrid[y - 4:y + 5, x - 4:x + 5]
+            base[f, y - 4:y + 5, x - 4:x + 5] += np.rint(3000 * np.exp(-0.5 * ((yy - y) ** 2 + (xx - x) ** 2) / 1.3 ** 2))
+    clean = base.astype(dtype)
+    spoiled = clean.copy()
+    if dtype == np.float32:
+        spoiled[4, 50, 100] += 0.5            # chunk 1 (frames 3..5): a fraction
+        spoiled[7, 3, 3] = np.float32(-1.0)   # chunk 2: negative
+        spoiled[10, 90, 200] = 70000.0        # chunk 3: beyond 16 bits
+    elif dtype == np.int32:
+        spoiled[4, 50, 100] = -7
+        spoiled[10, 90, 200] = 65536
+    else:
+        spoiled[4, 50, 100] = 65536
+        spoiled[9, 1, 1] = 4000000000
+    for mov in (clean, spoiled):
+        for min_ng, roi in ((5000.0, None), (-1e9, None), (3000.0, ((5, 9), (90, 250)))):
+            a = be.identify_arrays(mov, min_ng, 7, roi=roi)
+            b = orc.identify(mov, min_ng, 7, roi=roi, threads=4)
+            assert all(np.array_equal(p, q) for p, q in zip(a, b)), (dtype, min_ng, roi, len(a[0]), len(b[0]))
+    assert len(b[0]) > 20
+
+
 def test_identify_capacity_retry(be, orc, testdata_movie):
     """More rows than the first capacity guess: PMI_ERR_CAPACITY -> retry with the exact count."""
     rng = np.random.default_rng(5)

@@ -1,5 +1,6 @@
 #!/bin/bash
-# One PMC pass for one kernel regex (kernel-trace only).  Usage: tools/pmc_quick.sh <outdir> <regex> "<counters>" <program> [args...]
+# One PMC pass for one kernel regex (kernel-trace only).  Keep the sets small and each pass under `timeout`: passes with
+# FETCH_SIZE together with other TCC counters, or with TCC_HIT / TCC_MISS / TCC_REQ, hung on this pool (the whole timeout is charged).  Usage: tools/pmc_quick.sh <outdir> <regex> "<counters>" <program> [args...]
 set -u
 OUT=$(realpath -m "$1"); KREGEX=$2; CTRS=$3; shift 3
 mkdir -p "$OUT"; export TMPDIR=/tmp

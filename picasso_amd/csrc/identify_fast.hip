@@ -157,7 +157,16 @@ struct FastParams {
 #ifndef FAST_MIN_WAVES
 #define FAST_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for
 #endif
-constexpr int fast_waves_per_simd(int H) { return H <= 4 ? FAST_MIN_WAVES : (H <= 6 ? 3 : 2); }
+#ifndef FAST_WAVES_H4
+#define FAST_WAVES_H4 2
+#endif
+#ifndef FAST_WAVES_H56
+#define FAST_WAVES_H56 2
+#endif
+// Waves per SIMD the register allocator must leave room for.  Boxes 9 to 13 at four / three waves spilled a few values
+// INSIDE the row loop; a scratch reload is a vector-memory load, and waiting for it drains the prefetched rows at every
+// step (box 11: 1.45 -> 2.94 TB/s, box 9: 2.13 -> 2.73, box 13: 1.93 -> 2.42 with one wave less and no spill).
+constexpr int fast_waves_per_simd(int H) { return H <= 3 ? FAST_MIN_WAVES : (H == 4 ? FAST_WAVES_H4 : (H <= 6 ? FAST_WAVES_H56 : 2)); }
 
 // pair `s` = pixels (s, s+1) relative to the lane's first pixel.  A holds NA packed pairs: the lane's
 // own four in the middle, NB = NA - 4 neighbour pixels on either side (4 for boxes up to 9, 8 for

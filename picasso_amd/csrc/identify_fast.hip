@@ -296,7 +296,11 @@ __device__ __forceinline__ float exact_ng(const typename Px<PT>::T *__restrict__
 // the last rows (own columns and the neighbour lanes'), the right-hand side becomes a packed u16 floor that joins
 // the first-maximum threshold with one v_pk_max_u16 per pixel pair, and the shot-noise maxima (2 % of all pixels,
 // 20 x more than there are emitters) never reach the list.
-template <int H, int D, int P = 1, int PT = PT_U16>
+// EDGE: the frame is wider than the wave's 512 columns (lanes 0 / 63 fetch the pixels beyond it).  A compile-time
+// parameter, and the edge load is issued by EVERY lane (the others point it past the descriptor's bound: no access):
+// the compiler then counts two loads per row and waits with the exact vmcnt — as a run-time branch it has to assume
+// the smaller count on every path and the wide frames ran at half their prefetch depth.
+template <int H, int D, int P = 1, int PT = PT_U16, bool EDGE = false>
 __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_fast_kernel(
     FastParams p, const float *__restrict__ uxy, Record *__restrict__ recs, long long cap,
     unsigned long long *__restrict__ shard_cnt, int *__restrict__ frame_count)
@@ -511,11 +515,10 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
         // 8-byte loads next to the 16-byte ones doubled the HBM-side traffic (requests to a line whose
         // fill is still in flight are not merged).  Only lanes 0 and 63 load the 4 pixels beyond the wave.
         const unsigned off_m = (unsigned)col_m * (unsigned)PXB;
-        const unsigned off_e = (unsigned)(lane == 0 ? col_l : col_r) * (unsigned)PXB;
+        const unsigned off_e = (lane == 0 || lane == 63) ? (unsigned)(lane == 0 ? col_l : col_r) * (unsigned)PXB : 0x7ffffff0u;   // others: out of bounds
         // a sub-band's row lies wholly inside its lanes, and so does the row of a frame at most 512 pixels wide: the
         // pixels lanes 0 and 63 would take from beyond the wave then only feed masked positions
-        const bool any_edge = P == 1 && p.segs > 1;
-        const bool edge_lane = lane == 0 || lane == 63;
+        constexpr bool any_edge = EDGE && P == 1;
         // num_records bounds the descriptor at the end of the frames of this call: when the width is not a
         // multiple of 8 the last chunk of a row reads into the next row (masked columns), and on the very last
         // row it would read past the movie — the buffer unit returns 0 there instead
@@ -561,7 +564,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
                 // only lanes 0 and 63 ever read `e` (as the DPP fill value): the other lanes leave it undefined
                 // instead of spending two or four v_mov per row on zeros
                 asm("" : "=v"(ro.e.x), "=v"(ro.e.y), "=v"(ro.e.z), "=v"(ro.e.w));
-                if (any_edge && edge_lane) {
+                if constexpr (any_edge) {
                     if constexpr (PT == PT_U8) {
                         if constexpr (WIDE) {
                             const u32x2_t e = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)off_e, (int)soff, 0);
@@ -852,6 +855,13 @@ static int launch_fast(const FastParams &p, int pt, const float *d_tab, Record *
     const long long blocks = (p.units + p.upw - 1) / p.upw;
     if (blocks > 0x7fffffffLL) { set_error("identify: too many blocks (%lld)", blocks); return PMI_ERR_ARG; }
     const dim3 g((unsigned)blocks), b(64);
+    if (P == 1 && p.segs > 1) {       // frames wider than a wave: the variant with the edge loads
+        if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_U8, P == 1>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+        else if (pt == PT_I16) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_I16, P == 1>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+        else hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_U16, P == 1>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+        PMI_HIP(hipGetLastError());
+        return PMI_OK;
+    }
     if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_U8>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
     else if (pt == PT_I16) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_I16>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
     else hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_U16>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);

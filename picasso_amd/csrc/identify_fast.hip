@@ -139,6 +139,9 @@ struct FastParams {
 #ifndef FAST_D_H3
 #define FAST_D_H3 3          // rows prefetched ahead in the box-7 scan (divides its unroll period of 6).  6 / 3 / 2 -> 1.45 / 1.26 / 1.25 ms on one box: the twelve registers a deeper prefetch holds are worth more to the scheduler
 #endif
+#ifndef FAST_U_H3
+#define FAST_U_H3 6         // unroll period of the box-7 row loop (a multiple of the ring period 3 and of FAST_D_H3)
+#endif
 #ifndef FAST_D_H2
 #define FAST_D_H2 2
 #endif
@@ -314,7 +317,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
     // the slot about to be overwritten is skipped: both rings then share the period H.
     constexpr bool WIDE = H >= 5;
     constexpr int NB = WIDE ? 8 : 4, NA = 4 + NB, OWN = NB / 2;
-    constexpr int U_ = H <= 2 ? 4 : (H == 3 ? 6 : (H == 4 ? 4 : (H == 5 ? 10 : (H == 6 ? 6 : 2 * H))));   // unroll period: a multiple of the ring period H
+    constexpr int U_ = H <= 2 ? 4 : (H == 3 ? FAST_U_H3 : (H == 4 ? 4 : (H == 5 ? 10 : (H == 6 ? 6 : 2 * H))));   // unroll period: a multiple of the ring period H
     static_assert(U_ % D == 0, "prefetch depth must divide the unroll period");
     constexpr int NWL = (H + 1 + 7) / 8;                   // neighbour lanes (8 columns each) a stencil reaches on either side
     // Candidate ring: entries (row << 16 | column in the aligned row) + frame index.  A chunk of rows ends early when

@@ -1004,6 +1004,9 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
 #ifndef LQ_ROUNDS
 #define LQ_ROUNDS 5
 #endif
+#ifndef LQ_BATCH_LOG2
+#define LQ_BATCH_LOG2 21      // spots per batch (state: 548 B per spot); every batch ends with one host synchronisation
+#endif
 template <bool FROM_MOVIE_IN>
 static int launch(Params p, hipStream_t s)
 {
@@ -1011,7 +1014,7 @@ static int launch(Params p, hipStream_t s)
     int dev = 0, cus = 256;
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-    const int64_t BATCH = 1 << 19;
+    const int64_t BATCH = (int64_t)1 << LQ_BATCH_LOG2;
     const int64_t Ntotal = p.N;
     const int64_t cap = std::min<int64_t>(Ntotal, BATCH);
     void *ptr = nullptr;

@@ -164,27 +164,29 @@ __global__ __launch_bounds__(1024) void frame_scan_kernel(const int *__restrict_
                                                           unsigned long long *__restrict__ counters,
                                                           long long *__restrict__ out_n)
 {
-    __shared__ int buf[1024];
-    __shared__ int carry;
-    const int tid = threadIdx.x;
-    if (tid == 0) carry = 0;
+    // exclusive prefix sum of the per-frame counts, one workgroup: every thread sums a run of K consecutive frames,
+    // the 1024 run totals are scanned with wave shuffles (two levels, two barriers), the runs are written out
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const int K = (nframes + 1023) / 1024;
+    const int i0 = tid * K;
+    int local = 0;
+    for (int k = 0; k < K; k++) local += (i0 + k < nframes) ? count[i0 + k] : 0;
+    int incl = local;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int up = __shfl_up(incl, off);
+        if (lane >= off) incl += up;
+    }
+    if (lane == 63) wave_tot[wv] = incl;
     __syncthreads();
-    for (int start = 0; start < nframes; start += 1024) {
-        int i = start + tid;
-        int v = i < nframes ? count[i] : 0;
-        buf[tid] = v;
-        __syncthreads();
-        for (int off = 1; off < 1024; off <<= 1) {
-            int add = tid >= off ? buf[tid - off] : 0;
-            __syncthreads();
-            buf[tid] += add;
-            __syncthreads();
-        }
-        int incl = buf[tid];
-        if (i < nframes) { base[i] = carry + incl - v; cursor[i] = 0; }
-        __syncthreads();
-        if (tid == 1023) carry += incl;
-        __syncthreads();
+    int before = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) before += w < wv ? wave_tot[w] : 0;
+    int run = before + incl - local;
+    for (int k = 0; k < K; k++) {
+        const int i = i0 + k;
+        if (i < nframes) { base[i] = run; cursor[i] = 0; run += count[i]; }
     }
     if (tid == 0) {
         unsigned long long total = 0;

@@ -68,6 +68,7 @@ template <int B> __device__ __forceinline__ void div_const_row(float (&v)[B], co
 struct FitParams {
     // source: spots (float32) or movie + identifications
     const float *spots;
+    float *spots_out;      // g8_init from a movie: the photon values of every spot of the batch are kept here (batch-relative)
     const void *movie;
     const int32_t *frame, *y, *x;
     int dtype;
@@ -93,7 +94,7 @@ struct FitParams {
     unsigned *flag_count;
 };
 constexpr int FISHER_STRIDE = 21;
-enum { FIT_STAGE_NEWTON = 1, FIT_STAGE_FINAL = 2 };
+enum { FIT_STAGE_NEWTON = 1, FIT_STAGE_FINAL = 2, FIT_STAGE_INIT_ONLY = 4, FIT_STAGE_ITERATE_ONLY = 8 };
 // a fit that takes more iterations than this is re-fitted whatever its steps were: it spent dozens of iterations
 // within a few percent of eps and the float32 loop has drifted (config 2: four spots in ten thousand)
 constexpr int FIT_SLOW_ITERATIONS = 32;

@@ -480,6 +480,14 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     ScopedKernelTimer tm(s, &g_last_times.fit_ms);
     static const bool force_wave_per_spot = getenv("PMI_FIT_WAVE_PER_SPOT") != nullptr;
     const bool g8 = !force_wave_per_spot && p.box <= 15;
+    float *cut = nullptr;
+    static const bool no_keep = getenv("PMI_MLE_NO_KEEP") != nullptr;
+    if (g8 && from_movie && mode != PMI_MLE_STRICT && !no_keep) {
+        void *cptr = nullptr;
+        if ((rc = scratch(SCR_STAGE_C, per_batch * (size_t)(p.box * p.box) * sizeof(float), &cptr)) != PMI_OK) return rc;
+        cut = (float *)cptr;
+    }
+    p.spots_out = nullptr;
     for (int64_t bi = 0; bi < nb; bi++) {
         p.first = bi * BATCH;
         p.N = std::min<int64_t>(Ntotal, p.first + BATCH);
@@ -499,6 +507,23 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         // Newton stage: boxes <= 15 run eight or four spots per wavefront (gaussmle_g8.hip), boxes 17..21 one
         // wavefront per spot; then the flagged spots again in the reference's arithmetic; then Fisher matrix and
         // log-likelihood at the final thetas
+        if (mode != PMI_MLE_STRICT && g8 && from_movie && cut) {
+            // From a movie every stage would fetch the spot's B rows again — B cache lines of 128 B for B * B pixels, the
+            // memory side of g8_init and a good part of the Fisher pass.  The start-value kernel keeps the photon values
+            // it computed (2 lines per 7x7 spot, contiguous) and the later stages read those.
+            FitParams pi = p;
+            pi.spots_out = cut;
+            launch_fit_g8(pi, method, true, g_cu_count, state, FIT_STAGE_INIT_ONLY, s);
+            PMI_HIP(hipGetLastError());
+            FitParams q = p;
+            q.spots = cut - p.first * (int64_t)(p.box * p.box);      // indexed by the absolute spot number
+            launch_fit_g8(q, method, false, g_cu_count, state, FIT_STAGE_ITERATE_ONLY, s);
+            PMI_HIP(hipGetLastError());
+            if (mode == PMI_MLE_REFIT)
+                launch_fit_strict(q, method, false, flag_list, q.flag_count, count, g_cu_count, s);
+            PMI_HIP(hipGetLastError());
+            launch_fit_g8(q, method, false, g_cu_count, state, FIT_STAGE_FINAL, s);
+        } else {
         if (mode == PMI_MLE_STRICT) {
             launch_fit_strict(p, method, from_movie, nullptr, nullptr, count, g_cu_count, s);
         } else {
@@ -511,6 +536,7 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         PMI_HIP(hipGetLastError());
         if (g8) launch_fit_g8(p, method, from_movie, g_cu_count, state, FIT_STAGE_FINAL, s);
         else wave_per_spot(FIT_STAGE_FINAL);
+        }
         PMI_HIP(hipGetLastError());
         const unsigned cb = (unsigned)((count + 255) / 256);
         if (method == PMI_MLE_SIGMAXY)

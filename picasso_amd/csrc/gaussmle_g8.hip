@@ -386,6 +386,12 @@ __global__ __launch_bounds__(FIT_NT) void g8_init_kernel(FitParams p, float *__r
 
     float d[B];
     load_row<B, FROM_MOVIE>(p, sidx, j, spot_ok && rowok, d);
+    if (FROM_MOVIE && p.spots_out && spot_ok && rowok) {
+        // the Newton loop and the Fisher pass read the spot from here: 2 cache lines per spot instead of B
+        float *o = p.spots_out + (sidx - p.first) * (B * B) + j * B;
+#pragma unroll
+        for (int i = 0; i < B; i++) o[i] = d[i];
+    }
 
     double ps = 0.0, px = 0.0;
 #pragma unroll
@@ -698,10 +704,10 @@ static void launch_g8(const FitParams &p, float *state, int cu_count, int stages
     // persistent iterate grid: 6 workgroups (24 waves, 73 VGPRs each) per CU, each wave owning >= 64 spots when possible
     const int64_t pw = std::max<int64_t>(1, std::min<int64_t>((int64_t)cu_count * 24, (count + 63) / 64));
     const dim3 pers((unsigned)((pw + FIT_WAVES - 1) / FIT_WAVES));
-    if (stages & FIT_STAGE_NEWTON) {
+    if (stages & (FIT_STAGE_NEWTON | FIT_STAGE_INIT_ONLY))
         hipLaunchKernelGGL((g8_init_kernel<NP, B, FROM_MOVIE>), flat, dim3(FIT_NT), 0, s, p, state);
+    if (stages & (FIT_STAGE_NEWTON | FIT_STAGE_ITERATE_ONLY))
         hipLaunchKernelGGL((g8_iterate_kernel<NP, B, FROM_MOVIE>), pers, dim3(FIT_NT), 0, s, p, (const float *)state);
-    }
     if (stages & FIT_STAGE_FINAL)
         hipLaunchKernelGGL((g8_final_kernel<NP, B, FROM_MOVIE>), flat, dim3(FIT_NT), 0, s, p);
 }

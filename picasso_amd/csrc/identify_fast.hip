@@ -127,6 +127,8 @@ struct FastParams {
     int upf;                   // units per frame: ceil(cy / (rbu * P)) * segs
     long long units;           // nframes * upf
     int upw;                   // consecutive units per wavefront
+    int lin_rows;              // > 0 (one row range per lane set, P == 1): a wave takes lin_rows consecutive rows of the
+    long long lin_total;       //   sequence (segment, frame, row) of lin_total rows, cut into units only at frame boundaries
     int box;
     double min_ng;
     float filt_alpha, filt_t;  // floor filter: a maximum v can only reach min_ng if v > alpha * (minimum above it) + t; t < 0: off
@@ -333,8 +335,16 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
     __builtin_amdgcn_wave_barrier();
     __threadfence_block();
 
-    const long long unit0 = (long long)blockIdx.x * p.upw;
-    const long long unit1 = unit0 + p.upw < p.units ? unit0 + p.upw : p.units;
+    // Work of this wave: `upw` consecutive units of rbu rows, or (lin) a run of lin_rows consecutive rows of the
+    // sequence (segment, frame, row): the same number of rows for every wave, and halo rows are replayed only where
+    // the run starts and where it crosses into the next frame — not every rbu rows.
+    const bool lin = P == 1 && p.lin_rows > 0;
+    long long unit0 = (long long)blockIdx.x * p.upw;
+    long long unit1 = unit0 + p.upw < p.units ? unit0 + p.upw : p.units;
+    if (lin) {
+        unit0 = (long long)blockIdx.x * p.lin_rows;
+        unit1 = unit0 + p.lin_rows < p.lin_total ? unit0 + p.lin_rows : p.lin_total;
+    }
     if (unit0 >= unit1) return;
     if (p.gate && *p.gate != 0) return;
     const int sub = P > 1 ? lane / NL : 0;                            // this lane's sub-band and its rows' offset
@@ -480,12 +490,29 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
         if (++rounds == KBUF) flush();
     };
 
-    for (long long unit = unit0; unit < unit1; unit++) {
-        const int fi = (int)(unit / p.upf);
-        const int rem = (int)(unit - (long long)fi * p.upf);
-        // consecutive units = consecutive row ranges of one 512-column segment (P > 1: `band` counts groups of P row ranges, seg = 0)
-        const int bands = p.upf / p.segs;
-        const int seg = rem / bands, band = rem - seg * bands;
+    for (long long unit = unit0; unit < unit1;) {
+        int fi, seg, b0, unit_rows, bend;
+        if (lin) {
+            const long long per_seg = (long long)p.nframes * p.cy;
+            seg = (int)(unit / per_seg);
+            const long long rem = unit - (long long)seg * per_seg;
+            fi = (int)(rem / p.cy);
+            b0 = (int)(rem - (long long)fi * p.cy);
+            unit_rows = (int)(unit1 - unit < (long long)(p.cy - b0) ? unit1 - unit : (long long)(p.cy - b0));
+            bend = b0 + unit_rows;
+            unit += unit_rows;
+        } else {
+            fi = (int)(unit / p.upf);
+            const int rem = (int)(unit - (long long)fi * p.upf);
+            // consecutive units = consecutive row ranges of one 512-column segment (P > 1: `band` counts groups of P row ranges, seg = 0)
+            const int bands = p.upf / p.segs;
+            seg = rem / bands;
+            const int band = rem - seg * bands;
+            b0 = band * (p.rbu * P);                       // first row of sub-band 0
+            unit_rows = min(p.rbu, p.cy - b0);             // rows of sub-band 0 (the others may hold fewer: masked)
+            bend = b0 + p.rbu;
+            unit++;
+        }
         const int c8 = P > 1 ? lane % NL : seg * 64 + lane;
         const bool lane_valid = c8 < nch;
         const int cm = min(c8, nch - 1);
@@ -530,8 +557,6 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             const_cast<PX *>(src - xoff), 0, (int)(remaining < 0x7fffffffLL ? remaining : 0x7fffffffLL),
             0x00020000 /* raw 32-bit buffer, gfx94x/gfx950 */);
 
-        const int b0 = band * (p.rbu * P);                 // first row of sub-band 0
-        const int unit_rows = min(p.rbu, p.cy - b0);       // rows of sub-band 0 (the others may hold fewer: masked)
         int o = 0;                                         // rows of the unit already decided
         while (o < unit_rows) {
             // ---- one chunk: rows [clo, clo + len) of every sub-band (len shrinks if the ring fills up) ----
@@ -540,7 +565,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             const int nr = len + 2 * H + 2;                // pipeline rows: the stencils of rows clo .. clo + len - 1 (H + 1 rows above and below)
             // rows that may hold a maximum, in sub-band 0's numbering
             const int lo_rel = max(clo + sub_rows, H) - sub_rows;
-            const int hi_rel = min(min(clo + len, b0 + p.rbu) + sub_rows, min(p.cy, p.cy - H - 1)) - sub_rows;
+            const int hi_rel = min(min(clo + len, bend) + sub_rows, min(p.cy, p.cy - H - 1)) - sub_rows;
             // interior chunks never touch a row outside the crop: no clamping in their row loop
             const bool interior = P == 1 && rs0 >= 0 && rs0 + nr + U_ + D <= p.cy;
             auto load_row = [&](int r) -> RowRegs {
@@ -821,7 +846,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
                 tail = tail0;
                 const int wcols = P > 1 ? NL * 8 : 512;
                 for (int s = 0; s < P; s++) {
-                    const int r_lo = max(clo + s * p.rbu, H), r_hi = min(min(clo + dn, b0 + p.rbu) + s * p.rbu, p.cy - H - 1);
+                    const int r_lo = max(clo + s * p.rbu, H), r_hi = min(min(clo + dn, bend) + s * p.rbu, p.cy - H - 1);
                     for (int idx0 = 0; idx0 < dn * wcols; idx0 += 64) {
                         const int idx = idx0 + lane;
                         const int i = clo + s * p.rbu + idx / wcols;
@@ -955,6 +980,17 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     p.units = (long long)p.upf * nframes;
     const long long blocks = std::min<long long>(p.units, waves);
     p.upw = (int)((p.units + blocks - 1) / blocks);
+    p.lin_rows = 0; p.lin_total = 0;
+    static const bool no_lin = getenv("PMI_IDENTIFY_NOLIN") != nullptr;
+    if (pack == 1 && !no_lin && force_rbu <= 0) {
+        // one row range per lane set: every wave the same number of consecutive rows (at least 64: a run pays 2h + 2
+        // halo rows at its start)
+        p.lin_total = (long long)p.segs * nframes * cy;
+        const long long per = std::max<long long>(64, (p.lin_total + waves - 1) / waves);
+        p.lin_rows = (int)std::min<long long>(per, 1 << 30);
+        p.units = (p.lin_total + p.lin_rows - 1) / p.lin_rows;      // = workgroups (launch_fast)
+        p.upw = 1;
+    }
     // Floor filter (see the kernel): ng = sum_p w(p) f(p) over the (2H+3)^2 neighbourhood, sum_p w(p) = 0, positive
     // weights (total P_box) inside the box only.  N_K = negative weight in the rows a <= 2H - 3 of the neighbourhood,
     // the ones certainly behind the scan when it decides (a flush group is at most 4 rows).  Double precision;

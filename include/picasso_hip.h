@@ -202,7 +202,9 @@ int pmi_net_gradient(const float *image, int64_t Y, int64_t X, const int32_t *y,
  * x, y, photons, bg, sx, sy with x, y relative to the box CENTRE (the least-
  * squares model is point-sampled on the grid -r..r, gausslq.py:228).  info /
  * nfev (N, int32, may be NULL) are MINPACK's termination code and the number of
- * residual evaluations, what leastsq(full_output=1) would report.            */
+ * residual evaluations, what leastsq(full_output=1) would report.
+ * The _dev forms queue five rounds of (Jacobian, step) and then WAIT for the stream once per batch of 2 Mi spots to
+ * read how many fits need more (on photon data: none); they are asynchronous up to that point only.   */
 int pmi_gausslq(const float *spots, int64_t N, int box, float *thetas, int32_t *info, int32_t *nfev);
 int pmi_gausslq_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box, float *d_thetas,
                     int32_t *d_info, int32_t *d_nfev, void *stream);

@@ -60,8 +60,15 @@ class NativeComm:
         key = id(group)
         if key not in cls._cache:
             world, rank = dist.get_world_size(group), dist.get_rank(group)
-            box = [cls.unique_id() if rank == 0 else None]
+            box = [None]
+            if rank == 0:
+                try:
+                    box[0] = cls.unique_id()
+                except Exception as exc:      # noqa: BLE001 - every rank must leave the broadcast below the same way
+                    box[0] = f"error: {exc}".encode()
             dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            if not isinstance(box[0], (bytes, bytearray)) or len(box[0]) != 128:
+                raise RuntimeError(f"no RCCL unique id from rank 0 ({box[0]!r})")
             cls._cache[key] = cls(world, rank, box[0])
         return cls._cache[key]
 

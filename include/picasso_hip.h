@@ -90,8 +90,10 @@ int pmi_stream_create(void **stream);
 int pmi_stream_destroy(void *stream);
 int pmi_memcpy_d2h_async(void *dst_host, const void *src_dev, size_t bytes, void *stream);
 int pmi_release_scratch(void);               /* frees the library's cached scratch buffers */
-/* Scratch of the calls that follow comes from bank 0 (default) or 1: a caller that keeps two pipelines in flight on two
- * streams (the fit of one frame range beside the scan of the next) selects a bank before queueing each. */
+/* Scratch of the calls that follow ON THE CALLING THREAD comes from bank 0 (default) or 1: a caller that keeps two
+ * pipelines in flight on two streams (the fit of one frame range beside the scan of the next) selects a bank before
+ * queueing each; two host threads that drive one stream each select a bank each, once.  Calls that share a bank must
+ * not overlap in time (one thread at a time per bank). */
 int pmi_scratch_bank(int bank);
 
 /* ---- identify --------------------------------------------------------- *
@@ -149,18 +151,23 @@ int pmi_gaussmle_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y,
  * test |delta| < eps (:844-852, :632-638) is a discrete decision.
  *   PMI_MLE_FAST    the float32 loop only: ~1e-5 px from the reference, but a step that lands within rounding
  *                   distance of eps can end the fit an iteration earlier or later than the reference does;
- *   PMI_MLE_REFIT   (default) float32 loop, and every spot whose largest tested step came within `margin`
- *                   (relative) of eps in any iteration, or that ran into max_it, is fitted again from its initial
+ *   PMI_MLE_REFIT   (default) float32 loop, and every spot on which the two arithmetics can part — its largest tested
+ *                   step came within `margin` (relative) of eps in some iteration; a curvature term was not negative;
+ *                   a width fell below 0.3 px; a parameter swung back and forth without its steps shrinking (the
+ *                   iteration does not contract); a pixel lay far off the model (|data / model - 1| or
+ *                   |data / model^2| above 16); the fit took more than 32 iterations — is fitted again from its initial
  *                   parameters in the reference's own arithmetic (float64 intermediates, float32 stores, the
  *                   reference's summation order) inside the same call;
  *   PMI_MLE_STRICT  every spot in the reference's arithmetic.
  * Process-wide; the environment variable PMI_MLE_MODE = fast | refit | strict overrides the mode.
- * pmi_mle_last_refit_count: spots the last pmi_gaussmle*_dev / pmi_localize_mle_dev call on `stream` fitted again
- * (synchronises the stream).                                                 */
+ * pmi_mle_last_refit_count: spots the calling thread's last pmi_gaussmle*_dev / pmi_localize_mle_dev call on `stream`
+ * fitted again (synchronises the stream); pmi_mle_last_flag_reasons: of those, how many each criterion flagged, in the
+ * order margin, curvature, narrow width, swing, far-off pixel, slow (n <= 6 counters; a spot can carry several).   */
 enum pmi_mle_mode { PMI_MLE_FAST = 0, PMI_MLE_REFIT = 1, PMI_MLE_STRICT = 2 };
 int pmi_mle_set_mode(int mode, double margin);
 int pmi_mle_get_mode(int *mode, double *margin);
 int pmi_mle_last_refit_count(int64_t *n_refit, void *stream);
+int pmi_mle_last_flag_reasons(int64_t *counts, int n, void *stream);
 
 /* ---- locs_from_fits (gaussmle.py:957-1037) ---------------------------- *
  * Builds the 17-column localization table as structure-of-arrays, row i from

@@ -158,6 +158,16 @@ def last_refit_count(stream=None) -> int:
     return int(n.value)
 
 
+FLAG_REASONS = ("margin", "curvature", "narrow", "swing", "wild", "slow")
+
+
+def last_flag_reasons(stream=None) -> dict:
+    """Of the spots the last MLE call fitted a second time, how many each criterion flagged (a spot can carry several)."""
+    c = (ctypes.c_int64 * len(FLAG_REASONS))()
+    _lib.check(_lib.load().pmi_mle_last_flag_reasons(c, len(FLAG_REASONS), stream), "pmi_mle_last_flag_reasons")
+    return {k: int(v) for k, v in zip(FLAG_REASONS, c)}
+
+
 def gaussmle_arrays(spots: np.ndarray, eps: float, max_it: int, method: str = "sigmaxy"):
     """The allocation contract of picasso/gaussmle.py:455-459."""
     if method not in _lib.MLE_METHODS:

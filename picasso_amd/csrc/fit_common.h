@@ -92,13 +92,25 @@ struct FitParams {
     float eps_lo, eps_hi;
     int32_t *flag_list;          // spot indices, capacity = spots of the batch (nullptr: no flagging)
     unsigned *flag_count;
+    unsigned *flag_reasons;      // FLAG_REASONS counters of the call: how many spots each criterion flagged (nullptr: not counted)
 };
+// why a spot goes to the re-fit (a spot can carry several)
+enum : unsigned { FLAG_MARGIN = 1u, FLAG_CURVATURE = 2u, FLAG_NARROW = 4u, FLAG_SWING = 8u, FLAG_WILD = 16u, FLAG_SLOW = 32u };
+constexpr int FLAG_REASONS = 6;
 constexpr int FISHER_STRIDE = 21;
 enum { FIT_STAGE_NEWTON = 1, FIT_STAGE_FINAL = 2, FIT_STAGE_INIT_ONLY = 4, FIT_STAGE_ITERATE_ONLY = 8 };
 // a fit that takes more iterations than this is re-fitted whatever its steps were: it spent dozens of iterations
 // within a few percent of eps and the float32 loop has drifted (config 2: four spots in ten thousand)
 constexpr int FIT_SLOW_ITERATIONS = 32;
 constexpr float FIT_NARROW_SIGMA = 0.3f;      // a fitted width below this (px) sends the spot to the re-fit
+// the alternating component of a parameter's step sequence (second difference) that changes sign without shrinking below
+// FIT_WOBBLE_RATIO of its previous size, above the rounding floor (FIT_WOBBLE_FLOOR x |value| = 16 float32 ulps), for
+// FIT_WOBBLE_RUN iterations in a row: the iteration is not contracting, re-fit (see newton_step, gaussmle_g8.hip)
+constexpr float FIT_WOBBLE_RATIO = 0.9f;
+constexpr float FIT_WOBBLE_FLOOR = 1.9073486e-6f;
+constexpr int FIT_WOBBLE_RUN = 3;
+// max over the pixels of |data / model - 1| and |data / model^2| beyond which the float32 sums are not trusted: re-fit
+constexpr float FIT_TOP_FLAG = 16.0f;
 
 // ---- DPP wave reductions -------------------------------------------------
 template <int CTRL, int ROW_MASK = 0xf>
@@ -172,6 +184,13 @@ __device__ __forceinline__ Terms gauss_terms(float i, float mu, float sigma)
     t.S = q1 * c1 * is;
     t.S2 = c1 * is2 * (q3 * is2 - 2.0f * q1);
     return t;
+}
+
+__device__ __forceinline__ void count_flag_reasons(unsigned *reasons, unsigned bits)
+{
+    if (!reasons) return;
+    for (int b = 0; b < FLAG_REASONS; b++)
+        if (bits & (1u << b)) atomicAdd(reasons + b, 1u);
 }
 
 __device__ __forceinline__ float load_movie_px(const void *movie, int dtype, int64_t idx)

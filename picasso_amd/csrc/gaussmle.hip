@@ -28,11 +28,21 @@ namespace pmi {
 // Spots to fit again in the reference's arithmetic (gaussmle_strict.hip): the largest tested step D of iteration
 // kk (counted from 1) lies within the margin [eps_lo, eps_hi) of eps, widened with the iteration count (a slow fit
 // takes many steps close to eps and the float32 loop drifts from the reference by more than a few ulps)
-__device__ __forceinline__ bool borderline(float D, int kk, float eps_lo, float eps_hi)
+__device__ __forceinline__ unsigned borderline(float D, int kk, float eps_lo, float eps_hi)
 {
     const float wide = fmaxf(1.0f, (float)(kk - 1) * 0.0625f);
     const float epsf = 0.5f * (eps_lo + eps_hi), epsm = 0.5f * (eps_hi - eps_lo) * wide;
-    return (D >= epsf - epsm && D < epsf + epsm) || kk > FIT_SLOW_ITERATIONS;
+    return ((D >= epsf - epsm && D < epsf + epsm) ? FLAG_MARGIN : 0u) | (kk > FIT_SLOW_ITERATIONS ? FLAG_SLOW : 0u);
+}
+// the wobble test of newton_step (gaussmle_g8.hip) for one parameter: st = this iteration's step, h = its history
+struct StepHistory { float prev, prev2, wprev; int run; };
+__device__ __forceinline__ bool wobbles(float st, float value, int kk, StepHistory &h)
+{
+    const float w = kk >= 3 ? (st - 2.0f * h.prev) + h.prev2 : 0.0f;      // kk counts from 1 here
+    const bool wob = w * h.wprev < 0.0f && fabsf(w) > FIT_WOBBLE_RATIO * fabsf(h.wprev) && fabsf(w) > FIT_WOBBLE_FLOOR * fabsf(value);
+    h.run = wob ? h.run + 1 : 0;
+    h.wprev = w; h.prev2 = h.prev; h.prev = st;
+    return h.run >= FIT_WOBBLE_RUN;
 }
 
 // NP = params (5: "sigma", 6: "sigmaxy"); PPL = pixels per lane = ceil(box^2/64)
@@ -143,10 +153,17 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p, int stages
         ms[4] = (float)(0.2 * (double)th[4]); ms[5] = (float)(0.2 * (double)th[5]);
 
         float old_x = th[0], old_y = th[1], old_sx = th[4], old_sy = th[5];
-        bool flagged = false, conv = false;
+        StepHistory hist[6];
+#pragma unroll
+        for (int l = 0; l < 6; l++) hist[l] = {0.f, 0.f, 0.f, 0};
+        unsigned flagged = 0u;
+        bool conv = false;
         while (kk < p.max_it) {
             kk++;
             float num[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, den[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+            float top = 0.f, was[6];
+#pragma unroll
+            for (int l = 0; l < 6; l++) was[l] = th[l];
             const float sgy = NP == 6 ? th[5] : th[4];
 #pragma unroll
             for (int s = 0; s < PPL; s++) {
@@ -173,9 +190,10 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p, int stages
                     cf = data[s] * r - 1.f;
                     df = data[s] * r * r;
                 }
+                if (!act[s]) { cf = 0.f; df = 0.f; }
+                top = fmaxf(top, fmaxf(fabsf(cf), fabsf(df)));
                 cf = np_minf(cf, 10e4f);
                 df = np_minf(df, 10e4f);
-                if (!act[s]) { cf = 0.f; df = 0.f; }
 #pragma unroll
                 for (int l = 0; l < NP; l++) {
                     num[l] += cf * du[l];
@@ -185,8 +203,9 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p, int stages
 #pragma unroll
             for (int l = 0; l < NP; l++) {
                 num[l] = wave_sum(num[l]); den[l] = wave_sum(den[l]);
-                flagged = flagged || den[l] >= 0.0f;          // curvature not negative: chaotic trajectory (see borderline())
+                flagged |= den[l] >= 0.0f ? FLAG_CURVATURE : 0u;          // curvature not negative: chaotic trajectory
             }
+            flagged |= __any(top >= FIT_TOP_FLAG) ? FLAG_WILD : 0u;   // a pixel far off the model: the float32 sums are not trusted
 
             if (NP == 6) {                                  // gaussmle.py:860-884
 #pragma unroll
@@ -200,7 +219,9 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p, int stages
                 const float dx = fabsf(old_x - th[0]), dy = fabsf(old_y - th[1]), dsx_ = fabsf(old_sx - th[4]), dsy_ = fabsf(old_sy - th[5]);
                 const float D = __uint_as_float(max(max(__float_as_uint(dx), __float_as_uint(dy)), max(__float_as_uint(dsx_), __float_as_uint(dsy_))));
                 conv = (double)D < p.eps;
-                flagged = flagged || borderline(D, kk, p.eps_lo, p.eps_hi) || th[4] < FIT_NARROW_SIGMA || th[5] < FIT_NARROW_SIGMA;
+                flagged |= borderline(D, kk, p.eps_lo, p.eps_hi) | ((th[4] < FIT_NARROW_SIGMA || th[5] < FIT_NARROW_SIGMA) ? FLAG_NARROW : 0u);
+#pragma unroll
+                for (int l = 0; l < 6; l++) flagged |= wobbles(was[l] - th[l], th[l], kk, hist[l]) ? FLAG_SWING : 0u;
                 if (conv) break;
                 old_x = th[0]; old_y = th[1]; old_sx = th[4]; old_sy = th[5];
             } else {                                        // gaussmle.py:647-670
@@ -216,19 +237,23 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p, int stages
                 const float dx = fabsf(old_x - th[0]), dy = fabsf(old_y - th[1]);
                 const float D = __uint_as_float(max(__float_as_uint(dx), __float_as_uint(dy)));
                 conv = (double)D < p.eps;
-                flagged = flagged || borderline(D, kk, p.eps_lo, p.eps_hi) || th[4] < FIT_NARROW_SIGMA;
+                flagged |= borderline(D, kk, p.eps_lo, p.eps_hi) | (th[4] < FIT_NARROW_SIGMA ? FLAG_NARROW : 0u);
+#pragma unroll
+                for (int l = 0; l < 5; l++) flagged |= wobbles(was[l] - th[l], th[l], kk, hist[l]) ? FLAG_SWING : 0u;
                 if (conv) break;
                 old_x = th[0]; old_y = th[1];
             }
         }
-        if (!conv && p.max_it > 0 && th[0] == th[0]) flagged = true;      // ran into max_it
         if (lane == 0) {
             float *to = p.thetas + sidx * 6;
 #pragma unroll
             for (int l = 0; l < 5; l++) to[l] = th[l];
             to[5] = NP == 6 ? th[5] : th[4];
             p.iterations[sidx] = kk;
-            if (flagged && p.flag_list) p.flag_list[atomicAdd(p.flag_count, 1u)] = (int32_t)sidx;
+            if (flagged && p.flag_list) {
+                p.flag_list[atomicAdd(p.flag_count, 1u)] = (int32_t)sidx;
+                count_flag_reasons(p.flag_reasons, flagged);
+            }
         }
         }   // FIT_STAGE_NEWTON
         if (!(stages & FIT_STAGE_FINAL)) { __builtin_amdgcn_wave_barrier(); continue; }
@@ -419,8 +444,17 @@ void launch_fit_strict(const FitParams &p, int method, bool from_movie, const in
 //   PMI_MLE_STRICT  every spot in the reference's arithmetic
 static int g_mle_mode = PMI_MLE_REFIT;
 static double g_mle_margin = 0.001;
-static const unsigned *g_last_flag_counts = nullptr;     // device, one counter per batch of the last call
-static int64_t g_last_flag_batches = 0;
+// flag statistics of the calling thread's last fit: a device buffer of its own (SCR_STATS of the thread's scratch bank:
+// [0] = spots re-fitted, [1..FLAG_REASONS] = spots flagged per criterion), valid while the scratch generation stands
+static thread_local const unsigned *g_last_stats = nullptr;
+static thread_local unsigned g_last_stats_generation = 0;
+
+__global__ void flag_stats_kernel(const unsigned *__restrict__ flag_counts, int64_t nb, unsigned *__restrict__ stats)
+{
+    unsigned total = 0;
+    for (int64_t b = 0; b < nb; b++) total += flag_counts[b];
+    stats[0] = total;
+}
 
 static int mle_mode_now()
 {
@@ -463,8 +497,11 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     PMI_HIP(hipMemsetAsync(ptr, 0, (size_t)nb * 24, s));
     unsigned long long *queues = (unsigned long long *)ptr;
     unsigned *flag_counts = (unsigned *)(queues + 2 * nb);
-    g_last_flag_counts = flag_counts;
-    g_last_flag_batches = mode == PMI_MLE_REFIT ? nb : 0;
+    void *sptr = nullptr;
+    if ((rc = scratch(SCR_STATS, 64, &sptr)) != PMI_OK) return rc;
+    unsigned *stats = (unsigned *)sptr;
+    PMI_HIP(hipMemsetAsync(stats, 0, 64, s));
+    p.flag_reasons = stats + 1;
     p.fisher = (double *)fptr;
     static const char *menv = getenv("PMI_MLE_MARGIN");       // overrides the margin of pmi_mle_set_mode (tuning runs)
     const double margin = menv ? atof(menv) : g_mle_margin;
@@ -545,7 +582,20 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
             hipLaunchKernelGGL((crlb_kernel<5>), dim3(cb), dim3(256), 0, s, p.fisher, p.first, p.N, p.d_n, p.crlbs);
         PMI_HIP(hipGetLastError());
     }
+    hipLaunchKernelGGL(flag_stats_kernel, dim3(1), dim3(1), 0, s, flag_counts, mode == PMI_MLE_REFIT ? nb : 0, stats);
+    PMI_HIP(hipGetLastError());
+    g_last_stats = stats;
+    g_last_stats_generation = scratch_generation();
     tm.stop();
+    return PMI_OK;
+}
+
+static int read_last_stats(unsigned (&h)[16], hipStream_t s)
+{
+    for (unsigned &v : h) v = 0;
+    if (!g_last_stats || g_last_stats_generation != scratch_generation()) return PMI_OK;      // no fit yet, or its buffers are gone
+    PMI_HIP(hipStreamSynchronize(s));
+    PMI_HIP(hipMemcpy(h, g_last_stats, 64, hipMemcpyDeviceToHost));
     return PMI_OK;
 }
 
@@ -632,14 +682,20 @@ int pmi_mle_get_mode(int *mode, double *margin)
 int pmi_mle_last_refit_count(int64_t *n_refit, void *stream)
 {
     using namespace pmi;
-    int64_t total = 0;
-    if (g_last_flag_batches > 0) {
-        std::vector<unsigned> h((size_t)g_last_flag_batches);
-        PMI_HIP(hipStreamSynchronize((hipStream_t)stream));
-        PMI_HIP(hipMemcpy(h.data(), g_last_flag_counts, h.size() * sizeof(unsigned), hipMemcpyDeviceToHost));
-        for (unsigned v : h) total += v;
-    }
-    if (n_refit) *n_refit = total;
+    unsigned h[16];
+    int rc = read_last_stats(h, (hipStream_t)stream);
+    if (rc != PMI_OK) return rc;
+    if (n_refit) *n_refit = h[0];
+    return PMI_OK;
+}
+
+int pmi_mle_last_flag_reasons(int64_t *counts, int n, void *stream)
+{
+    using namespace pmi;
+    unsigned h[16];
+    int rc = read_last_stats(h, (hipStream_t)stream);
+    if (rc != PMI_OK) return rc;
+    for (int i = 0; counts && i < n; i++) counts[i] = i < FLAG_REASONS ? h[1 + i] : 0;
     return PMI_OK;
 }
 

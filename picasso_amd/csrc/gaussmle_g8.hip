@@ -77,6 +77,14 @@ template <int CTRL> __device__ __forceinline__ unsigned dpp_u(unsigned v)
 {
     return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, false);
 }
+template <int GS> __device__ __forceinline__ unsigned gor_u(unsigned v)
+{
+    v |= dpp_u<0xB1>(v);
+    v |= dpp_u<0x4E>(v);
+    v |= dpp_u<0x141>(v);
+    if (GS == 16) v |= dpp_u<0x140>(v);
+    return v;
+}
 template <int GS> __device__ __forceinline__ unsigned gmax_u(unsigned v)
 {
     v = max(v, dpp_u<0xB1>(v));
@@ -199,13 +207,16 @@ struct LaneRole {          // what lane j does in the update stage: parameter j 
     float ms;              // max_step of its parameter
     float floor_, cap;     // lower / upper clamp of its parameter (-inf / +inf = none)
     float th;              // current value of its parameter
+    float prev, prev2;     // the steps its parameter took in the two previous iterations
+    float wprev;           // the second difference of its step sequence one iteration ago
+    int run;               // consecutive iterations in which that second difference changed sign without shrinking
     bool conv_rel;         // its parameter takes part in the convergence test
 };
 
 template <int NP, int B>
 __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6], LaneRole &role, float *lds,
                                             int j, bool rowok, bool active, int &kk, double eps, int max_it,
-                                            float eps_lo, float eps_hi, bool &flagged)
+                                            float eps_lo, float eps_hi, unsigned &flags)
 {
     constexpr int GS = GroupOf<B>::GS;
     float *cols = lds, *red = lds + GS * 12, *bc = lds + 2 * GS * 12;
@@ -245,7 +256,7 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
         const float cf = __builtin_fmaf(d[i], r, -1.f);
         const float df = (d[i] * r) * r;
         guard = guard || !(model > 10e-3f);          // also true for a NaN model
-        top = fmaxf(top, fmaxf(cf, df));
+        top = fmaxf(top, fmaxf(fabsf(cf), fabsf(df)));      // (source modifiers: still one v_max3_f32)
         const f32x2 cf2 = {cf, cf}, df2 = {df, df};
         pA_E = cf2 * (f32x2){c0.x, c0.y} + pA_E;
         pS_A2 = cf2 * (f32x2){c0.z, c0.w} + pS_A2;
@@ -337,7 +348,29 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
     // ... and spots whose width collapses below a third of a pixel (a single hot pixel in a small box): the likelihood
     // is then flat in the position inside the pixel and the two arithmetics end up to 1e-2 px apart on equal counts
     const bool narrow = (j == 4 || (NP == 6 && j == 5)) && nt < FIT_NARROW_SIGMA;
-    flagged = flagged || (active && ((D >= epsf - epsm && D < epsf + epsm) || (j < NP && denl >= 0.0f) || narrow || kk >= FIT_SLOW_ITERATIONS));
+    // ... and spots whose iteration does not contract.  The update treats every parameter on its own (a diagonal Newton
+    // step), so photons, background and width — which trade against each other, the more the wider the spot is in its
+    // box — over-correct jointly: the iteration map has an alternating mode, and where its factor reaches 1 a rounding
+    // difference doubles from one iteration to the next instead of dying out (the two arithmetics end 1e-3 px and more
+    // apart on equal iteration counts, every single decision taken far from eps).  The mode shows in a parameter's step
+    // sequence d_k as a second difference w_k = d_k - 2 d_{k-1} + d_{k-2} that changes sign every iteration without
+    // shrinking; FIT_WOBBLE_RUN such iterations in a row flag the spot (a damped wobble, factor < FIT_WOBBLE_RATIO, is
+    // what a healthy fit shows while its step clamps release)
+    const float step = role.th - nt;
+    const float w = kk >= 2 ? (step - 2.0f * role.prev) + role.prev2 : 0.0f;
+    const bool wob = j < NP && w * role.wprev < 0.0f && fabsf(w) > FIT_WOBBLE_RATIO * fabsf(role.wprev)
+                     && fabsf(w) > FIT_WOBBLE_FLOOR * fabsf(nt);
+    const int run = wob ? role.run + 1 : 0;
+    const bool swing = run >= FIT_WOBBLE_RUN;
+    if (active) { role.run = run; role.wprev = w; role.prev2 = role.prev; role.prev = step; }
+    // ... and spots with a pixel whose count is far off the model (|data / model - 1| or |data / model^2| beyond
+    // FIT_TOP_FLAG: a model pinned at the 0.01 floors under negative or bright pixels): the sums then cancel from terms
+    // orders of magnitude above the result and their float32 rounding moves the step by more than any margin
+    const bool wild = top >= FIT_TOP_FLAG;
+    const unsigned why = ((D >= epsf - epsm && D < epsf + epsm) ? FLAG_MARGIN : 0u) | ((j < NP && denl >= 0.0f) ? FLAG_CURVATURE : 0u)
+                         | (narrow ? FLAG_NARROW : 0u) | (swing ? FLAG_SWING : 0u) | (wild ? FLAG_WILD : 0u)
+                         | (kk >= FIT_SLOW_ITERATIONS ? FLAG_SLOW : 0u);
+    flags |= active ? why : 0u;
     // the previous-iteration values the reference compares with ARE th (old_x = theta after every pass);
     // finished groups keep their state
     role.th = active ? nt : role.th;
@@ -351,7 +384,8 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
         if (NP == 6) th[5] = t1.y;
     }
     kk += active ? 1 : 0;
-    flagged = flagged || (active && !conv && kk >= max_it && D == D);      // ran into max_it: chaotic in float32
+    // (a fit that runs into max_it needs no flag of its own: with max_it above FIT_SLOW_ITERATIONS it carries the
+    // slow-fit flag, below it the count says nothing about the fit — at max_it = 5 most healthy fits end that way)
     return active && !(conv || kk >= max_it);
 }
 
@@ -360,7 +394,7 @@ template <int NP, int B>
 __device__ __forceinline__ LaneRole make_role(const float (&th)[6], const float (&ms)[6], int j)
 {
     LaneRole r;
-    r.ms = 0.f; r.th = 0.f;
+    r.ms = 0.f; r.th = 0.f; r.prev = 0.f; r.prev2 = 0.f; r.wprev = 0.f; r.run = 0;
 #pragma unroll
     for (int l = 0; l < 6; l++) { r.ms = (j == l) ? ms[l] : r.ms; r.th = (j == l) ? th[l] : r.th; }
     r.floor_ = j == 2 ? 1.0f : ((j == 3 || j == 4 || (NP == 6 && j == 5)) ? 0.01f : -INFINITY);
@@ -505,7 +539,8 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
     LaneRole role = make_role<NP, B>(th, ms, j);
     int kk = 0;
     int64_t sidx = -1;
-    bool active = false, flagged = false;
+    bool active = false;
+    unsigned flags = 0u;
     const unsigned long long below = (1ull << (lane & ~(GS - 1))) - 1ull;     // lanes of lower groups
 
     for (;;) {
@@ -519,15 +554,17 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
         if (__popcll(pend) >= REFILL_K || (pend != 0 && !any_active) || (empty != 0 && next < end)) {
             // finished groups publish theta / iteration count, then take the next spots of the chunk
             // (the curvature flag is per parameter lane: any lane of the group flags the spot)
-            constexpr unsigned long long gmask = GS == 8 ? 0xffull : 0xffffull;
-            const bool gflag = ((__ballot(flagged) >> (lane & ~(GS - 1))) & gmask) != 0;
+            const unsigned gflag = gor_u<GS>(flags);
             if (!active && sidx >= 0 && j == 0) {
                 float *to = p.thetas + sidx * 6;
 #pragma unroll
                 for (int l = 0; l < 5; l++) to[l] = th[l];
                 to[5] = NP == 6 ? th[5] : th[4];
                 p.iterations[sidx] = kk;
-                if (gflag && p.flag_list) p.flag_list[atomicAdd(p.flag_count, 1u)] = (int32_t)sidx;
+                if (gflag && p.flag_list) {
+                    p.flag_list[atomicAdd(p.flag_count, 1u)] = (int32_t)sidx;
+                    count_flag_reasons(p.flag_reasons, gflag);
+                }
             }
             const unsigned long long want = pend | empty;
             const int64_t cand = next + __popcll(want & below);
@@ -542,7 +579,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
                     load_row<B, FROM_MOVIE>(p, sidx, j, rowok, d);
                     role = make_role<NP, B>(th, ms, j);
                     kk = 0;
-                    flagged = false;
+                    flags = 0u;
                     active = p.max_it > 0;
                     if (!active && j == 0) {          // max_it == 0: the initial theta is the result
                         float *to = p.thetas + sidx * 6;
@@ -562,7 +599,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
         } else if (!any_active) {
             break;                                     // nothing running, nothing pending, chunk exhausted
         }
-        active = newton_step<NP, B>(d, th, role, xs, j, rowok, active, kk, p.eps, p.max_it, p.eps_lo, p.eps_hi, flagged);
+        active = newton_step<NP, B>(d, th, role, xs, j, rowok, active, kk, p.eps, p.max_it, p.eps_lo, p.eps_hi, flags);
     }
 }
 

@@ -35,10 +35,12 @@ enum ScratchSlot {
     SCR_ROWS,             // rows the fit stages of the fused pipelines may touch
     SCR_NARROW,           // uint16 copy of a chunk of a 32-bit movie (identify)
     SCR_GATES,            // per-chunk flags of that copy
+    SCR_STATS,            // flag statistics of the last MLE fit (re-fit count, count per criterion)
     SCR_NUM
 };
 int scratch(int slot, size_t bytes, void **ptr);
 int scratch_release_all();
+unsigned scratch_generation();      // bumped whenever buffers are released: pointers taken before are stale
 // Fused pipelines: *d_rows = *d_total if it fits the caller's capacity, else 0 (the identification columns were not
 // written; the caller sees *d_total > cap and resubmits), so that the fit stages never follow stale rows.
 int rows_to_fit(const int64_t *d_total, int64_t cap, const int64_t **d_rows, hipStream_t s);

@@ -30,15 +30,19 @@ struct ScratchBuf { void *p = nullptr; size_t bytes = 0; };
 // scanned) gives each its own scratch (pmi_scratch_bank); everything else lives in bank 0.
 constexpr int SCR_BANKS = 2;
 static ScratchBuf g_scratch_banks[SCR_BANKS][SCR_NUM];
-static int g_scratch_bank = 0;
+// the bank is a property of the calling thread: two host threads that drive two streams select a bank each
+// (pmi_scratch_bank) and never see each other's records or fit state
+static thread_local int g_scratch_bank = 0;
 static std::mutex g_scratch_mu;
+static unsigned g_scratch_generation = 0;
+unsigned scratch_generation() { std::lock_guard<std::mutex> lk(g_scratch_mu); return g_scratch_generation; }
 
 int scratch(int slot, size_t bytes, void **ptr)
 {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     ScratchBuf &b = g_scratch_banks[g_scratch_bank][slot];
     if (b.bytes < bytes) {
-        if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
+        if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; g_scratch_generation++; }
         size_t want = bytes + bytes / 4 + 4096;   // headroom so repeated calls stop reallocating
         PMI_HIP(hipMalloc(&b.p, want));
         b.bytes = want;
@@ -50,6 +54,7 @@ int scratch(int slot, size_t bytes, void **ptr)
 int scratch_release_all()
 {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
+    g_scratch_generation++;
     for (auto &bank : g_scratch_banks)
         for (auto &b : bank)
             if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
@@ -58,7 +63,6 @@ int scratch_release_all()
 int scratch_select_bank(int bank)
 {
     if (bank < 0 || bank >= SCR_BANKS) { set_error("scratch bank %d out of range", bank); return PMI_ERR_ARG; }
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
     g_scratch_bank = bank;
     return PMI_OK;
 }

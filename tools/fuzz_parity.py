@@ -1,7 +1,7 @@
 """Randomised differential test: GPU path vs the CPU oracle over random shapes, boxes, dtypes, ROIs,
 frame bounds and thresholds (identify: bit-exact), random spots (gaussmle: every row on the oracle's iteration count and within 1e-3 px; gausslq: tolerances of
 tests/test_gpu_parity.py) and random tables (render: ordered sums).  Prints every mismatch.
-usage: python tools/fuzz_parity.py [seconds] [seed]"""
+usage: python tools/fuzz_parity.py [seconds] [seed] [kinds: identify,mle,lq,render]"""
 import sys
 import time
 
@@ -13,6 +13,7 @@ from picasso_amd import backend as be  # noqa: E402
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+kinds = set((sys.argv[3] if len(sys.argv) > 3 else "identify,mle,lq,render").split(","))
 rng = np.random.default_rng(seed)
 t_end = time.time() + budget
 fails = 0
@@ -47,6 +48,9 @@ def random_movie(dtype, F, Y, X):
 
 while time.time() < t_end:
     which = rng.integers(0, 10)
+    kind = "identify" if which < 5 else ("mle" if which < 7 else ("lq" if which < 9 else "render"))
+    if kind not in kinds:
+        continue
     try:
         if which < 5:
             dtype = [np.uint16, np.uint16, np.uint16, np.uint8, np.int16, np.float32, np.uint32, np.int32][rng.integers(0, 8)]
@@ -72,8 +76,8 @@ while time.time() < t_end:
                 fails += 1
                 print("IDENTIFY MISMATCH", dtype.__name__, (F, Y, X), box, roi, fb, min_ng, len(a[0]), len(b[0]), flush=True)
         elif which < 7:
-            box = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17, 21]))
-            n = 64
+            box = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 17, 19, 21]))
+            n = 2048
             c = box // 2
             idx = np.arange(box)
             spots = np.empty((n, box, box), np.float32)
@@ -85,8 +89,8 @@ while time.time() < t_end:
                 spots[i] = rng.poisson(rng.uniform(20, 9000) * np.outer(gy, gx) + rng.uniform(0.05, 60))
             spots -= np.float32(rng.choice([0.0, 0.0, 3.0]))                       # sometimes negative pixels
             method = ["sigmaxy", "sigma"][rng.integers(0, 2)]
-            eps = float(rng.choice([1e-3, 1e-3, 1e-2]))
-            max_it = int(rng.choice([100, 100, 5]))
+            eps = float(rng.choice([1e-3, 1e-3, 1e-2, 1e-4, 3e-3, 1e-5]))
+            max_it = int(rng.choice([100, 100, 5, 20, 1000 if box <= 9 else 300]))
             th, cr, ll, it = be.gaussmle_arrays(spots, eps, max_it, method)
             oth, ocr, oll, oit = orc.gaussmle(spots, eps, max_it, method, threads=4)
             counts["mle"] += 1
@@ -97,14 +101,16 @@ while time.time() < t_end:
             bad = 0
             if not same.all():
                 bad = 1
-            if fin.any() and np.max(np.abs(th[fin][:, [0, 1, 4, 5]] - oth[fin][:, [0, 1, 4, 5]])) > 1e-3:
-                bad = 2
+            if fin.any() and np.max(np.abs(th[fin][:, [0, 1, 4, 5]] - oth[fin][:, [0, 1, 4, 5]])) > max(1e-3, eps):
+                bad = 2      # (a coarser eps than 1e-3 leaves the converged position undetermined to eps)
             if bad:
                 fails += 1
                 dd = np.abs(th[:, [0, 1, 4, 5]] - oth[:, [0, 1, 4, 5]]).max(axis=1)
                 dd[~fin] = 0
                 w = int(np.argmax(dd))
-                print("MLE MISMATCH", bad, box, method, eps, max_it, "same", same.mean(), "maxdiff", dd[w], "it", it[w], oit[w],
+                if bad == 1:
+                    w = int(np.flatnonzero(~same)[0])
+                print("MLE MISMATCH", bad, box, method, eps, max_it, "rows differing", int((~same).sum()), "maxdiff", dd[w], "it", it[w], oit[w],
                       "gpu", np.round(th[w], 4), "orc", np.round(oth[w], 4), "sum", spots[w].sum(), "min", spots[w].min(), flush=True)
         elif which < 9:
             box = int(rng.choice([3, 5, 7, 9, 11, 13]))

@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--method", default="sigmaxy")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra instrumented steps for per-kernel time")
+    ap.add_argument("--allow-env", action="store_true",
+                    help="run although PMI_* / PICASSO_AMD_LIB tuning variables are set (they are echoed in the line)")
     ap.add_argument("--serial-gather", action="store_true",
                     help="N > 1: wait for each step's all-gather before the next step computes (no overlap)")
     return ap.parse_args()
@@ -73,6 +75,11 @@ def launch_ranks(args):
 
 def main():
     args = parse()
+    # the library reads tuning / debugging variables from the environment (PMI_MLE_MODE, PMI_IDENTIFY_GENERIC, ...,
+    # PICASSO_AMD_LIB loads another build): a benchmark line measured under any of them is not the product's
+    overrides = {k: v for k, v in sorted(os.environ.items()) if k.startswith("PMI_") or k == "PICASSO_AMD_LIB"}
+    if overrides and not args.allow_env:
+        raise SystemExit(f"bench.py: tuning variables are set ({overrides}); unset them or pass --allow-env")
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         raise SystemExit(launch_ranks(args))
     import torch
@@ -152,7 +159,8 @@ def main():
             if os.environ.get("PMI_BENCH_TORCH_GATHER"):
                 raise RuntimeError("PMI_BENCH_TORCH_GATHER set")
             from picasso_amd.dist import NativeComm
-            comm = NativeComm.for_group(None)
+            comm = NativeComm.for_group(None, dev)
+            assert comm.info() == (world, rank), f"communicator {comm.info()} but the launch has world {world} rank {rank}"
             gstream = torch.cuda.Stream(device=dev)
             gather_impl = "pmi_allgather_locs (RCCL from libpicasso_hip.so)"
         except Exception as exc:      # noqa: BLE001 - any failure to set up the native communicator
@@ -167,16 +175,16 @@ def main():
             gather_impl = "torch.distributed all_gather_into_tensor (native communicator unavailable on another rank)"
     g_stream_ptr = ctypes.c_void_p(gstream.cuda_stream) if gstream is not None else None
 
-    def native_gather(k):
+    timeline = []          # per timed step: (compute start, compute end, gather end or None) events
+
+    def native_gather(k, ready):
         """gather set k on the side stream, after the kernels queued so far; returns the event that marks its end"""
-        ready = torch.cuda.Event()
-        ready.record(torch.cuda.current_stream(dev))
         gstream.wait_event(ready)
         rc = L.pmi_allgather_locs(comm._h, ctypes.c_void_p(tables[k].data_ptr()), _lib.PMI_LOC_COLUMNS, cap,
                                   ctypes.c_void_p(d_ns[k].data_ptr()), ctypes.c_void_p(gathered[k].data_ptr()),
                                   ctypes.c_void_p(gathered_n[k].data_ptr()), g_stream_ptr)
         _lib.check(rc, "pmi_allgather_locs")
-        done = torch.cuda.Event()
+        done = torch.cuda.Event(enable_timing=True)
         done.record(gstream)
         return done
 
@@ -189,13 +197,21 @@ def main():
                     w.wait()             # the compute stream waits for that gather; the host does not block
             pending[k] = None
 
-    def step(i):
+    def step(i, timed=False):
         k = i % nbuf
         drain(k)
+        cur = torch.cuda.current_stream(dev)
+        ev_a, ev_b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev_a.record(cur)
         run(tables[k], d_ns[k], cap)
+        ev_b.record(cur)
+        if timed:
+            timeline.append([ev_a, ev_b, None])
         if grouped:        # localization table of every shard on every GPU (RCCL over xGMI)
             if comm is not None:
-                pending[k] = native_gather(k)
+                pending[k] = native_gather(k, ev_b)
+                if timed:
+                    timeline[-1][2] = pending[k]
                 if nbuf == 1:
                     drain(k)
             elif nbuf == 1:
@@ -218,7 +234,7 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        step(i)
+        step(i, timed=True)
     drain_all()
     torch.cuda.synchronize()
     if grouped:
@@ -232,6 +248,19 @@ def main():
         assert counts[rank] == int(d_ns[last].item()) and all(0 < c <= cap for c in counts), counts
         mine = gathered[last].view(world, _lib.PMI_LOC_COLUMNS, cap)[rank, :, : counts[rank]]
         assert torch.equal(mine, tables[last][:, : counts[rank]]), "gathered table differs from the local one"
+    # where a rank's step went: kernels of the path (compute stream) and, beside them, the all-gather on its side stream
+    # (from the moment the step's table was ready to the end of the collective — it includes waiting for the slowest rank)
+    compute_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in timeline])) if timeline else float("nan")
+    gather_ms = float(np.mean([b.elapsed_time(g) for _, b, g in timeline if g is not None])) if any(g is not None for _, _, g in timeline) else None
+    per_rank = None
+    if grouped:
+        mine_t = torch.tensor([compute_ms, gather_ms if gather_ms is not None else float("nan")], dtype=torch.float64, device=dev)
+        all_t = torch.empty((world, 2), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(all_t, mine_t)
+        all_h = all_t.cpu().tolist()
+        per_rank = {"compute_ms": [round(r[0], 4) for r in all_h],
+                    "gather_ms": [None if r[1] != r[1] else round(r[1], 4) for r in all_h],
+                    "gather_bytes_received_per_step": world * _lib.PMI_LOC_COLUMNS * cap * 4 + 8 * world}
     et = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     nt = torch.tensor([int(d_n.item())], dtype=torch.int64, device=dev)
     if grouped:
@@ -297,13 +326,16 @@ def main():
                        "eps": 1e-3, "max_it": 100, "localizations_total": n_total,
                        "mle_mode": mle_mode, "refit_margin": mle_margin, "refit_spots_rank0": refit,
                        "all_gather": gather_impl,
-                       "sharding": f"frames x{world}"},
+                       "sharding": f"frames x{world}", "per_rank": per_rank, "env_overrides": overrides},
             "roofline": roofline,
             "cpu_baseline": cpu,
         }
         print(json.dumps(result), flush=True)
     if grouped:
         dist.barrier()
+        if comm is not None:
+            from picasso_amd.dist import NativeComm
+            NativeComm.close_all()
         dist.destroy_process_group()
     return result
 

@@ -108,6 +108,10 @@ int pmi_identify(const void *movie, int dtype, int64_t F, int64_t Y, int64_t X,
                  int32_t *out_frame, int32_t *out_y, int32_t *out_x, float *out_ng,
                  int64_t cap, int64_t *out_n);
 
+/* 32-bit movies that hold 16-bit counts pass through a uint16 copy, `frames` frames at a time (0 = default: as many as
+ * fit 1 GiB).  A memory knob; the table does not depend on it. */
+int pmi_identify_set_narrow_chunk(int64_t frames);
+
 /* Device form.  d_out_n is a device int64 receiving the row count (rows beyond
  * cap are counted but not written).  Nothing is synchronised. */
 int pmi_identify_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
@@ -304,6 +308,10 @@ int pmi_rcc_pair_list(const double *segments, int64_t n_seg, int64_t Y, int64_t 
  * The reference has no distributed code; its workers split the movie frame by frame inside one process
  * (picasso/localize.py:438-454).  Here each GPU (one process per GPU) localizes a contiguous frame range and the
  * tables are all-gathered with RCCL, called from this library (loaded at the first pmi_comm_* call).
+ *   pmi_comm_available  PMI_OK when RCCL and the entry points used here resolve on this rank; creates nothing.  A
+ *                       host AGREES on this over its own channel before any rank enters pmi_comm_init: the
+ *                       communicator set-up is itself a collective, and a rank that cannot join it leaves the others
+ *                       waiting inside ncclCommInitRank;
  *   pmi_comm_unique_id  rank 0 fills a 128-byte id, which the HOST hands to every rank (file, socket, MPI, ...);
  *   pmi_comm_init       every rank, on its own device (pmi_set_device first);
  *   pmi_allgather_locs  d_table: this rank's ncols x cap column-major table of 4-byte cells (PMI_LOC_COLUMNS or
@@ -312,6 +320,7 @@ int pmi_rcc_pair_list(const double *segments, int64_t n_seg, int64_t Y, int64_t 
  *                       One grouped submission on `stream`, asynchronous, no host synchronisation;
  *   pmi_compact_gathered_dev  the gathered tables as ONE ncols x table_cap column-major table, rows in rank order
  *                       (= frame order for contiguous frame shards, picasso/gaussmle.py:1036), total in *d_total.  */
+int pmi_comm_available(void);
 int pmi_comm_unique_id(void *id128);
 int pmi_comm_init(const void *id128, int world, int rank, void **comm);
 int pmi_comm_info(void *comm, int *world, int *rank);

@@ -47,6 +47,7 @@ SYMBOLS = {
     "pmi_memcpy_d2h_async": (_i32, [_p, _p, _sz, _p]),
     "pmi_release_scratch": (_i32, []),
     "pmi_scratch_bank": (_i32, [_i32]),
+    "pmi_identify_set_narrow_chunk": (_i32, [_i64]),
     "pmi_identify": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p]),
     "pmi_identify_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _p, _p, _p, _p, _i64, _p, _p]),
     "pmi_net_gradient": (_i32, [_p, _i64, _i64, _p, _p, _i64, _i32, _p, _p, _p]),
@@ -84,6 +85,7 @@ SYMBOLS = {
     "pmi_rcc_pair_list": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _i64, _p, _p, _p, _p]),
     "pmi_peak_fit": (_i32, [_p, _i64, _i32, _p, _p]),
     "pmi_rcc_shifts": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _i64, _p, _p]),
+    "pmi_comm_available": (_i32, []),
     "pmi_comm_unique_id": (_i32, [_p]),
     "pmi_comm_init": (_i32, [_p, _i32, _i32, _p]),
     "pmi_comm_info": (_i32, [_p, _p, _p]),

@@ -97,6 +97,11 @@ __global__ void compact_gathered_kernel(const int32_t *__restrict__ src, const i
 
 extern "C" {
 
+int pmi_comm_available(void)
+{
+    return pmi::load_rccl();      // PMI_OK when librccl and the entry points used here resolve; nothing is created
+}
+
 int pmi_comm_unique_id(void *id128)
 {
     using namespace pmi;

@@ -971,7 +971,7 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
         const int64_t waves = (count + spots_per_wave - 1) / spots_per_wave;
         return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
     };
-    static const bool g16 = getenv("PMI_LQ_GROUP16") != nullptr;      // A/B: the 16-lane groups for boxes up to 7
+    static const bool g16 = tuning_env("PMI_LQ_GROUP16") != nullptr;      // A/B: the 16-lane groups for boxes up to 7
     if (p.box <= 7 && !g16) {
         // eight spots per wavefront: the scalar chains of the factorisation (norm updates, Householder scalings:
         // float64 divisions and square roots every lane of a group repeats) are shared by twice as many fits

@@ -503,7 +503,7 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     PMI_HIP(hipMemsetAsync(stats, 0, 64, s));
     p.flag_reasons = stats + 1;
     p.fisher = (double *)fptr;
-    static const char *menv = getenv("PMI_MLE_MARGIN");       // overrides the margin of pmi_mle_set_mode (tuning runs)
+    static const char *menv = tuning_env("PMI_MLE_MARGIN");       // overrides the margin of pmi_mle_set_mode (tuning runs)
     const double margin = menv ? atof(menv) : g_mle_margin;
     // The tested step |delta| is a difference of float32 coordinates near box/2, i.e. a multiple of their ulp: the
     // two arithmetics differ by a few ulps there, so the margin is never smaller than four of them
@@ -515,10 +515,10 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     const int ppl = (p.box * p.box + 63) / 64;
     const int64_t Ntotal = p.N;
     ScopedKernelTimer tm(s, &g_last_times.fit_ms);
-    static const bool force_wave_per_spot = getenv("PMI_FIT_WAVE_PER_SPOT") != nullptr;
+    static const bool force_wave_per_spot = tuning_env("PMI_FIT_WAVE_PER_SPOT") != nullptr;
     const bool g8 = !force_wave_per_spot && p.box <= 15;
     float *cut = nullptr;
-    static const bool no_keep = getenv("PMI_MLE_NO_KEEP") != nullptr;
+    static const bool no_keep = tuning_env("PMI_MLE_NO_KEEP") != nullptr;
     if (g8 && from_movie && mode != PMI_MLE_STRICT && !no_keep) {
         void *cptr = nullptr;
         if ((rc = scratch(SCR_STAGE_C, per_batch * (size_t)(p.box * p.box) * sizeof(float), &cptr)) != PMI_OK) return rc;

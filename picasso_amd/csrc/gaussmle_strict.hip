@@ -362,7 +362,7 @@ void launch_fit_strict(const FitParams &p, int method, bool from_movie, const in
 {
     // four / two / one spot per wavefront: the kernel is bound by instruction issue, not by the latency of one fit
     // (measured on config 2's 6 500 flagged spots: 16-lane groups 0.30 ms, 64-lane groups 0.45 ms)
-    static const char *genv = getenv("PMI_STRICT_LIST_GS");      // tuning: group size for the flagged-spot list
+    static const char *genv = tuning_env("PMI_STRICT_LIST_GS");      // tuning: group size for the flagged-spot list
     const int packed = p.box <= 7 ? 16 : (p.box <= 15 ? 32 : 64);
     const int gs = list ? std::max(packed, genv ? atoi(genv) : packed) : packed;
     if (method == PMI_MLE_SIGMAXY) {

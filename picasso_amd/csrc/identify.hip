@@ -26,6 +26,9 @@
 
 namespace pmi {
 
+// frames per chunk of the uint16 copy a 32-bit movie goes through (0 = as many as fit 1 GiB); pmi_identify_set_narrow_chunk
+static int64_t g_narrow_chunk_frames = 0;
+
 // float32 ops that must round exactly like the reference's unfused arithmetic.  They are
 // defined HERE, under the pragma above, so the instructions carry no `contract` flag
 // (the __f*_rn helpers of the HIP headers are compiled with contraction allowed).
@@ -449,12 +452,11 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
                                       d_tab, recs, cap, d_total, count, s, &fast);
         p.gate = nullptr;
         const bool wide = dtype == PMI_U32 || dtype == PMI_I32 || dtype == PMI_F32;
-        static const bool no_narrow = getenv("PMI_IDENTIFY_NO_NARROW") != nullptr;
+        static const bool no_narrow = tuning_env("PMI_IDENTIFY_NO_NARROW") != nullptr;
         if (rc == PMI_OK && !fast && wide && !no_narrow && ((uintptr_t)d_movie & 15) == 0 && ((Y * X) & 3) == 0) {
             // chunks of frames through a uint16 copy of at most 1 GiB
             const int64_t frame_px = Y * X;
-            const char *cenv = getenv("PMI_IDENTIFY_NARROW_CHUNK");             // frames per chunk (tests: several chunks on a small movie)
-            const int64_t chunk = cenv && atoll(cenv) > 0 ? atoll(cenv) : std::max<int64_t>(1, ((int64_t)1 << 29) / frame_px);
+            const int64_t chunk = g_narrow_chunk_frames > 0 ? g_narrow_chunk_frames : std::max<int64_t>(1, ((int64_t)1 << 29) / frame_px);
             const int64_t nchunks = (nf + chunk - 1) / chunk;
             void *tmp = nullptr, *gptr = nullptr;
             if ((rc = scratch(SCR_NARROW, (size_t)std::min<int64_t>(nf, chunk) * frame_px * 2 + 64, &tmp)) != PMI_OK) return rc;
@@ -549,6 +551,13 @@ __global__ __launch_bounds__(256) void net_gradient_kernel(const float *__restri
 }  // namespace pmi
 
 extern "C" {
+
+int pmi_identify_set_narrow_chunk(int64_t frames)
+{
+    if (frames < 0) { pmi::set_error("chunk length must not be negative"); return PMI_ERR_ARG; }
+    pmi::g_narrow_chunk_frames = frames;
+    return PMI_OK;
+}
 
 int pmi_identify_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X, int box, double min_ng,
                      const int64_t *roi4, int64_t f_lo, int64_t f_hi, int32_t *d_frame, int32_t *d_y,

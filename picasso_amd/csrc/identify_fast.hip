@@ -928,7 +928,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
                          const int *gate)
 {
     *handled = false;
-    static const bool force_generic = getenv("PMI_IDENTIFY_GENERIC") != nullptr;
+    static const bool force_generic = tuning_env("PMI_IDENTIFY_GENERIC") != nullptr;
     if (force_generic) return PMI_OK;
     const int h = box / 2;
     if (h < 1 || h > 8) return PMI_OK;
@@ -947,7 +947,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     }
     // narrow frames: several row ranges side by side in one wavefront instead of idle lanes
     const int nch = ((x0 & 7) + cx + 7) / 8;
-    static const bool no_pack = getenv("PMI_IDENTIFY_NOPACK") != nullptr;
+    static const bool no_pack = tuning_env("PMI_IDENTIFY_NOPACK") != nullptr;
     int pack = 1;
     if (h >= 2 && h <= 6 && !no_pack) {
         if (nch <= 8 && h == 3) pack = 8;              // <= 64 px wide: eight row ranges side by side
@@ -961,7 +961,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     // Rows per unit: long units amortise the 2H + 2 pipeline rows a unit spends on its halo, short ones balance the
     // persistent waves (every wave runs ceil(units / waves) units).  Pick the length with the least total work.
     const long long waves = (long long)g_fast_cus * 4 * fast_waves_per_simd(h);
-    static const int force_rbu = getenv("PMI_IDENTIFY_RBU") ? atoi(getenv("PMI_IDENTIFY_RBU")) : 0;
+    static const int force_rbu = tuning_env("PMI_IDENTIFY_RBU") ? atoi(tuning_env("PMI_IDENTIFY_RBU")) : 0;
     int best_rbu = 0;
     double best_cost = 0.0;
     const int full = (cy + pack - 1) / pack;
@@ -981,7 +981,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     const long long blocks = std::min<long long>(p.units, waves);
     p.upw = (int)((p.units + blocks - 1) / blocks);
     p.lin_rows = 0; p.lin_total = 0;
-    static const bool no_lin = getenv("PMI_IDENTIFY_NOLIN") != nullptr;
+    static const bool no_lin = tuning_env("PMI_IDENTIFY_NOLIN") != nullptr;
     if (pack == 1 && !no_lin && force_rbu <= 0) {
         // one row range per lane set: every wave the same number of consecutive rows (at least 64: a run pays 2h + 2
         // halo rows at its start)
@@ -1026,7 +1026,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
         p.filt_alpha = 0.0f; p.filt_t = -1.0f; p.filt_slack = 0;
         p.filt_kr = p.filt_kc = p.filt_krc = 0.0f;
     }
-    static const int dbg = getenv("PMI_IDENTIFY_DBG") ? atoi(getenv("PMI_IDENTIFY_DBG")) : 0;
+    static const int dbg = tuning_env("PMI_IDENTIFY_DBG") ? atoi(tuning_env("PMI_IDENTIFY_DBG")) : 0;
     p.dbg = dbg;
     int rc;
     switch (h) {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include "../../include/picasso_hip.h"
@@ -10,6 +11,15 @@
 #define PMI_WAVE 64
 
 namespace pmi {
+
+// Launch-shape and debugging variables (PMI_IDENTIFY_*, PMI_FIT_*, PMI_LQ_*, ...) are honoured only by a tuning build
+// (make TUNING=1 -> -DPMI_TUNING): the shipped library reads none of them, so nothing in the environment can make it
+// skip work or take another kernel.  (PMI_MLE_MODE, documented in picasso_hip.h, is the one variable it reads.)
+#ifdef PMI_TUNING
+inline const char *tuning_env(const char *name) { return getenv(name); }
+#else
+inline const char *tuning_env(const char *) { return nullptr; }
+#endif
 
 void set_error(const char *fmt, ...);
 int hip_fail(hipError_t e, const char *what, const char *file, int line);

@@ -29,12 +29,26 @@ def shard_frames(n_frames: int, world: int, rank: int) -> Tuple[int, int]:
     return lo, hi
 
 
+class NativeCommUnavailable(RuntimeError):
+    """Raised on EVERY rank of a group when some rank cannot take part in the library's RCCL communicator; callers
+    fall back to torch.distributed's collectives."""
+
+
+def _agree(ok: bool, device, group=None) -> bool:
+    """True on every rank iff `ok` on every rank (all-reduce MIN over the group's own backend)."""
+    t = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(t.item()))
+
+
 class NativeComm:
     """RCCL communicator owned by libpicasso_hip.so (pmi_comm_init): the all-gather of the localization tables
     runs inside the library (pmi_allgather_locs + pmi_compact_gathered_dev), torch.distributed only carries the
     128-byte id from rank 0 to the others — the part a host without torch does with a file or a socket."""
 
-    _cache = {}
+    # (group object, communicator or the exception that said why there is none): the group object itself is kept (a
+    # strong reference), so its identity cannot be reused by a later group while the entry stands
+    _cache = []
 
     def __init__(self, world: int, rank: int, id_bytes: bytes):
         import ctypes
@@ -46,6 +60,14 @@ class NativeComm:
         _lib.check(_lib.load().pmi_comm_init(buf, self.world, self.rank, ctypes.byref(self._h)), "pmi_comm_init")
 
     @staticmethod
+    def available() -> bool:
+        from . import _lib
+        try:
+            return _lib.load().pmi_comm_available() == 0
+        except Exception:      # noqa: BLE001 - a library that does not load is "not available"
+            return False
+
+    @staticmethod
     def unique_id() -> bytes:
         import ctypes
 
@@ -55,22 +77,68 @@ class NativeComm:
         return buf.raw
 
     @classmethod
-    def for_group(cls, group=None):
-        """The communicator that mirrors a torch.distributed group (made once per group)."""
-        key = id(group)
-        if key not in cls._cache:
-            world, rank = dist.get_world_size(group), dist.get_rank(group)
-            box = [None]
-            if rank == 0:
-                try:
-                    box[0] = cls.unique_id()
-                except Exception as exc:      # noqa: BLE001 - every rank must leave the broadcast below the same way
-                    box[0] = f"error: {exc}".encode()
-            dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            if not isinstance(box[0], (bytes, bytearray)) or len(box[0]) != 128:
-                raise RuntimeError(f"no RCCL unique id from rank 0 ({box[0]!r})")
-            cls._cache[key] = cls(world, rank, box[0])
-        return cls._cache[key]
+    def for_group(cls, group=None, device=None):
+        """The communicator that mirrors a torch.distributed group (made once per group).  Collective: every rank of
+        the group calls it.  The ranks agree, over the group itself, that each of them can load RCCL BEFORE any of
+        them enters ncclCommInitRank (a rank that cannot join would leave the others waiting inside it), that rank 0
+        produced an id, and that every rank's communicator came up; on any "no" every rank raises
+        NativeCommUnavailable and the callers take torch.distributed's collectives instead."""
+        pg = group if group is not None else dist.distributed_c10d._get_default_group()
+        for g, entry in cls._cache:
+            if g is pg:
+                if isinstance(entry, Exception):
+                    raise entry
+                return entry
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        if device is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+
+        def give_up(why):
+            exc = NativeCommUnavailable(why)
+            cls._cache.append((pg, exc))
+            raise exc
+
+        if not _agree(cls.available(), device, group):
+            give_up("RCCL cannot be loaded from libpicasso_hip.so on some rank")
+        box = [None]
+        if rank == 0:
+            try:
+                box[0] = cls.unique_id()
+            except Exception as exc:      # noqa: BLE001 - every rank must leave the broadcast below the same way
+                box[0] = f"error: {exc}".encode()
+        dist.broadcast_object_list(box, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+        if not isinstance(box[0], (bytes, bytearray)) or len(box[0]) != 128:
+            give_up(f"no RCCL unique id from rank 0 ({box[0]!r})")        # the same verdict on every rank: it was broadcast
+        comm, err = None, None
+        try:
+            comm = cls(world, rank, box[0])
+            w, r = comm.info()
+            if (w, r) != (world, rank):
+                raise RuntimeError(f"communicator reports world {w} rank {r}, the group has world {world} rank {rank}")
+        except Exception as exc:      # noqa: BLE001
+            err = exc
+        if not _agree(err is None, device, group):
+            if comm is not None:
+                comm.close()
+            give_up(f"pmi_comm_init failed on some rank ({err})" if err else "pmi_comm_init failed on another rank")
+        cls._cache.append((pg, comm))
+        return comm
+
+    @classmethod
+    def close_all(cls):
+        """Destroys the cached communicators (call before dist.destroy_process_group)."""
+        for _, entry in cls._cache:
+            if isinstance(entry, NativeComm):
+                entry.close()
+        cls._cache.clear()
+
+    def info(self):
+        import ctypes
+
+        from . import _lib
+        w, r = ctypes.c_int(0), ctypes.c_int(0)
+        _lib.check(_lib.load().pmi_comm_info(self._h, ctypes.byref(w), ctypes.byref(r)), "pmi_comm_info")
+        return w.value, r.value
 
     def allgather_table(self, table: torch.Tensor, d_n: torch.Tensor, stream=None):
         """table: (C, cap) int32 on the GPU, the same cap on every rank; d_n: its device row count (int64).
@@ -117,8 +185,15 @@ def allgather_table(table: torch.Tensor, n_rows, group=None) -> torch.Tensor:
     if not (dist.is_available() and dist.is_initialized()):
         return table[:, : int(n_rows)].clone()
     world = dist.get_world_size(group)
+    if table.element_size() != 4:
+        raise TypeError(f"allgather_table moves 4-byte cells, got {table.dtype}")
+    comm = None
     if table.is_cuda:
-        comm = NativeComm.for_group(group)
+        try:
+            comm = NativeComm.for_group(group, table.device)
+        except NativeCommUnavailable:      # raised on every rank alike: all of them take torch.distributed's path below
+            comm = None
+    if comm is not None:
         cap = _all_reduce_max_int(max(int(n_rows), 1), table.device, group)      # the same padded width on every rank
         send = torch.zeros((table.shape[0], cap), dtype=torch.int32, device=table.device)
         send[:, : int(n_rows)] = table[:, : int(n_rows)].view(torch.int32) if table.dtype != torch.int32 else table[:, : int(n_rows)]

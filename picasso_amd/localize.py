@@ -155,7 +155,7 @@ def identify(movie, minimum_ng: float, box: int, *, roi=None, frame_bounds=None,
         bar.close()
     ids = pd.concat(parts, ignore_index=True) if parts else _empty_identifications()
     if return_info:
-        info = {"Generated by": f"Picasso: v{__version__} Identify (picasso_amd HIP backend)",
+        info = {"Generated by": f"Picasso: v{__version__} Identify",
                 "Min. Net Gradient": minimum_ng, "Box Size": box, "ROI": roi, "Frame Bounds": frame_bounds}
         return ids, info
     return ids
@@ -271,7 +271,7 @@ def fit2D(movie, movie_info, camera_info: dict, identifications: pd.DataFrame, b
             locs = None
         else:
             locs = avgroi.locs_from_fits(identifications, avgroi.fit_spots(spots, progress_callback), box, em)
-    localize_info = {"Generated by": f"Picasso: v{__version__} Fit 2D (picasso_amd HIP backend)",
+    localize_info = {"Generated by": f"Picasso: v{__version__} Fit 2D",
                      "Fit method": fitting_method}
     if fitting_method == "gaussmle":
         localize_info["Convergence criterion"] = eps
@@ -303,9 +303,9 @@ def localize(movie, camera_info: dict, parameters: dict, *, roi=None, frame_boun
                                  progress_callback=identification_progress_callback)
         if callable(fit_progress_callback):
             fit_progress_callback(len(locs), len(locs))
-        identify_info = {"Generated by": f"Picasso: v{__version__} Identify (picasso_amd HIP backend)",
+        identify_info = {"Generated by": f"Picasso: v{__version__} Identify",
                          "Min. Net Gradient": min_ng, "Box Size": box, "ROI": roi, "Frame Bounds": frame_bounds}
-        fit_info = {"Generated by": f"Picasso: v{__version__} Fit 2D (picasso_amd HIP backend)",
+        fit_info = {"Generated by": f"Picasso: v{__version__} Fit 2D",
                     "Fit method": fitting_method}
         if fitting_method == "gaussmle":
             fit_info["Convergence criterion"] = eps
@@ -625,22 +625,16 @@ def localize_file(path: str, camera_info: dict, parameters: dict, *, fitting_met
 
     from . import io, postprocess
     movie, info = io.load_movie(path)
-    locs = localize_streamed(movie, camera_info, parameters, roi=roi, frame_bounds=frame_bounds,
-                             fitting_method=fitting_method, eps=eps, max_it=max_it, mle_method=mle_method)
-    localize_info = {"Generated by": f"Picasso: v{__version__} Localize (picasso_amd HIP backend)",
-                     "ROI": roi, "Box Size": parameters["Box Size"],
-                     "Min. Net Gradient": parameters["Min. Net Gradient"], "Fit method": fitting_method}
-    if fitting_method == "gaussmle":
-        localize_info["Convergence criterion"] = eps
-        localize_info["Max iterations"] = max_it
-    info = info + [localize_info | camera_info]
+    # the metadata the CLI saves: movie info + identify info + fit info (picasso/__main__.py:1086-1100, localize.py:1810)
+    locs, info = localize(movie, camera_info, parameters, roi=roi, frame_bounds=frame_bounds, movie_info=info,
+                          fitting_method=fitting_method, eps=eps, max_it=max_it, mle_method=mle_method, return_info=True)
     base = os.path.splitext(path)[0]
     out = base + suffix + ".hdf5"
     io.save_locs(out, locs, info)
     if drift and drift > 0:
         pinfo = info if lib.get_from_metadata(info, "Pixelsize") is not None else info + [{"Pixelsize": 130}]
         drift_table, locs = postprocess.undrift(locs, pinfo, drift, display=False)
-        info = info + [{"Generated by": f"Picasso: v{__version__} Undrift (picasso_amd HIP backend)", "Segmentation": drift,
+        info = info + [{"Generated by": f"Picasso v{__version__} Undrift", "Segmentation": drift,       # __main__.py:443-481
                         "Drift X": float(drift_table["x"].mean()), "Drift Y": float(drift_table["y"].mean())}]
         out = base + suffix + "_undrift.hdf5"
         io.save_locs(out, locs, info)

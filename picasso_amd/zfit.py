@@ -185,6 +185,6 @@ def zfit(locs: pd.DataFrame, info, *, calibration: dict, magnification_factor: f
                  progress_callback, abort_callback)
     if out is None:
         return None, None
-    new_info = {"Generated by": f"Picasso v{__version__} Fit 3D (picasso_amd HIP backend)",
+    new_info = {"Generated by": f"Picasso v{__version__} Fit 3D",
                 "Calibration path": calibration.get("Path", "N/A"), "Filter range": filter}
     return out, info + [new_info | calibration]

@@ -212,3 +212,59 @@ def test_pipelined_table_gather_single_process():
     g = pdist.PipelinedTableGather()
     g.submit(pieces[0][0], torch.tensor([11], dtype=torch.int64))
     assert g.finish() is None
+
+
+# ---------------------------------------------------------------------------
+# the native communicator's set-up: one rank that cannot join must not leave the others waiting
+# ---------------------------------------------------------------------------
+def _comm_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        # rank 1 "cannot load RCCL"; rank 0 could.  No rank may reach pmi_comm_init (here it would fail anyway: no GPU),
+        # and BOTH must learn that the native path is off — twice: the verdict is cached per group.
+        pdist.NativeComm.available = staticmethod(lambda: rank == 0)
+        pdist.NativeComm.unique_id = staticmethod(lambda: (_ for _ in ()).throw(AssertionError("id requested although a rank is out")))
+        seen = []
+        for _ in range(2):
+            try:
+                pdist.NativeComm.for_group(None, device=torch.device("cpu"))
+                seen.append("communicator")
+            except pdist.NativeCommUnavailable as exc:
+                seen.append(str(exc))
+        # second scenario on a fresh sub-group: every rank is able, rank 0 fails to make the id -> the same verdict everywhere
+        sub = dist.new_group([0, 1])
+        pdist.NativeComm.available = staticmethod(lambda: True)
+        pdist.NativeComm.unique_id = staticmethod(lambda: (_ for _ in ()).throw(RuntimeError("no id today")))
+        try:
+            pdist.NativeComm.for_group(sub, device=torch.device("cpu"))
+            seen.append("communicator")
+        except pdist.NativeCommUnavailable as exc:
+            seen.append(str(exc))
+        q.put((rank, seen))
+    except Exception as exc:
+        q.put((rank, repr(exc)))
+        raise
+    finally:
+        dist.barrier()
+        pdist.NativeComm.close_all()
+        dist.destroy_process_group()
+
+
+def test_native_comm_setup_agrees_before_any_rank_enters_rccl():
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_comm_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = dict(q.get(timeout=60) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for r in range(2):
+        seen = results[r]
+        assert isinstance(seen, list) and len(seen) == 3, seen
+        assert "cannot be loaded" in seen[0] and seen[1] == seen[0]
+        assert "no RCCL unique id from rank 0" in seen[2] and "no id today" in seen[2]

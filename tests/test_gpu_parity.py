@@ -359,11 +359,12 @@ def test_identify_plateaus_and_saturated_fiducials(be, orc, dtype, box):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.int32, np.uint32])
-def test_identify_wide_movies_holding_counts(be, orc, dtype, monkeypatch):
+def test_identify_wide_movies_holding_counts(be, orc, dtype):
     """32-bit movies whose pixels are 16-bit counts are narrowed to uint16 chunk by chunk and take the packed scan; a chunk
     with one pixel that is not such a count (a fraction, a negative, 65536, NaN) takes the generic kernel — the table is
     the reference's either way, chunk boundaries included."""
-    monkeypatch.setenv("PMI_IDENTIFY_NARROW_CHUNK", "3")
+    from picasso_amd import _lib
+    assert _lib.load().pmi_identify_set_narrow_chunk(3) == 0          # several chunks on a small movie
     rng = np.random.default_rng(21)
     base = rng.poisson(40, size=(11, 96, 272)).astype(np.float64)
     for f in range(11):
@@ -389,6 +390,7 @@ def test_identify_wide_movies_holding_counts(be, orc, dtype, monkeypatch):
             b = orc.identify(mov, min_ng, 7, roi=roi, threads=4)
             assert all(np.array_equal(p, q) for p, q in zip(a, b)), (dtype, min_ng, roi, len(a[0]), len(b[0]))
     assert len(b[0]) > 20
+    assert _lib.load().pmi_identify_set_narrow_chunk(0) == 0
 
 
 def test_identify_capacity_retry(be, orc, testdata_movie):

@@ -80,19 +80,18 @@ while time.time() < t_end:
             n = 2048
             c = box // 2
             idx = np.arange(box)
-            spots = np.empty((n, box, box), np.float32)
-            for i in range(n):
-                x0, y0 = c + rng.uniform(-1.5, 1.5, 2)
-                sx, sy = rng.uniform(0.5, 0.3 * box + 0.5, 2)
-                gx = np.exp(-0.5 * ((idx - x0) / sx) ** 2) / (np.sqrt(2 * np.pi) * sx)
-                gy = np.exp(-0.5 * ((idx - y0) / sy) ** 2) / (np.sqrt(2 * np.pi) * sy)
-                spots[i] = rng.poisson(rng.uniform(20, 9000) * np.outer(gy, gx) + rng.uniform(0.05, 60))
-            spots -= np.float32(rng.choice([0.0, 0.0, 3.0]))                       # sometimes negative pixels
+            x0 = c + rng.uniform(-1.5, 1.5, n); y0 = c + rng.uniform(-1.5, 1.5, n)
+            sx = rng.uniform(0.5, 0.3 * box + 0.5, n); sy = rng.uniform(0.5, 0.3 * box + 0.5, n)
+            gx = np.exp(-0.5 * ((idx[None, :] - x0[:, None]) / sx[:, None]) ** 2) / (np.sqrt(2 * np.pi) * sx[:, None])
+            gy = np.exp(-0.5 * ((idx[None, :] - y0[:, None]) / sy[:, None]) ** 2) / (np.sqrt(2 * np.pi) * sy[:, None])
+            spots = rng.poisson(rng.uniform(20, 9000, n)[:, None, None] * gy[:, :, None] * gx[:, None, :]
+                                + rng.uniform(0.05, 60, n)[:, None, None]).astype(np.float32)
+            spots -= rng.choice(np.float32([0.0, 0.0, 3.0]), n)[:, None, None]      # a third with negative pixels
             method = ["sigmaxy", "sigma"][rng.integers(0, 2)]
             eps = float(rng.choice([1e-3, 1e-3, 1e-2, 1e-4, 3e-3, 1e-5]))
             max_it = int(rng.choice([100, 100, 5, 20, 1000 if box <= 9 else 300]))
             th, cr, ll, it = be.gaussmle_arrays(spots, eps, max_it, method)
-            oth, ocr, oll, oit = orc.gaussmle(spots, eps, max_it, method, threads=4)
+            oth, ocr, oll, oit = orc.gaussmle(spots, eps, max_it, method, threads=orc.max_threads())
             counts["mle"] += 1
             same = it == oit
             # every row: the iteration count is the oracle's (borderline / chaotic fits are re-fitted on the device in the
@@ -112,6 +111,10 @@ while time.time() < t_end:
                     w = int(np.flatnonzero(~same)[0])
                 print("MLE MISMATCH", bad, box, method, eps, max_it, "rows differing", int((~same).sum()), "maxdiff", dd[w], "it", it[w], oit[w],
                       "gpu", np.round(th[w], 4), "orc", np.round(oth[w], 4), "sum", spots[w].sum(), "min", spots[w].min(), flush=True)
+                rows = np.flatnonzero(~same | (fin & (np.abs(th[:, [0, 1, 4, 5]] - oth[:, [0, 1, 4, 5]]).max(axis=1) > max(1e-3, eps))))
+                __import__("os").makedirs("gpurun_out/fuzz_fail", exist_ok=True)
+                np.savez_compressed(f"gpurun_out/fuzz_fail/mle_{seed}_{counts['mle']}.npz", spots=spots[rows], box=box, method=method, eps=eps,
+                                    max_it=max_it, theta_gpu=th[rows], theta_orc=oth[rows], it_gpu=it[rows], it_orc=oit[rows])
         elif which < 9:
             box = int(rng.choice([3, 5, 7, 9, 11, 13]))
             n = 64

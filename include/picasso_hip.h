@@ -190,8 +190,12 @@ int pmi_locs_from_fits_dev(const int32_t *d_frame, const int32_t *d_y, const int
  * identify -> fused cut+fit -> table, one asynchronous submission.  d_table is
  * one device block of PMI_LOC_COLUMNS * cap * 4 bytes (column c starts at
  * element c*cap).  d_out_n: device int64 row count.  When it comes back
- * larger than cap nothing was fitted and the table is untouched: resubmit
- * with cap >= *d_out_n.                                                     */
+ * larger than cap the table is untouched: resubmit with cap >= *d_out_n.
+ * Schedule: a large frame range is cut in two and the scan of the second half runs beside the fit of the first, on
+ * a stream of the library's that joins the caller's stream at the start of the call and is joined again before the
+ * table is written (the scan is bound by memory requests, the fit by VALU issue); the table is the same, bit for bit.
+ * pmi_localize_set_ranges(1) keeps a call on the caller's stream alone (2 = default).                  */
+int pmi_localize_set_ranges(int ranges);
 int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
                          int box, double min_ng, const int64_t *roi4, int64_t f_lo, int64_t f_hi,
                          double baseline, double sensitivity, double gain,
@@ -215,8 +219,18 @@ int pmi_net_gradient(const float *image, int64_t Y, int64_t X, const int32_t *y,
  * nfev (N, int32, may be NULL) are MINPACK's termination code and the number of
  * residual evaluations, what leastsq(full_output=1) would report.
  * The _dev forms queue five rounds of (Jacobian, step) and then WAIT for the stream once per batch of 2 Mi spots to
- * read how many fits need more (on photon data: none); they are asynchronous up to that point only.   */
+ * read how many fits need more (on photon data: none); they are asynchronous up to that point only.
+ * Arithmetic: the sums over the box^2 residual rows (column norms, Householder products, Q^T f) are tree
+ * reductions over the lanes of a spot's group; MINPACK adds them one after the other.  The two differ in the last
+ * bits of float64, which matters only where one of lmdif's tests (the gain ratio against 1e-4 / 0.25 / 0.75, the
+ * termination tests, lmpar's 10 % band, qrfac's pivot choice) is decided within those bits: every such spot is
+ * fitted AGAIN from its start values with the sums in MINPACK's order, inside the same call.
+ * pmi_gausslq_last_refit_count: how many spots of the calling thread's last call were.                       */
 int pmi_gausslq(const float *spots, int64_t N, int box, float *thetas, int32_t *info, int32_t *nfev);
+int pmi_gausslq_last_refit_count(int64_t *n_refit);
+/* ... and which test sent them there (n <= 7 counters: pivot choice, lmpar's band, 0.1 fnorm1 < fnorm, the gain-ratio
+ * thresholds, the ftol tests, a reduction at the noise level, the xtol test; a spot can carry several)        */
+int pmi_gausslq_last_tie_reasons(int64_t *counts, int n);
 int pmi_gausslq_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box, float *d_thetas,
                     int32_t *d_info, int32_t *d_nfev, void *stream);
 int pmi_gausslq_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
@@ -336,8 +350,9 @@ int pmi_compact_gathered_dev(const void *d_all_tables, const int64_t *d_all_coun
  * -inf, 0, 0], inf)) = least_squares(method="trf", jac="2-point"): the Trust Region Reflective algorithm
  * of scipy 1.15.3, restated for one thread per window (csrc/peakfit.hip).
  * pmi_peak_fit: rois (n, box, box) float64 -> popt (n, 5) = a, xc, yc, s, b and scipy's termination
- * status (1 gtol, 2 ftol, 3 xtol, 4 both, 0 max_nfev; -2: window minimum < 0, where curve_fit raises
- * "x0 is infeasible").
+ * status (1 gtol, 2 ftol, 3 xtol, 4 both; 0 max_nfev, where curve_fit raises RuntimeError; -2: window minimum
+ * < 0, where curve_fit raises "x0 is infeasible"; -3: a NaN or an infinity in the window, where curve_fit raises
+ * ValueError).
  * pmi_rcc_shifts: all of get_image_shift (:53-161) for a list of (i, j) pairs of the n_seg float64
  * images — correlation, centre crop, first maximum, window, fit — -> shift_yx (n_pairs, 2) = (-yc, -xc);
  * fit_status as above, or -1 where the reference returns (0, 0) without fitting (empty image, window

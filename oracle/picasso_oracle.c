@@ -35,6 +35,7 @@
  * Build: see oracle/Makefile (gcc -O2 -ffp-contract=off -fopenmp).
  */
 #include <math.h>
+#include <stdio.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -791,12 +792,20 @@ int orc_zfit(const float *sx, const float *sy, int64_t N, const double *cx7, con
 static const double LQ_EPSMCH = 2.220446049250313e-16;
 static const double LQ_DWARF = 2.2250738585072014e-308;
 
+/* PROBE (diagnostics only, default 0 = MINPACK's order): 1 adds the long sums of lmdif — column norms, Householder
+ * products, Q^T fvec — in REVERSE row order.  tools/probe_lq_order.py uses it to find the spots whose fit depends on
+ * the order of those sums, i.e. the spots the device must fit with MINPACK's own order. */
+static int g_lq_sum_reverse = 0, g_lq_trace = 0;
+void orc_lq_set_sum_order(int reverse) { g_lq_sum_reverse = reverse; }
+void orc_lq_set_trace(int on) { g_lq_trace = on; }
+
 static double enorm(int n, const double *x)
 {
     const double rdwarf = 3.834e-20, rgiant = 1.304e19;
     double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0;
     const double agiant = rgiant / (double)n;
-    for (int i = 0; i < n; i++) {
+    for (int ii = 0; ii < n; ii++) {
+        const int i = (g_lq_sum_reverse && n > 6) ? n - 1 - ii : ii;
         double xabs = fabs(x[i]);
         if (xabs > rdwarf && xabs < agiant) { s2 += xabs * xabs; }
         else if (xabs <= rdwarf) {
@@ -1015,7 +1024,8 @@ static void qrfac(int m, int n, double *a, int lda, int *ipvt, double *rdiag, do
             a[j + j * lda] += 1;
             for (int k = j + 1; k < n; k++) {
                 double sum = 0;
-                for (int i = j; i < m; i++) sum += a[i + j * lda] * a[i + k * lda];
+                if (g_lq_sum_reverse) for (int i = m - 1; i >= j; i--) sum += a[i + j * lda] * a[i + k * lda];
+                else for (int i = j; i < m; i++) sum += a[i + j * lda] * a[i + k * lda];
                 double temp = sum / a[j + j * lda];
                 for (int i = j; i < m; i++) a[i + k * lda] -= temp * a[i + j * lda];
                 if (rdiag[k] != 0) {
@@ -1070,7 +1080,8 @@ static int lmdif_spot(const float *spot, int size, double *x, double ftol, doubl
         for (int j = 0; j < n; j++) {
             if (fjac[j + j * ld] != 0) {
                 double sum = 0;
-                for (int i = j; i < m; i++) sum += fjac[i + j * ld] * wa4[i];
+                if (g_lq_sum_reverse) for (int i = m - 1; i >= j; i--) sum += fjac[i + j * ld] * wa4[i];
+                else for (int i = j; i < m; i++) sum += fjac[i + j * ld] * wa4[i];
                 double temp = -sum / fjac[j + j * ld];
                 for (int i = j; i < m; i++) wa4[i] += fjac[i + j * ld] * temp;
             }
@@ -1121,6 +1132,9 @@ static int lmdif_spot(const float *spot, int size, double *x, double ftol, doubl
                 delta = pnorm / 0.5;
                 par = 0.5 * par;
             }
+            if (g_lq_trace)
+                fprintf(stderr, "iter %d nfev %d par %.17g delta %.17g pnorm %.17g fnorm %.17g fnorm1 %.17g actred %.17g prered %.17g ratio %.17g xnorm %.17g ipvt %d%d%d%d%d%d\n",
+                        iter, nfev, par, delta, pnorm, fnorm, fnorm1, actred, prered, ratio, xnorm, ipvt[0], ipvt[1], ipvt[2], ipvt[3], ipvt[4], ipvt[5]);
             if (ratio >= 1e-4) {
                 for (int j = 0; j < n; j++) { x[j] = wa2[j]; wa2[j] = diag[j] * x[j]; }
                 for (int i = 0; i < m; i++) fvec[i] = wa4[i];

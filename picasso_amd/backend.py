@@ -158,6 +158,22 @@ def last_refit_count(stream=None) -> int:
     return int(n.value)
 
 
+def last_lq_refit_count() -> int:
+    """Spots the last least-squares call fitted a second time with MINPACK's summation order."""
+    n = ctypes.c_int64(0)
+    _lib.check(_lib.load().pmi_gausslq_last_refit_count(ctypes.byref(n)), "pmi_gausslq_last_refit_count")
+    return int(n.value)
+
+
+LQ_TIE_REASONS = ("pivot", "lmpar", "fnorm", "ratio", "ftol", "noise", "xtol", "rounds_first_pass", "rounds_second_pass")
+
+
+def last_lq_tie_reasons() -> dict:
+    c = (ctypes.c_int64 * len(LQ_TIE_REASONS))()
+    _lib.check(_lib.load().pmi_gausslq_last_tie_reasons(c, len(LQ_TIE_REASONS)), "pmi_gausslq_last_tie_reasons")
+    return {k: int(v) for k, v in zip(LQ_TIE_REASONS, c)}
+
+
 FLAG_REASONS = ("margin", "curvature", "narrow", "swing", "wild", "slow")
 
 

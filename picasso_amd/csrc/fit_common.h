@@ -71,6 +71,10 @@ struct FitParams {
     float *spots_out;      // g8_init from a movie: the photon values of every spot of the batch are kept here (batch-relative)
     const void *movie;
     const int32_t *frame, *y, *x;
+    // pixel hand-off (uint16 movies): where the scan's exact stage left the box rows of spot i — pix[slot[i]], box rows of
+    // box / 2 + 1 packed uint16 pairs — or slot[i] < 0 / slot == nullptr: read the movie
+    const uint32_t *pix;
+    const int32_t *slot;
     int dtype;
     int64_t Y, X;
     float baseline, sensitivity, gain;
@@ -105,10 +109,12 @@ constexpr int FIT_SLOW_ITERATIONS = 32;
 constexpr float FIT_NARROW_SIGMA = 0.3f;      // a fitted width below this (px) sends the spot to the re-fit
 // the alternating component of a parameter's step sequence (second difference) that changes sign without shrinking below
 // FIT_WOBBLE_RATIO of its previous size, above the rounding floor (FIT_WOBBLE_FLOOR x |value| = 16 float32 ulps), for
-// FIT_WOBBLE_RUN iterations in a row: the iteration is not contracting, re-fit (see newton_step, gaussmle_g8.hip)
+// FIT_WOBBLE_RUN iterations in a row — two in a row from iteration FIT_WOBBLE_LATE on, where a healthy fit's step clamps
+// have long released: the iteration is not contracting, re-fit (see newton_step, gaussmle_g8.hip)
 constexpr float FIT_WOBBLE_RATIO = 0.9f;
 constexpr float FIT_WOBBLE_FLOOR = 1.9073486e-6f;
 constexpr int FIT_WOBBLE_RUN = 3;
+constexpr int FIT_WOBBLE_LATE = 9;
 // max over the pixels of |data / model - 1| and |data / model^2| beyond which the float32 sums are not trusted: re-fit
 constexpr float FIT_TOP_FLAG = 16.0f;
 

@@ -201,6 +201,78 @@ __device__ __forceinline__ double enorm6(const double (&x)[6])
     return x3max * sqrt(s3);
 }
 
+// MINPACK enorm, one component at a time in the published order (the trial residuals are never stored)
+struct EnormAcc {
+    double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0, agiant;
+    __device__ __forceinline__ explicit EnormAcc(int n) : agiant(RGIANT / (double)n) {}
+    __device__ __forceinline__ void add(double xv)
+    {
+        const double xabs = fabs(xv);
+        if (xabs > RDWARF && xabs < agiant) { s2 += xabs * xabs; }
+        else if (xabs <= RDWARF) {
+            if (xabs > x3max) { double r = x3max / xabs; s3 = 1 + s3 * r * r; x3max = xabs; }
+            else if (xabs != 0) { double r = xabs / x3max; s3 += r * r; }
+        } else {
+            if (xabs > x1max) { double r = x1max / xabs; s1 = 1 + s1 * r * r; x1max = xabs; }
+            else { double r = xabs / x1max; s1 += r * r; }
+        }
+    }
+    __device__ __forceinline__ double norm() const
+    {
+        if (s1 != 0) return x1max * sqrt(s1 + (s2 / x1max) / x1max);
+        if (s2 != 0) {
+            if (s2 >= x3max) return sqrt(s2 * (1 + (x3max / s2) * (x3max * s3)));
+            return sqrt(x3max * ((s2 / x3max) + (x3max * s3)));
+        }
+        return x3max * sqrt(s3);
+    }
+};
+
+// ---- strict mode: the sums over the m rows in MINPACK's own (sequential) order ------------------------------------
+// The group kernels hold residual row r in lane r % GS, element r / GS, and add over the rows with DPP trees; MINPACK
+// adds them one after the other (enorm, qrfac's Householder products, Q^T fvec).  The two agree to the last bits of
+// float64 — which is everything except where one of lmdif's accept / reject / terminate tests is decided within those
+// bits.  Spots on which that happens (flagged by lq_step_kernel and qrfac_step below) are fitted again with these
+// forms: the rows go through LDS and every lane of the group adds them in row order.
+constexpr double LQ_RANK = 1e-3;             // |R_jj| / |column| below which the factor counts as rank deficient (re-fit)
+constexpr double LQ_TIE = 1e-12;              // relative distance of a decision from its threshold below which a spot is re-fitted
+__device__ __forceinline__ void grp_sync()
+{
+    __builtin_amdgcn_wave_barrier();
+    __threadfence_block();
+    __builtin_amdgcn_wave_barrier();
+}
+template <int GS, int E>
+__device__ __forceinline__ void rows_to_lds(const double (&v)[E], int lane, int m, double *buf)
+{
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int r = lane + GS * e;
+        if (r < m) buf[r] = v[e];
+    }
+    grp_sync();
+}
+template <int GS, int E>
+__device__ __forceinline__ double seq_sum(const double (&v)[E], int lane, int row_lo, int m, double *buf)
+{
+    rows_to_lds<GS, E>(v, lane, m, buf);
+    double acc = 0;
+#pragma unroll 8
+    for (int r = row_lo; r < m; r++) acc += buf[r];       // (the reads do not depend on acc: eight in flight per step)
+    grp_sync();
+    return acc;
+}
+template <int GS, int E>
+__device__ __forceinline__ double seq_enorm(const double (&v)[E], int lane, int row_lo, int m, double *buf)
+{
+    rows_to_lds<GS, E>(v, lane, m, buf);
+    EnormAcc acc(m - row_lo);
+#pragma unroll 4
+    for (int r = row_lo; r < m; r++) acc.add(buf[r]);
+    grp_sync();
+    return acc.norm();
+}
+
 // enorm over rows [row_lo, m) of a register column.  Mid-range components (all of
 // them, for finite photon data) take one reduction; the scaled accumulators of
 // MINPACK are only formed when a component is tiny, huge or NaN.
@@ -366,9 +438,11 @@ __device__ __forceinline__ void qrsolv(double *R, const int (&ipvt)[6], const do
 }
 
 // MINPACK lmpar.
+// tie: set when one of its tests (the Gauss-Newton step inside the region? the 10 % band around it reached?) is decided
+// within LQ_TIE of its threshold
 __device__ __forceinline__ void lmpar(double *R, const int (&ipvt)[6], const double (&diag)[6],
                                       const double (&qtb)[6], double delta, double &par, double (&x)[6],
-                                      double (&sdiag)[6])
+                                      double (&sdiag)[6], unsigned &tie)
 {
     double wa1[6], wa2[6];
     int nsing = 6;
@@ -394,6 +468,7 @@ __device__ __forceinline__ void lmpar(double *R, const int (&ipvt)[6], const dou
     for (int j = 0; j < 6; j++) wa2[j] = diag[j] * x[j];
     double dxnorm = enorm6(wa2);
     double fp = dxnorm - delta;
+    tie |= !(fabs(fp - 0.1 * delta) > LQ_TIE * (dxnorm + delta)) ? 2u : 0u;
     if (fp <= 0.1 * delta) { par = 0; return; }
     double parl = 0;
     if (nsing >= 6) {
@@ -434,6 +509,8 @@ __device__ __forceinline__ void lmpar(double *R, const int (&ipvt)[6], const dou
         dxnorm = enorm6(wa2);
         temp = fp;
         fp = dxnorm - delta;
+        tie |= (!(fabs(fabs(fp) - 0.1 * delta) > LQ_TIE * (dxnorm + delta))
+                || (parl == 0 && temp < 0 && !(fabs(fp - temp) > LQ_TIE * (dxnorm + delta)))) ? 2u : 0u;
         if (fabs(fp) <= 0.1 * delta || (parl == 0 && fp <= temp && temp < 0) || iter == 10) break;
 #pragma unroll
         for (int j = 0; j < 6; j++) { const int l = ipvt[j]; wa1[j] = get6(diag, l) * (get6(wa2, l) / dxnorm); }
@@ -455,15 +532,28 @@ __device__ __forceinline__ void lmpar(double *R, const int (&ipvt)[6], const dou
 
 // One column of MINPACK qrfac (pivot, Householder vector, update of the trailing
 // columns and of their running norms).  rdiag = wa1, wa = wa3.
-template <int GS, int E, int j>
+template <int GS, int E, int j, bool STRICT>
 __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], double (&wa3)[6], int (&ipvt)[6],
-                                           int lane, int m)
+                                           int lane, int m, double *sbuf, bool &tie)
 {
     int kmax = j;
     double best = wa1[j];
 #pragma unroll
     for (int k = j + 1; k < 6; k++)
         if (wa1[k] > best) { best = wa1[k]; kmax = k; }
+    if (!STRICT) {
+        // the pivot is the largest of the running column norms: a second candidate within their rounding error of it
+        // may be MINPACK's choice.  A running norm that was scaled down by q = wa1 / wa3 since it was last computed
+        // carries a relative error of ~ eps / q^2 (MINPACK itself recomputes it only when q^2 < 20 eps).
+        const double qb = best / wa3[kmax];
+        const double eb = LQ_TIE * (1.0 + 1e-3 / (qb * qb));
+#pragma unroll
+        for (int k = j; k < 6; k++) {
+            const double qk = wa1[k] / wa3[k];
+            const double ek = LQ_TIE * (1.0 + 1e-3 / (qk * qk));
+            if (k != kmax && !(fabs(wa1[k] - best) > (eb + ek) * best)) tie = tie || wa1[k] != 0 || best != 0;
+        }
+    }
 #pragma unroll
     for (int k = j + 1; k < 6; k++) {
         // selects, not a branch: a conditional swap sinks into stores through pointer phis
@@ -481,7 +571,7 @@ __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], 
         ipvt[j] = sw ? u : t;
         ipvt[k] = sw ? t : u;
     }
-    double ajnorm = enorm_rows<GS, E>(a[j], lane, j, m);
+    double ajnorm = STRICT ? seq_enorm<GS, E>(a[j], lane, j, m, sbuf) : enorm_rows<GS, E>(a[j], lane, j, m);
     if (ajnorm != 0) {
         if (Grp<GS>::bcast_d(a[j][0], j) < 0) ajnorm = -ajnorm;
 #pragma unroll
@@ -492,10 +582,17 @@ __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], 
 #pragma unroll
         for (int k = j + 1; k < 6; k++) {
             double sum = 0;
+            if (STRICT) {
+                double prod[E];
 #pragma unroll
-            for (int e = 0; e < E; e++)
-                if (e > 0 || lane >= j) sum += a[j][e] * a[k][e];
-            sum = Grp<GS>::sum_d(sum);
+                for (int e = 0; e < E; e++) prod[e] = a[j][e] * a[k][e];
+                sum = seq_sum<GS, E>(prod, lane, j, m, sbuf);
+            } else {
+#pragma unroll
+                for (int e = 0; e < E; e++)
+                    if (e > 0 || lane >= j) sum += a[j][e] * a[k][e];
+                sum = Grp<GS>::sum_d(sum);
+            }
             double temp = sum / ajj;
 #pragma unroll
             for (int e = 0; e < E; e++)
@@ -505,8 +602,9 @@ __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], 
                 const double t2 = 1 - temp * temp;
                 wa1[k] *= sqrt(t2 > 0 ? t2 : 0);
                 const double q = wa1[k] / wa3[k];
+                if (!STRICT && fabs(0.05 * (q * q) - EPSMCH) <= 1e-3 * EPSMCH) tie = true;      // recompute or not: decided in the noise
                 if (0.05 * (q * q) <= EPSMCH) {
-                    wa1[k] = enorm_rows<GS, E>(a[k], lane, j + 1, m);
+                    wa1[k] = STRICT ? seq_enorm<GS, E>(a[k], lane, j + 1, m, sbuf) : enorm_rows<GS, E>(a[k], lane, j + 1, m);
                     wa3[k] = wa1[k];
                 }
             }
@@ -524,22 +622,26 @@ __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], 
 // 63 spilled registers) was most of the kernel.  Here (b) runs ONE SPOT PER LANE in its own kernel, the state of a
 // fit travels through a scratch record (LqState), and the spots that need another Jacobian are compacted into the
 // list of the next round.
-constexpr int LQ_NSD = 64, LQ_NSI = 9;          // doubles / ints of state per spot
+constexpr int LQ_NSD = 64, LQ_NSI = 10;         // doubles / ints of state per spot
 struct LqState {                                 // structure of arrays, stride = spots of the batch
     double *d;                                   // [0..5] x  [6..11] diag  12 fnorm  13 delta  14 par  15 xnorm
                                                  // [16..51] R (row-major 6x6, upper)  [52..57] qtf  [58..63] acnorm
     int32_t *i;                                  // [0..5] ipvt  6 iter  7 nfev  8 info (-1 fresh, 0 running, > 0 done)
+                                                 // 9 tie: some decision of this fit was taken within rounding distance of its threshold
     int64_t stride, first;                       // state index of spot s = s - first
 };
 #define LQD(st, f, ls) (st).d[(int64_t)(f) * (st).stride + (ls)]
 #define LQI(st, f, ls) (st).i[(int64_t)(f) * (st).stride + (ls)]
 
 // (a): residuals at x, Jacobian, QR.  list == nullptr: spots [first, min(first + count, n)).
-template <int GS, int E, bool FROM_MOVIE>
+template <int GS, int E, bool FROM_MOVIE, bool STRICT>
 __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kernel(Params p, LqState st, const int32_t *__restrict__ list,
                                                                       const unsigned *__restrict__ list_n, int64_t count)
 {
     constexpr int NGRP = 64 / GS;                              // spots per wavefront
+    extern __shared__ __attribute__((aligned(16))) char s_rows[];      // strict mode: m doubles per group of the workgroup
+    double *sbuf = STRICT ? reinterpret_cast<double *>(s_rows) + (size_t)(((threadIdx.x >> 6) * NGRP) + (threadIdx.x & 63) / GS) * (size_t)(p.box * p.box)
+                          : nullptr;
     const int lane = (threadIdx.x & 63) % GS;                  // lane inside the group
     const int grp = (threadIdx.x & 63) / GS;
     const int64_t wave0 = (int64_t)blockIdx.x * LQ_WAVES + (threadIdx.x >> 6);
@@ -607,17 +709,26 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kerne
         // qrfac with column pivoting: rdiag = wa1, acnorm = wa2, wa = wa3
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            wa2[j] = enorm_rows<GS, E>(a[j], lane, 0, m);
+            wa2[j] = STRICT ? seq_enorm<GS, E>(a[j], lane, 0, m, sbuf) : enorm_rows<GS, E>(a[j], lane, 0, m);
             wa1[j] = wa2[j];
             wa3[j] = wa1[j];
             ipvt[j] = j;
         }
-        qrfac_step<GS, E, 0>(a, wa1, wa3, ipvt, lane, m);
-        qrfac_step<GS, E, 1>(a, wa1, wa3, ipvt, lane, m);
-        qrfac_step<GS, E, 2>(a, wa1, wa3, ipvt, lane, m);
-        qrfac_step<GS, E, 3>(a, wa1, wa3, ipvt, lane, m);
-        qrfac_step<GS, E, 4>(a, wa1, wa3, ipvt, lane, m);
-        qrfac_step<GS, E, 5>(a, wa1, wa3, ipvt, lane, m);
+        bool tie = false;
+        qrfac_step<GS, E, 0, STRICT>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
+        qrfac_step<GS, E, 1, STRICT>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
+        qrfac_step<GS, E, 2, STRICT>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
+        qrfac_step<GS, E, 3, STRICT>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
+        qrfac_step<GS, E, 4, STRICT>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
+        qrfac_step<GS, E, 5, STRICT>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
+        if (!STRICT) {
+            // a column of which less than LQ_RANK survives the projection on the columns before it: the Jacobian is
+            // close to rank deficient, the Gauss-Newton step amplifies the last bits of R and Q^T f by 1 / that ratio, and
+            // every later decision inherits the difference (a width that collapses or turns negative, nine residuals
+            // for six parameters): the sums' order decides the fit although no single test is close to its threshold
+#pragma unroll
+            for (int j = 0; j < 6; j++) tie = tie || !(fabs(wa1[j]) > LQ_RANK * get6(wa2, ipvt[j]));
+        }
         // (Q^T fvec)[0..6): row j of the transformed vector ends in lane j; R: row i in lane i
 #pragma unroll
         for (int e = 0; e < E; e++) w4[e] = (double)fv[e];
@@ -626,10 +737,17 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kerne
             const double ajj = Grp<GS>::bcast_d(a[j][0], j);
             if (ajj != 0) {
                 double sum = 0;
+                if (STRICT) {
+                    double prod[E];
 #pragma unroll
-                for (int e = 0; e < E; e++)
-                    if (e > 0 || lane >= j) sum += a[j][e] * w4[e];
-                sum = Grp<GS>::sum_d(sum);
+                    for (int e = 0; e < E; e++) prod[e] = a[j][e] * w4[e];
+                    sum = seq_sum<GS, E>(prod, lane, j, m, sbuf);
+                } else {
+#pragma unroll
+                    for (int e = 0; e < E; e++)
+                        if (e > 0 || lane >= j) sum += a[j][e] * w4[e];
+                    sum = Grp<GS>::sum_d(sum);
+                }
                 const double temp = -sum / ajj;
 #pragma unroll
                 for (int e = 0; e < E; e++)
@@ -643,6 +761,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kerne
             LQD(st, 52 + lane, ls) = w4[0];
             LQD(st, 58 + lane, ls) = get6(wa2, lane);
             LQI(st, lane, ls) = lane == 0 ? ipvt[0] : (lane == 1 ? ipvt[1] : (lane == 2 ? ipvt[2] : (lane == 3 ? ipvt[3] : (lane == 4 ? ipvt[4] : ipvt[5]))));
+            if (!STRICT && tie && lane == 0) LQI(st, 9, ls) = LQI(st, 9, ls) | 1;
         }
     }
 }
@@ -693,17 +812,20 @@ __global__ void lq_cut_kernel(Params p, int64_t first, int64_t count, float *__r
 }
 
 // start values (gausslq.py:95-112), one spot per lane, float64 sums in the reference's row-major order
+// list == nullptr: spots [first, first + count); else the *list_n spots of the list (the strict re-fit starts them again)
 template <bool FROM_MOVIE>
-__global__ __launch_bounds__(256) void lq_init_kernel(Params p, LqState st, int64_t count)
+__global__ __launch_bounds__(256) void lq_init_kernel(Params p, LqState st, int64_t count, const int32_t *__restrict__ list,
+                                                      const unsigned *__restrict__ list_n)
 {
     int64_t n = p.N;
     if (p.d_n) { const int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+    if (list) { const int64_t ln = (int64_t)*list_n; count = ln < count ? ln : count; }
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];      // [256] spot indices, then the tile of 256 x m floats
     int64_t (&s_idx)[256] = *reinterpret_cast<int64_t (*)[256]>(s_dyn);
     float *s_tile = reinterpret_cast<float *>(s_dyn + 256 * sizeof(int64_t));
     const int64_t w = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t s = st.first + w;
-    const bool mine = w < count && s < n;
+    const int64_t s = list ? (w < count ? (int64_t)list[w] : -1) : st.first + w;
+    const bool mine = w < count && s >= 0 && s < n;
     const int size = p.box, m = size * size, hsz = size / 2;
     const bool staged = m <= LQ_TILE_MAXPIX;
     s_idx[threadIdx.x] = mine ? s : -1;
@@ -745,38 +867,12 @@ __global__ __launch_bounds__(256) void lq_init_kernel(Params p, LqState st, int6
     const float t5 = (float)sqrt(sdy / sum), t4 = (float)sqrt(sdx / sum);
     t0 = t0 - (float)hsz;
     t1 = t1 - (float)hsz;
-    const int64_t ls = w;
+    const int64_t ls = s - st.first;
     LQD(st, 0, ls) = (double)t0; LQD(st, 1, ls) = (double)t1; LQD(st, 2, ls) = (double)t2; LQD(st, 3, ls) = (double)mn;
     LQD(st, 4, ls) = (double)t4; LQD(st, 5, ls) = (double)t5;
     LQI(st, 8, ls) = -1;                                        // fresh: lq_step_kernel starts its counters
+    LQI(st, 9, ls) = 0;
 }
-
-// MINPACK enorm, one component at a time in the published order (the trial residuals are never stored)
-struct EnormAcc {
-    double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0, agiant;
-    __device__ __forceinline__ explicit EnormAcc(int n) : agiant(RGIANT / (double)n) {}
-    __device__ __forceinline__ void add(double xv)
-    {
-        const double xabs = fabs(xv);
-        if (xabs > RDWARF && xabs < agiant) { s2 += xabs * xabs; }
-        else if (xabs <= RDWARF) {
-            if (xabs > x3max) { double r = x3max / xabs; s3 = 1 + s3 * r * r; x3max = xabs; }
-            else if (xabs != 0) { double r = xabs / x3max; s3 += r * r; }
-        } else {
-            if (xabs > x1max) { double r = x1max / xabs; s1 = 1 + s1 * r * r; x1max = xabs; }
-            else { double r = xabs / x1max; s1 += r * r; }
-        }
-    }
-    __device__ __forceinline__ double norm() const
-    {
-        if (s1 != 0) return x1max * sqrt(s1 + (s2 / x1max) / x1max);
-        if (s2 != 0) {
-            if (s2 >= x3max) return sqrt(s2 * (1 + (x3max / s2) * (x3max * s3)));
-            return sqrt(x3max * ((s2 / x3max) + (x3max * s3)));
-        }
-        return x3max * sqrt(s3);
-    }
-};
 
 constexpr int LQ_STEP_NT = 128;
 
@@ -785,7 +881,8 @@ constexpr int LQ_STEP_NT = 128;
 template <bool FROM_MOVIE>
 __global__ __launch_bounds__(LQ_STEP_NT) void lq_step_kernel(Params p, LqState st, const int32_t *__restrict__ list,
                                                              const unsigned *__restrict__ list_n, int64_t count,
-                                                             int32_t *__restrict__ next_list, unsigned *__restrict__ next_n)
+                                                             int32_t *__restrict__ next_list, unsigned *__restrict__ next_n,
+                                                             int32_t *__restrict__ tie_list, unsigned *__restrict__ tie_n)
 {
     // dynamic LDS: [NT] spot indices, the x profile of the current evaluation (box x NT floats), the tile of NT x m floats
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
@@ -865,6 +962,10 @@ __global__ __launch_bounds__(LQ_STEP_NT) void lq_step_kernel(Params p, LqState s
 #pragma unroll
     for (int j = 0; j < 6; j++) { qtf[j] = LQD(st, 52 + j, ls); wa2[j] = LQD(st, 58 + j, ls); ipvt[j] = LQI(st, j, ls); }
     nfev += 6;                                                 // the forward differences of this round
+    // tie: a decision of this fit fell within LQ_TIE of its threshold — here, in lmpar or in the pivoting of the Jacobian
+    // kernel (slot 9).  The group kernel's tree sums differ from MINPACK's sequential ones in the last bits of float64,
+    // so such a decision may be MINPACK's other branch: the spot is fitted again with sequential sums (tie_list).
+    unsigned tie = tie_list ? (unsigned)LQI(st, 9, ls) : 0u;       // bit 0: the pivot choice of the Jacobian kernel; 1: lmpar; 2..6 below
     double gnorm = 0, fnorm1, actred, prered, dirder, ratio, pnorm;
     if (iter == 1) {
 #pragma unroll
@@ -894,7 +995,7 @@ __global__ __launch_bounds__(LQ_STEP_NT) void lq_step_kernel(Params p, LqState s
         for (int j = 0; j < 6; j++)
             if (wa2[j] > diag[j]) diag[j] = wa2[j];
         for (;;) {
-            lmpar(R, ipvt, diag, qtf, delta, par, wa1, wa2);
+            lmpar(R, ipvt, diag, qtf, delta, par, wa1, wa2, tie);
 #pragma unroll
             for (int j = 0; j < 6; j++) { wa1[j] = -wa1[j]; wa2[j] = x[j] + wa1[j]; wa3[j] = diag[j] * wa1[j]; }
             pnorm = enorm6(wa3);
@@ -916,6 +1017,17 @@ __global__ __launch_bounds__(LQ_STEP_NT) void lq_step_kernel(Params p, LqState s
             dirder = -(temp1 * temp1 + temp2 * temp2);
             ratio = 0;
             if (prered != 0) ratio = actred / prered;
+            {
+                // actred = 1 - (fnorm1 / fnorm)^2 carries an absolute error of a few eps (1 + r^2); ratio divides it by prered
+                const double r1 = fnorm1 / fnorm;
+                const double ea = LQ_TIE * (1.0 + r1 * r1);
+                const double er = prered != 0 ? ea / prered + LQ_TIE * fabs(ratio) : 0.0;
+                tie |= (!(fabs(0.1 * fnorm1 - fnorm) > LQ_TIE * fnorm) ? 4u : 0u)
+                       | ((!(fabs(ratio - 0.25) > er) || (par != 0 && !(fabs(ratio - 0.75) > er)) || !(fabs(ratio - 1e-4) > er)
+                           || !(fabs(ratio - 2.0) > er)) ? 8u : 0u)
+                       | ((!(fabs(fabs(actred) - ftol) > ea) || !(fabs(prered - ftol) > LQ_TIE * prered)) ? 16u : 0u)
+                       | ((fabs(actred) <= 64 * ea && prered <= 64 * ea) ? 32u : 0u);        // reduction at the noise level: the EPSMCH tests
+            }
             if (ratio <= 0.25) {
                 double temp = 0.5;
                 if (actred < 0) temp = 0.5 * dirder / (dirder + 0.5 * actred);
@@ -934,6 +1046,7 @@ __global__ __launch_bounds__(LQ_STEP_NT) void lq_step_kernel(Params p, LqState s
                 fnorm = fnorm1;
                 iter++;
             }
+            tie |= !(fabs(delta - xtol * xnorm) > LQ_TIE * delta) ? 64u : 0u;
             if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1) info = 1;
             if (delta <= xtol * xnorm) info = 2;
             if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1 && info == 2) info = 3;
@@ -952,16 +1065,22 @@ __global__ __launch_bounds__(LQ_STEP_NT) void lq_step_kernel(Params p, LqState s
         if (p.info) p.info[s] = info;
         if (p.nfev) p.nfev[s] = nfev;
         LQI(st, 8, ls) = info;
+        if (tie && tie_list) {
+            tie_list[atomicAdd(tie_n, 1u)] = (int32_t)s;
+            for (int b = 0; b < 7; b++)
+                if (tie & (1u << b)) atomicAdd(tie_n + 1 + b, 1u);      // why (diagnostics: pmi_gausslq_last_tie_reasons)
+        }
     } else {
 #pragma unroll
         for (int j = 0; j < 6; j++) { LQD(st, j, ls) = x[j]; LQD(st, 6 + j, ls) = diag[j]; }
         LQD(st, 12, ls) = fnorm; LQD(st, 13, ls) = delta; LQD(st, 14, ls) = par; LQD(st, 15, ls) = xnorm;
         LQI(st, 6, ls) = iter; LQI(st, 7, ls) = nfev; LQI(st, 8, ls) = 0;
+        if (tie && tie_list) LQI(st, 9, ls) = (int32_t)tie;
         next_list[atomicAdd(next_n, 1u)] = (int32_t)s;
     }
 }
 
-template <bool FROM_MOVIE>
+template <bool FROM_MOVIE, bool STRICT>
 static void launch_jacobian(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count,
                             int cus, hipStream_t s)
 {
@@ -971,42 +1090,50 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
         const int64_t waves = (count + spots_per_wave - 1) / spots_per_wave;
         return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
     };
+    // strict mode: m doubles of LDS per group (the rows of one column at a time, summed in MINPACK's order)
+    auto lds_for = [&](int spots_per_wave) { return STRICT ? (size_t)LQ_WAVES * spots_per_wave * m * sizeof(double) : (size_t)0; };
     static const bool g16 = tuning_env("PMI_LQ_GROUP16") != nullptr;      // A/B: the 16-lane groups for boxes up to 7
+#define LQ_JAC(GS, E, SPW) hipLaunchKernelGGL((lq_jacobian_kernel<GS, E, FROM_MOVIE, STRICT>), grid_for(SPW), block, lds_for(SPW), s, p, st, list, list_n, count)
     if (p.box <= 7 && !g16) {
         // eight spots per wavefront: the scalar chains of the factorisation (norm updates, Householder scalings:
         // float64 divisions and square roots every lane of a group repeats) are shared by twice as many fits
-        const dim3 grid = grid_for(8);
-        if (m <= 16) hipLaunchKernelGGL((lq_jacobian_kernel<8, 2, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
-        else if (m <= 32) hipLaunchKernelGGL((lq_jacobian_kernel<8, 4, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
-        else hipLaunchKernelGGL((lq_jacobian_kernel<8, 7, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+        if (m <= 16) LQ_JAC(8, 2, 8);
+        else if (m <= 32) LQ_JAC(8, 4, 8);
+        else LQ_JAC(8, 7, 8);
     } else if (p.box <= 7) {
-        const dim3 grid = grid_for(4);
-        if (m <= 16) hipLaunchKernelGGL((lq_jacobian_kernel<16, 1, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
-        else if (m <= 32) hipLaunchKernelGGL((lq_jacobian_kernel<16, 2, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
-        else hipLaunchKernelGGL((lq_jacobian_kernel<16, 4, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+        if (m <= 16) LQ_JAC(16, 1, 4);
+        else if (m <= 32) LQ_JAC(16, 2, 4);
+        else LQ_JAC(16, 4, 4);
     } else if (p.box <= 15) {
-        const dim3 grid = grid_for(2);
-        if (m <= 96) hipLaunchKernelGGL((lq_jacobian_kernel<32, 3, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
-        else if (m <= 128) hipLaunchKernelGGL((lq_jacobian_kernel<32, 4, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
-        else if (m <= 192) hipLaunchKernelGGL((lq_jacobian_kernel<32, 6, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
-        else hipLaunchKernelGGL((lq_jacobian_kernel<32, 8, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+        if (m <= 96) LQ_JAC(32, 3, 2);
+        else if (m <= 128) LQ_JAC(32, 4, 2);
+        else if (m <= 192) LQ_JAC(32, 6, 2);
+        else LQ_JAC(32, 8, 2);
     } else {
         const int e = (m + 63) / 64;
-        const dim3 grid = grid_for(1);
-        if (e <= 5) hipLaunchKernelGGL((lq_jacobian_kernel<64, 5, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
-        else hipLaunchKernelGGL((lq_jacobian_kernel<64, 7, FROM_MOVIE>), grid, block, 0, s, p, st, list, list_n, count);
+        if (e <= 5) LQ_JAC(64, 5, 1);
+        else LQ_JAC(64, 7, 1);
     }
+#undef LQ_JAC
 }
 
 // Rounds of (Jacobian + QR, step) over the spots still running.  The first LQ_ROUNDS rounds are queued without
 // looking at the device; then the stream is synchronised once to read how many spots go on (on photon data: none —
-// a fit takes 2-4 outer iterations) and the stragglers get rounds of their own size until none is left.
+// a fit takes 2-4 outer iterations) and the stragglers get rounds of their own size until none is left.  The same
+// synchronisation returns the number of spots with a decision inside rounding distance of its threshold (tie list):
+// those are started again and fitted with MINPACK's summation order (strict Jacobian kernel), rounds sized to the list.
 #ifndef LQ_ROUNDS
 #define LQ_ROUNDS 5
 #endif
-#ifndef LQ_BATCH_LOG2
-#define LQ_BATCH_LOG2 21      // spots per batch (state: 548 B per spot); every batch ends with one host synchronisation
+#ifndef LQ_STRAGGLER_BURST
+#define LQ_STRAGGLER_BURST 24
 #endif
+#ifndef LQ_BATCH_LOG2
+#define LQ_BATCH_LOG2 21      // spots per batch (state: 552 B per spot); every batch ends with one host synchronisation
+#endif
+static thread_local int64_t g_last_lq_strict = 0;       // spots of the calling thread's last fit that were fitted again
+static thread_local int64_t g_last_lq_why[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // [7], [8]: rounds queued in the first / second pass
+
 template <bool FROM_MOVIE_IN>
 static int launch(Params p, hipStream_t s)
 {
@@ -1015,19 +1142,22 @@ static int launch(Params p, hipStream_t s)
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int64_t BATCH = (int64_t)1 << LQ_BATCH_LOG2;
-    const int64_t Ntotal = p.N;
+    int64_t Ntotal = p.N;
     const int64_t cap = std::min<int64_t>(Ntotal, BATCH);
     void *ptr = nullptr;
     int rc;
-    const size_t bytes = (size_t)cap * (LQ_NSD * sizeof(double) + LQ_NSI * sizeof(int32_t) + 2 * sizeof(int32_t)) + 1024;
+    const size_t bytes = (size_t)cap * (LQ_NSD * sizeof(double) + LQ_NSI * sizeof(int32_t) + 3 * sizeof(int32_t)) + 2048;
     if ((rc = scratch(SCR_STAGE_D, bytes, &ptr)) != PMI_OK) return rc;
     LqState st;
     st.d = (double *)ptr;
     st.i = (int32_t *)(st.d + (size_t)cap * LQ_NSD);
     st.stride = cap;
     int32_t *lists[2] = {st.i + (size_t)cap * LQ_NSI, st.i + (size_t)cap * (LQ_NSI + 1)};
-    unsigned *counters = (unsigned *)(lists[1] + cap);           // one per round, zeroed per batch
+    int32_t *tie_list = st.i + (size_t)cap * (LQ_NSI + 2);
+    unsigned *counters = (unsigned *)(tie_list + cap);           // one per round + the tie counter, zeroed per batch
     constexpr int NCTR = 64;
+    unsigned *tie_n = counters + NCTR;
+    static const bool no_strict = tuning_env("PMI_LQ_NO_STRICT") != nullptr;      // A/B: the tree sums only
     float *cut = nullptr;
     const int mpix = p.box * p.box;
     if (FROM_MOVIE_IN) {
@@ -1035,6 +1165,11 @@ static int launch(Params p, hipStream_t s)
         if ((rc = scratch(SCR_STAGE_C, (size_t)cap * mpix * sizeof(float), &cptr)) != PMI_OK) return rc;
         cut = (float *)cptr;
     }
+    const size_t init_lds = 256 * sizeof(int64_t) + (mpix <= LQ_TILE_MAXPIX ? (size_t)256 * mpix * sizeof(float) : 0);
+    const size_t step_lds = LQ_STEP_NT * sizeof(int64_t) + (size_t)p.box * LQ_STEP_NT * sizeof(float) +
+                            (mpix <= LQ_TILE_MAXPIX ? (size_t)LQ_STEP_NT * mpix * sizeof(float) : 0);
+    g_last_lq_strict = 0;
+    for (int64_t &v : g_last_lq_why) v = 0;
     for (int64_t first = 0; first < Ntotal; first += BATCH) {
         const int64_t count = std::min<int64_t>(BATCH, Ntotal - first);
         st.first = first;
@@ -1043,31 +1178,57 @@ static int launch(Params p, hipStream_t s)
             hipLaunchKernelGGL(lq_cut_kernel, dim3(cb), dim3(256), 0, s, p, first, count, cut);
             p.spots = cut - first * mpix;          // indexed by the absolute spot number
         }
-        PMI_HIP(hipMemsetAsync(counters, 0, NCTR * sizeof(unsigned), s));
-        const size_t init_lds = 256 * sizeof(int64_t) + (mpix <= LQ_TILE_MAXPIX ? (size_t)256 * mpix * sizeof(float) : 0);
-        hipLaunchKernelGGL((lq_init_kernel<FROM_MOVIE>), dim3((unsigned)((count + 255) / 256)), dim3(256), init_lds, s, p, st, count);
-        const int32_t *cur = nullptr;
-        const unsigned *cur_n = nullptr;
-        int64_t bound = count;                                   // spots the next round may hold
-        int round = 0;
-        for (;;) {
-            int32_t *nxt = lists[round & 1];
-            unsigned *nxt_n = counters + (round % NCTR);
-            if (round >= NCTR) PMI_HIP(hipMemsetAsync(nxt_n, 0, sizeof(unsigned), s));
-            launch_jacobian<FROM_MOVIE>(p, st, cur, cur_n, bound, cus, s);
-            const unsigned sb = (unsigned)((bound + LQ_STEP_NT - 1) / LQ_STEP_NT);
-            const size_t step_lds = LQ_STEP_NT * sizeof(int64_t) + (size_t)p.box * LQ_STEP_NT * sizeof(float) +
-                                    (mpix <= LQ_TILE_MAXPIX ? (size_t)LQ_STEP_NT * mpix * sizeof(float) : 0);
-            hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, cur, cur_n, bound, nxt, nxt_n);
-            PMI_HIP(hipGetLastError());
-            cur = nxt; cur_n = nxt_n;
-            round++;
-            if (round >= LQ_ROUNDS) {
-                unsigned left = 0;
-                PMI_HIP(hipMemcpyAsync(&left, cur_n, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+        PMI_HIP(hipMemsetAsync(counters, 0, (NCTR + 8) * sizeof(unsigned), s));
+        hipLaunchKernelGGL((lq_init_kernel<FROM_MOVIE>), dim3((unsigned)((count + 255) / 256)), dim3(256), init_lds, s, p, st, count,
+                           (const int32_t *)nullptr, (const unsigned *)nullptr);
+        // pass 0: every spot of the batch, tree sums, decisions near a threshold collected in tie_list;
+        // pass 1: the spots of tie_list again from their start values, sequential sums, no flagging
+        unsigned hw[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // tie count and its reasons, read with the first pass's last look at the stream
+        for (int pass = 0; pass < 2; pass++) {
+            const int32_t *cur = pass == 0 ? nullptr : tie_list;
+            const unsigned *cur_n = pass == 0 ? nullptr : tie_n;
+            int64_t bound = count;                                   // spots the next round may hold
+            unsigned h[3] = {0, 0, 0};                               // spots left, spots tied, (first batch) device row count
+            if (pass == 1) {
+                h[1] = hw[0];
+                for (int b = 0; b < 7; b++) g_last_lq_why[b] += hw[1 + b];
+                if (h[1] == 0 || no_strict) break;
+                bound = h[1];
+                g_last_lq_strict += bound;
+                hipLaunchKernelGGL((lq_init_kernel<FROM_MOVIE>), dim3((unsigned)((bound + 255) / 256)), dim3(256), init_lds, s, p, st, bound,
+                                   (const int32_t *)tie_list, (const unsigned *)tie_n);
+                PMI_HIP(hipMemsetAsync(counters, 0, NCTR * sizeof(unsigned), s));
+            }
+            // rounds are queued in bursts and the stream is read only after a burst: LQ_ROUNDS rounds at first (on photon
+            // data every fit is done by then), afterwards LQ_STRAGGLER_BURST rounds sized to the spots that are left —
+            // a round over an empty list costs two launches that exit at once, a synchronisation per round cost more
+            // than the rounds themselves (degenerate fits take up to 200 of them: maxfev = 1400)
+            int round = 0, burst = LQ_ROUNDS;
+            for (;;) {
+                for (int q = 0; q < burst; q++) {
+                    int32_t *nxt = lists[round & 1];
+                    unsigned *nxt_n = counters + (round % NCTR);
+                    if (round >= NCTR) PMI_HIP(hipMemsetAsync(nxt_n, 0, sizeof(unsigned), s));
+                    if (pass == 0) launch_jacobian<FROM_MOVIE, false>(p, st, cur, cur_n, bound, cus, s);
+                    else launch_jacobian<FROM_MOVIE, true>(p, st, cur, cur_n, bound, cus, s);
+                    const unsigned sb = (unsigned)((bound + LQ_STEP_NT - 1) / LQ_STEP_NT);
+                    hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, cur, cur_n, bound, nxt, nxt_n,
+                                       pass == 0 ? tie_list : (int32_t *)nullptr, pass == 0 ? tie_n : (unsigned *)nullptr);
+                    PMI_HIP(hipGetLastError());
+                    cur = nxt; cur_n = nxt_n;
+                    round++;
+                    g_last_lq_why[7 + pass]++;
+                }
+                PMI_HIP(hipMemcpyAsync(&h[0], cur_n, sizeof(unsigned), hipMemcpyDeviceToHost, s));
+                if (pass == 0) PMI_HIP(hipMemcpyAsync(hw, tie_n, sizeof(hw), hipMemcpyDeviceToHost, s));
+                int64_t dn = -1;
+                if (pass == 0 && first == 0 && p.d_n) PMI_HIP(hipMemcpyAsync(&dn, p.d_n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
                 PMI_HIP(hipStreamSynchronize(s));
-                if (left == 0) break;
-                bound = left;
+                // the caller's N is a capacity when the row count lives on the device: no batch is queued past the rows that exist
+                if (dn >= 0 && dn < Ntotal) Ntotal = dn;
+                if (h[0] == 0) break;
+                bound = h[0];
+                burst = LQ_STRAGGLER_BURST;
             }
         }
     }
@@ -1136,6 +1297,18 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
 }  // namespace pmi
 
 extern "C" {
+
+int pmi_gausslq_last_refit_count(int64_t *n_refit)
+{
+    if (n_refit) *n_refit = pmi::lq::g_last_lq_strict;
+    return PMI_OK;
+}
+
+int pmi_gausslq_last_tie_reasons(int64_t *counts, int n)
+{
+    for (int i = 0; counts && i < n; i++) counts[i] = i < 9 ? pmi::lq::g_last_lq_why[i] : 0;
+    return PMI_OK;
+}
 
 int pmi_gausslq_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box, float *d_thetas,
                     int32_t *d_info, int32_t *d_nfev, void *stream)

@@ -42,7 +42,7 @@ __device__ __forceinline__ bool wobbles(float st, float value, int kk, StepHisto
     const bool wob = w * h.wprev < 0.0f && fabsf(w) > FIT_WOBBLE_RATIO * fabsf(h.wprev) && fabsf(w) > FIT_WOBBLE_FLOOR * fabsf(value);
     h.run = wob ? h.run + 1 : 0;
     h.wprev = w; h.prev2 = h.prev; h.prev = st;
-    return h.run >= FIT_WOBBLE_RUN;
+    return h.run >= FIT_WOBBLE_RUN || (h.run >= 2 && kk >= FIT_WOBBLE_LATE);
 }
 
 // NP = params (5: "sigma", 6: "sigmaxy"); PPL = pixels per lane = ceil(box^2/64)
@@ -446,8 +446,9 @@ static int g_mle_mode = PMI_MLE_REFIT;
 static double g_mle_margin = 0.001;
 // flag statistics of the calling thread's last fit: a device buffer of its own (SCR_STATS of the thread's scratch bank:
 // [0] = spots re-fitted, [1..FLAG_REASONS] = spots flagged per criterion), valid while the scratch generation stands
-static thread_local const unsigned *g_last_stats = nullptr;
+static thread_local const unsigned *g_last_stats[2] = {nullptr, nullptr};      // [1]: the second frame range of a fused call
 static thread_local unsigned g_last_stats_generation = 0;
+static thread_local bool g_stats_second = false;                                  // the fit being queued is that second range
 
 __global__ void flag_stats_kernel(const unsigned *__restrict__ flag_counts, int64_t nb, unsigned *__restrict__ stats)
 {
@@ -584,7 +585,8 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     }
     hipLaunchKernelGGL(flag_stats_kernel, dim3(1), dim3(1), 0, s, flag_counts, mode == PMI_MLE_REFIT ? nb : 0, stats);
     PMI_HIP(hipGetLastError());
-    g_last_stats = stats;
+    g_last_stats[g_stats_second ? 1 : 0] = stats;
+    if (!g_stats_second) g_last_stats[1] = nullptr;
     g_last_stats_generation = scratch_generation();
     tm.stop();
     return PMI_OK;
@@ -593,9 +595,14 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
 static int read_last_stats(unsigned (&h)[16], hipStream_t s)
 {
     for (unsigned &v : h) v = 0;
-    if (!g_last_stats || g_last_stats_generation != scratch_generation()) return PMI_OK;      // no fit yet, or its buffers are gone
+    if (!g_last_stats[0] || g_last_stats_generation != scratch_generation()) return PMI_OK;      // no fit yet, or its buffers are gone
     PMI_HIP(hipStreamSynchronize(s));
-    PMI_HIP(hipMemcpy(h, g_last_stats, 64, hipMemcpyDeviceToHost));
+    for (const unsigned *src : g_last_stats) {
+        if (!src) continue;
+        unsigned part[16];
+        PMI_HIP(hipMemcpy(part, src, 64, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 16; i++) h[i] += part[i];
+    }
     return PMI_OK;
 }
 
@@ -624,18 +631,19 @@ __global__ void locs_from_fits_kernel(const int32_t *__restrict__ frame, const i
                                       const int32_t *__restrict__ x, const float *__restrict__ ng,
                                       const float *__restrict__ th, const float *__restrict__ cr,
                                       const float *__restrict__ ll, const int32_t *__restrict__ it, int64_t N,
-                                      const int64_t *__restrict__ d_n, int box, LocCols cols)
+                                      const int64_t *__restrict__ d_n, int box, LocCols cols, const int64_t *__restrict__ d_row0)
 {
     int64_t n = N;
     if (d_n) { int64_t dn = *d_n; n = dn < n ? dn : n; }
-    int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
+    const int64_t src = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // row of the fit arrays
+    if (src >= n) return;
+    const int64_t i = src + (d_row0 ? *d_row0 : 0);                            // row of the table: a second frame range follows the first
     const int off = box / 2;
-    const float *t = th + i * 6, *c = cr + i * 6;
+    const float *t = th + src * 6, *c = cr + src * 6;
     // float32 theta + int64 coordinate -> float64 in pandas, then - offset, then cast
-    ((uint32_t *)cols.c[0])[i] = (uint32_t)frame[i];
-    ((float *)cols.c[1])[i] = (float)((double)t[0] + (double)x[i] - (double)off);
-    ((float *)cols.c[2])[i] = (float)((double)t[1] + (double)y[i] - (double)off);
+    ((uint32_t *)cols.c[0])[i] = (uint32_t)frame[src];
+    ((float *)cols.c[1])[i] = (float)((double)t[0] + (double)x[src] - (double)off);
+    ((float *)cols.c[2])[i] = (float)((double)t[1] + (double)y[src] - (double)off);
     ((float *)cols.c[3])[i] = t[2];
     ((float *)cols.c[4])[i] = t[4];
     ((float *)cols.c[5])[i] = t[5];
@@ -644,9 +652,9 @@ __global__ void locs_from_fits_kernel(const int32_t *__restrict__ frame, const i
     ((float *)cols.c[8])[i] = sqrtf(c[1]);
     float a = np_maxf(t[4], t[5]), b = np_minf(t[4], t[5]);
     ((float *)cols.c[9])[i] = (a - b) / a;
-    ((float *)cols.c[10])[i] = ng[i];
-    ((float *)cols.c[11])[i] = ll[i];
-    ((uint32_t *)cols.c[12])[i] = (uint32_t)it[i];
+    ((float *)cols.c[10])[i] = ng[src];
+    ((float *)cols.c[11])[i] = ll[src];
+    ((uint32_t *)cols.c[12])[i] = (uint32_t)it[src];
     ((float *)cols.c[13])[i] = sqrtf(c[2]);
     ((float *)cols.c[14])[i] = sqrtf(c[3]);
     ((float *)cols.c[15])[i] = sqrtf(c[4]);
@@ -722,6 +730,8 @@ int pmi_gaussmle_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y,
     p.baseline = (float)baseline; p.sensitivity = (float)sensitivity; p.gain = (float)gain; p.gdiv = pmi::make_const_div((float)gain);
     p.N = N; p.d_n = d_n; p.box = box; p.eps = eps; p.max_it = max_it;
     p.thetas = d_thetas; p.crlbs = d_crlbs; p.loglik = d_loglik; p.iterations = d_iterations;
+    // a fused call whose scan handed the pixels on (these identifications, this thread, just now)
+    if (pmi::g_handoff.used && pmi::g_handoff.d_slot && dtype == PMI_U16) { p.pix = pmi::g_handoff.pix; p.slot = pmi::g_handoff.d_slot; }
     return pmi::fit_impl(p, method, true, (hipStream_t)stream);
 }
 
@@ -828,8 +838,44 @@ int pmi_locs_from_fits_dev(const int32_t *d_frame, const int32_t *d_y, const int
     for (int c = 0; c < PMI_LOC_COLUMNS; c++) cols.c[c] = d_cols[c];
     unsigned blocks = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(locs_from_fits_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_frame, d_y, d_x,
-                       d_ng, d_thetas, d_crlbs, d_loglik, d_iterations, N, d_n, box, cols);
+                       d_ng, d_thetas, d_crlbs, d_loglik, d_iterations, N, d_n, box, cols, (const int64_t *)nullptr);
     PMI_HIP(hipGetLastError());
+    return PMI_OK;
+}
+
+// ---- two frame ranges in flight ---------------------------------------------------------------------------------
+// The scan is bound by memory requests, the fit by VALU issue: the scan of frame range B beside the fit of range A
+// takes less than the two one after the other.  pmi_localize_mle_dev therefore cuts its frames
+// in two: stream s runs scan A, fit A; a side stream of the library runs scan B (started when scan A is done) and
+// fit B, with scratch from the inner bank; the table rows are written once both counts are known (A's rows, then
+// B's), so the capacity contract holds for the sum.
+namespace pmi {
+static int g_localize_ranges = 2;
+struct SideLane { hipStream_t s2 = nullptr; hipEvent_t ev_start = nullptr, ev_scan_a = nullptr, ev_b = nullptr; };
+static thread_local SideLane g_side;
+
+// [0] rows of A to fit, [1] rows of B to fit, [2] rows of A for the table, [3] rows of B for the table, [4] row offset of B
+__global__ void range_rows_a_kernel(const int64_t *__restrict__ n_a, int64_t cap, int64_t *__restrict__ rows)
+{
+    rows[0] = *n_a > cap ? 0 : *n_a;
+}
+__global__ void range_rows_b_kernel(const int64_t *__restrict__ n_a, const int64_t *__restrict__ n_b, int64_t cap,
+                                    int64_t *__restrict__ rows, int64_t *__restrict__ d_out_n)
+{
+    const int64_t a = *n_a, b = *n_b, total = a + b;
+    const bool fits = total <= cap;
+    rows[1] = fits ? b : 0;
+    rows[2] = fits ? a : 0;
+    rows[3] = fits ? b : 0;
+    rows[4] = a;
+    *d_out_n = total;
+}
+}  // namespace pmi
+
+int pmi_localize_set_ranges(int ranges)
+{
+    if (ranges != 1 && ranges != 2) { pmi::set_error("ranges in flight: 1 or 2"); return PMI_ERR_ARG; }
+    pmi::g_localize_ranges = ranges;
     return PMI_OK;
 }
 
@@ -841,23 +887,110 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
     using namespace pmi;
     if (cap <= 0) { set_error("capacity must be positive"); return PMI_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
-    void *ptr = nullptr;
-    int rc;
-    if ((rc = scratch(SCR_IDS, (size_t)cap * (16 + 14 * 4), &ptr)) != PMI_OK) return rc;
-    int32_t *d_f = (int32_t *)ptr, *d_y = d_f + cap, *d_x = d_y + cap;
-    float *d_ng = (float *)(d_x + cap);
-    float *d_th = d_ng + cap, *d_cr = d_th + cap * 6, *d_ll = d_cr + cap * 6;
-    int32_t *d_it = (int32_t *)(d_ll + cap);
-    rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, f_lo, f_hi, 0, d_f, d_y, d_x, d_ng, cap, d_out_n, s);
-    if (rc != PMI_OK) return rc;
-    const int64_t *d_rows = nullptr;
-    if ((rc = rows_to_fit(d_out_n, cap, &d_rows, s)) != PMI_OK) return rc;
-    rc = pmi_gaussmle_movie_dev(d_movie, dtype, F, Y, X, d_f, d_y, d_x, cap, d_rows, box, baseline, sensitivity,
-                                gain, eps, max_it, method, d_th, d_cr, d_ll, d_it, stream);
-    if (rc != PMI_OK) return rc;
     void *cols[PMI_LOC_COLUMNS];
     for (int c = 0; c < PMI_LOC_COLUMNS; c++) cols[c] = (char *)d_table + (size_t)c * cap * 4;
-    return pmi_locs_from_fits_dev(d_f, d_y, d_x, d_ng, d_th, d_cr, d_ll, d_it, cap, d_rows, box, cols, stream);
+    struct Ids { int32_t *f, *y, *x; float *ng, *th, *cr, *ll; int32_t *it, *slot; };
+    auto carve = [&](void *ptr) {
+        Ids d;
+        d.f = (int32_t *)ptr; d.y = d.f + cap; d.x = d.y + cap;
+        d.ng = (float *)(d.x + cap);
+        d.th = d.ng + cap; d.cr = d.th + cap * 6; d.ll = d.cr + cap * 6;
+        d.it = (int32_t *)(d.ll + cap);
+        d.slot = d.it + cap;
+        return d;
+    };
+    const size_t ids_bytes = (size_t)cap * (16 + 15 * 4);
+    // pixel hand-off from the scan's exact stage to the fit (uint16 movies, boxes of the row-per-lane fit): room for twice
+    // the table's rows (candidates that fail the threshold take a slot too), spread over the eight record shards
+    const bool hand = dtype == PMI_U16 && box <= 15 && mle_mode_now() != PMI_MLE_STRICT && !tuning_env("PMI_MLE_NO_HANDOFF");
+    const unsigned pix_cap = (unsigned)std::min<int64_t>(std::max<int64_t>(cap / 4, 4096), 0x0fffffff);
+    const size_t pix_bytes = (size_t)8 * pix_cap * (size_t)(box * (box / 2 + 1)) * sizeof(uint32_t);
+    auto arm_handoff = [&](int32_t *d_slot) -> int {         // in the scratch bank that is current
+        g_handoff = PixHandoff();
+        if (!hand) return PMI_OK;
+        void *pp = nullptr;
+        int r = scratch(SCR_PIX, pix_bytes, &pp);
+        if (r != PMI_OK) return r;
+        g_handoff.pix = (uint32_t *)pp; g_handoff.cap_per_shard = pix_cap; g_handoff.d_slot = d_slot;
+        return PMI_OK;
+    };
+    const int64_t lo = f_lo < 0 ? 0 : f_lo, hi = f_hi > F - 1 ? F - 1 : f_hi, nf = hi - lo + 1;
+    // two ranges pay when each keeps the chip busy for a while (below ~1e8 pixels a range is a few tens of microseconds)
+    const bool two = g_localize_ranges == 2 && !g_kernel_timing && nf >= 16 && (double)nf * (double)Y * (double)X >= 2.5e8;
+    void *ptr = nullptr;
+    int rc;
+    if (!two) {
+        if ((rc = scratch(SCR_IDS, ids_bytes, &ptr)) != PMI_OK) return rc;
+        const Ids d = carve(ptr);
+        if ((rc = arm_handoff(d.slot)) != PMI_OK) return rc;
+        rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, f_lo, f_hi, 0, d.f, d.y, d.x, d.ng, cap, d_out_n, s);
+        if (rc != PMI_OK) { g_handoff = PixHandoff(); return rc; }
+        const int64_t *d_rows = nullptr;
+        if ((rc = rows_to_fit(d_out_n, cap, &d_rows, s)) != PMI_OK) { g_handoff = PixHandoff(); return rc; }
+        rc = pmi_gaussmle_movie_dev(d_movie, dtype, F, Y, X, d.f, d.y, d.x, cap, d_rows, box, baseline, sensitivity,
+                                    gain, eps, max_it, method, d.th, d.cr, d.ll, d.it, stream);
+        g_handoff = PixHandoff();
+        if (rc != PMI_OK) return rc;
+        return pmi_locs_from_fits_dev(d.f, d.y, d.x, d.ng, d.th, d.cr, d.ll, d.it, cap, d_rows, box, cols, stream);
+    }
+    SideLane &side = g_side;
+    if (!side.s2) {
+        PMI_HIP(hipStreamCreateWithFlags(&side.s2, hipStreamNonBlocking));
+        PMI_HIP(hipEventCreateWithFlags(&side.ev_start, hipEventDisableTiming));
+        PMI_HIP(hipEventCreateWithFlags(&side.ev_scan_a, hipEventDisableTiming));
+        PMI_HIP(hipEventCreateWithFlags(&side.ev_b, hipEventDisableTiming));
+    }
+    const int64_t mid = lo + nf / 2 - 1;                      // A = [lo, mid], B = [mid + 1, hi]
+    // counts of the two ranges and the row bookkeeping live in the OUTER bank (both streams read them)
+    void *cptr = nullptr;
+    if ((rc = scratch(SCR_ROWS, 8 * sizeof(int64_t), &cptr)) != PMI_OK) return rc;
+    int64_t *d_na = (int64_t *)cptr, *d_nb = d_na + 1, *rows = d_na + 2;
+    if ((rc = scratch(SCR_IDS, ids_bytes, &ptr)) != PMI_OK) return rc;
+    const Ids a = carve(ptr);
+    PMI_HIP(hipEventRecord(side.ev_start, s));               // the side stream joins the caller's stream order here
+    PMI_HIP(hipStreamWaitEvent(side.s2, side.ev_start, 0));
+    // ---- range A on the caller's stream
+    if ((rc = arm_handoff(a.slot)) != PMI_OK) return rc;
+    rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, lo, mid, 0, a.f, a.y, a.x, a.ng, cap, d_na, s);
+    if (rc != PMI_OK) { g_handoff = PixHandoff(); return rc; }
+    hipLaunchKernelGGL(range_rows_a_kernel, dim3(1), dim3(1), 0, s, (const int64_t *)d_na, cap, rows);
+    PMI_HIP(hipEventRecord(side.ev_scan_a, s));
+    rc = pmi_gaussmle_movie_dev(d_movie, dtype, F, Y, X, a.f, a.y, a.x, cap, rows + 0, box, baseline, sensitivity,
+                                gain, eps, max_it, method, a.th, a.cr, a.ll, a.it, s);
+    g_handoff = PixHandoff();
+    if (rc != PMI_OK) return rc;
+    // ---- range B on the side stream, scratch from the inner bank; its scan starts when scan A is done
+    PMI_HIP(hipStreamWaitEvent(side.s2, side.ev_scan_a, 0));
+    const int outer = scratch_enter_inner();
+    Ids b2 = {};
+    rc = scratch(SCR_IDS, ids_bytes, &ptr);
+    if (rc == PMI_OK) {
+        b2 = carve(ptr);
+        rc = arm_handoff(b2.slot);
+    }
+    if (rc == PMI_OK) rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, mid + 1, hi, 0, b2.f, b2.y, b2.x, b2.ng, cap, d_nb, side.s2);
+    if (rc == PMI_OK) {
+        hipLaunchKernelGGL(range_rows_b_kernel, dim3(1), dim3(1), 0, side.s2, (const int64_t *)d_na, (const int64_t *)d_nb, cap, rows, d_out_n);
+        g_stats_second = true;
+        rc = pmi_gaussmle_movie_dev(d_movie, dtype, F, Y, X, b2.f, b2.y, b2.x, cap, rows + 1, box, baseline, sensitivity,
+                                    gain, eps, max_it, method, b2.th, b2.cr, b2.ll, b2.it, side.s2);
+        g_stats_second = false;
+    }
+    g_handoff = PixHandoff();
+    scratch_leave_inner(outer);
+    if (rc != PMI_OK) return rc;
+    PMI_HIP(hipEventRecord(side.ev_b, side.s2));
+    PMI_HIP(hipStreamWaitEvent(s, side.ev_b, 0));
+    // ---- the table, once both counts are known: A's rows, then B's
+    LocCols lc;
+    for (int c = 0; c < PMI_LOC_COLUMNS; c++) lc.c[c] = cols[c];
+    const unsigned blocks = (unsigned)((cap + 255) / 256);
+    hipLaunchKernelGGL(locs_from_fits_kernel, dim3(blocks), dim3(256), 0, s, a.f, a.y, a.x, a.ng, a.th, a.cr, a.ll, a.it, cap,
+                       (const int64_t *)(rows + 2), box, lc, (const int64_t *)nullptr);
+    hipLaunchKernelGGL(locs_from_fits_kernel, dim3(blocks), dim3(256), 0, s, b2.f, b2.y, b2.x, b2.ng, b2.th, b2.cr, b2.ll, b2.it, cap,
+                       (const int64_t *)(rows + 3), box, lc, (const int64_t *)(rows + 4));
+    PMI_HIP(hipGetLastError());
+    return PMI_OK;
 }
 
 }  // extern "C"

@@ -160,9 +160,21 @@ __device__ __forceinline__ void load_row(const FitParams &p, int64_t sidx, int j
     for (int i = 0; i < B; i++) d[i] = 0.f;
     if (valid) {
         if (FROM_MOVIE) {
+            float raw[B];
+            const int sl = p.slot ? p.slot[sidx] : -1;
+            if (sl >= 0) {
+                // the scan's exact stage left this spot's rows behind (identify_fast.hip): B rows of H + 1 packed pairs, one
+                // or two cache lines per spot instead of B lines of the movie
+                constexpr int NPR = H + 1;
+                const uint32_t *q = p.pix + (size_t)sl * (size_t)(B * NPR) + j * NPR;
+                uint32_t w[NPR];
+#pragma unroll
+                for (int t = 0; t < NPR; t++) w[t] = q[t];
+#pragma unroll
+                for (int i = 0; i < B; i++) raw[i] = (float)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu));
+            } else {
             const int64_t fr = p.frame[sidx], yy = p.y[sidx], xx = p.x[sidx];
             const int64_t o = (fr * p.Y + (yy - H + j)) * p.X + (xx - H);
-            float raw[B];
             // one switch per row, not per pixel: the B loads of a row issue back to back
             switch (p.dtype) {
             case PMI_U16: { const uint16_t *q = (const uint16_t *)p.movie + o; _Pragma("unroll") for (int i = 0; i < B; i++) raw[i] = (float)q[i]; } break;
@@ -171,6 +183,7 @@ __device__ __forceinline__ void load_row(const FitParams &p, int64_t sidx, int j
             case PMI_U32: { const uint32_t *q = (const uint32_t *)p.movie + o; _Pragma("unroll") for (int i = 0; i < B; i++) raw[i] = (float)q[i]; } break;
             case PMI_I32: { const int32_t *q = (const int32_t *)p.movie + o;   _Pragma("unroll") for (int i = 0; i < B; i++) raw[i] = (float)q[i]; } break;
             default:      { const float *q = (const float *)p.movie + o;       _Pragma("unroll") for (int i = 0; i < B; i++) raw[i] = q[i]; } break;
+            }
             }
 #pragma unroll
             for (int i = 0; i < B; i++)      // localize.py:1112: float32 sub, mul, div in this order
@@ -361,7 +374,7 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
     const bool wob = j < NP && w * role.wprev < 0.0f && fabsf(w) > FIT_WOBBLE_RATIO * fabsf(role.wprev)
                      && fabsf(w) > FIT_WOBBLE_FLOOR * fabsf(nt);
     const int run = wob ? role.run + 1 : 0;
-    const bool swing = run >= FIT_WOBBLE_RUN;
+    const bool swing = run >= FIT_WOBBLE_RUN || (run >= 2 && kk + 1 >= FIT_WOBBLE_LATE);
     if (active) { role.run = run; role.wprev = w; role.prev2 = role.prev; role.prev = step; }
     // ... and spots with a pixel whose count is far off the model (|data / model - 1| or |data / model^2| beyond
     // FIT_TOP_FLAG: a model pinned at the 0.01 floors under negative or bright pixels): the sums then cancel from terms

@@ -152,8 +152,8 @@ __global__ __launch_bounds__(ID_NT) void identify_scan_kernel(
             if ((long long)pos < cap) {
                 Record rec;
                 rec.frame = (int32_t)(p.f_lo + fi + p.frame_label_offset);
-                rec.y = ty * ID_TH + rr + p.y0;
-                rec.x = tx * ID_TW + cc + p.x0;
+                rec.yx = pack_yx(ty * ID_TH + rr + p.y0, tx * ID_TW + cc + p.x0);
+                rec.slot = -1;
                 rec.ng = ng;
                 recs[(long long)shard * cap + pos] = rec;
             }
@@ -247,7 +247,8 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_in_frame_kernel(const Recor
                                                                      const unsigned long long *__restrict__ counters,
                                                                      long long cap,
                                                                      int32_t *__restrict__ o_frame, int32_t *__restrict__ o_y,
-                                                                     int32_t *__restrict__ o_x, float *__restrict__ o_ng)
+                                                                     int32_t *__restrict__ o_x, float *__restrict__ o_ng,
+                                                                     int32_t *__restrict__ o_slot)
 {
     using key_t = typename std::conditional<K32, unsigned, unsigned long long>::type;
     __shared__ __attribute__((aligned(16))) key_t s_key[SORT_LDS];
@@ -257,10 +258,7 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_in_frame_kernel(const Recor
     const int per = (((m + (int)gridDim.y - 1) / (int)gridDim.y) + 63) & ~63;
     const int q0 = (int)blockIdx.y * per, q1 = min(m, q0 + per);
     if (q0 >= m) return;
-    auto key_of = [](const Record &o) -> key_t {
-        if constexpr (K32) return ((unsigned)o.y << 16) | (unsigned)o.x;
-        else return ((unsigned long long)(unsigned)o.y << 32) | (unsigned)o.x;
-    };
+    auto key_of = [](const Record &o) -> key_t { return (key_t)o.yx; };       // y << 16 | x: row-major order
     // keys go through LDS in tiles of SORT_LDS; a frame with fewer maxima than that (the usual case) is staged once
     auto stage = [&](int t0, int tm) {
         const int tmp = (tm + 3) & ~3;
@@ -300,9 +298,10 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_in_frame_kernel(const Recor
         }
         if (act) {
             o_frame[b + rank] = r.frame;
-            o_y[b + rank] = r.y;
-            o_x[b + rank] = r.x;
+            o_y[b + rank] = (int32_t)(r.yx >> 16);
+            o_x[b + rank] = (int32_t)(r.yx & 0xffffu);
             o_ng[b + rank] = r.ng;
+            if (o_slot) o_slot[b + rank] = r.slot;
         }
     }
 }
@@ -360,7 +359,7 @@ static int launch_scan(const void *d_movie, const IdParams &p, const float *d_ta
 int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
                          int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
                          long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled,
-                         const int *gate = nullptr);
+                         const int *gate = nullptr, uint32_t *pix = nullptr, unsigned *pix_cnt = nullptr, unsigned pix_cap = 0);
 
 // float32 / int32 / uint32 movies that hold 16-bit counts (a camera's counts saved wide): the frames are narrowed to
 // uint16 — exactly, or not at all: any pixel that is not an integer in 0..65535 raises the chunk's flag — and take the
@@ -417,9 +416,11 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
     unsigned long long *d_total = nullptr;
     void *ptr = nullptr;
     int rc;
-    if ((rc = scratch(SCR_COUNTERS, 128, &ptr)) != PMI_OK) return rc;
+    if ((rc = scratch(SCR_COUNTERS, 256, &ptr)) != PMI_OK) return rc;
     d_total = (unsigned long long *)ptr;
-    PMI_HIP(hipMemsetAsync(d_total, 0, 128, s));
+    unsigned *pix_cnt = (unsigned *)((char *)ptr + 128);              // slot counters of the pixel hand-off, one per shard
+    PMI_HIP(hipMemsetAsync(d_total, 0, 256, s));
+    g_handoff.used = false;
     if (nf <= 0 || cy < box + 1 || cx < box + 1) {   // no interior pixel can be scanned
         PMI_HIP(hipMemsetAsync(d_out_n, 0, sizeof(int64_t), s));
         return PMI_OK;
@@ -448,8 +449,11 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
         bool fast = false;
         rc = PMI_OK;
         // register-pipelined packed-u16 scan (identify_fast.hip: uint16, uint8, int16) when the layout allows
+        const bool hand = g_handoff.pix && dtype == PMI_U16;
         rc = launch_scan_u16_fast(d_movie, dtype, Y, X, p.y0, p.x0, p.cy, p.cx, f_lo, label_offset, p.nframes, box, min_ng,
-                                      d_tab, recs, cap, d_total, count, s, &fast);
+                                      d_tab, recs, cap, d_total, count, s, &fast, nullptr, hand ? g_handoff.pix : nullptr,
+                                      hand ? pix_cnt : nullptr, hand ? g_handoff.cap_per_shard : 0u);
+        g_handoff.used = hand && fast;
         p.gate = nullptr;
         const bool wide = dtype == PMI_U32 || dtype == PMI_I32 || dtype == PMI_F32;
         static const bool no_narrow = tuning_env("PMI_IDENTIFY_NO_NARROW") != nullptr;
@@ -509,10 +513,10 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
         const unsigned split = (unsigned)std::min<int64_t>(16, std::max<int64_t>(1, (Y * X + 262143) / 262144));
         if (Y <= 65536 && X <= 65536)
             hipLaunchKernelGGL(sort_in_frame_kernel<true>, dim3((unsigned)nf, split), dim3(SORT_THREADS), 0, s, grouped, base,
-                               count, d_total, (long long)cap, d_frame, d_y, d_x, d_ng);
+                               count, d_total, (long long)cap, d_frame, d_y, d_x, d_ng, g_handoff.d_slot);
         else
             hipLaunchKernelGGL(sort_in_frame_kernel<false>, dim3((unsigned)nf, split), dim3(SORT_THREADS), 0, s, grouped, base,
-                               count, d_total, (long long)cap, d_frame, d_y, d_x, d_ng);
+                               count, d_total, (long long)cap, d_frame, d_y, d_x, d_ng, g_handoff.d_slot);
     }
     PMI_HIP(hipGetLastError());
     return PMI_OK;

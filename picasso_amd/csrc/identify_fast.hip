@@ -134,6 +134,13 @@ struct FastParams {
     float filt_alpha, filt_t;  // floor filter: a maximum v can only reach min_ng if v > alpha * (minimum above it) + t; t < 0: off
     float filt_kr, filt_kc, filt_krc;   // the same for stencils that wrap through index -1 (row, column, both): v > k * cfloor + t
     int filt_slack;            // counts by which later pixels may undercut the minimum seen so far before a chunk is run again
+    // pixel hand-off to the fit (uint16 movies): the exact stage has a candidate's (2H+3)^2 neighbourhood in registers and
+    // leaves the box rows — BOX rows of H + 1 packed pairs (BOX + 1 pixels), 4 (H + 1) bytes per row — at pix[slot], so the
+    // fit reads one or two cache lines per spot instead of BOX lines of the movie.  pix_cnt: one slot counter per shard,
+    // pix_cap slots per shard; a round that finds its shard full hands nothing on (slot -1: the fit reads the movie).
+    u32 *pix;
+    unsigned *pix_cnt;
+    unsigned pix_cap;
     const int *gate;           // optional device flag: the launch does nothing unless it is 0 (32-bit movies narrowed to uint16, identify.hip)
     int dbg;                   // PMI_IDENTIFY_DBG: 1 = skip the exact net gradient, 2 = skip the record append, 4 = no floor filter (timing only)
 };
@@ -215,7 +222,7 @@ __device__ __forceinline__ u32 from_lane_above(u32 v, u32 edge) { return (u32)__
 // than the window pixels before it in row-major order, not smaller than those after it (np.argmax, localize.py:128).
 template <int H, int K0, int K1, int PT>
 __device__ __forceinline__ float exact_ng_rows(const typename Px<PT>::T *__restrict__ base, const typename Px<PT>::T *__restrict__ row0w,
-                                               int64_t X, int c0w, float ng, float &vc, bool &first_max)
+                                               int64_t X, int c0w, float ng, float &vc, bool &first_max, u32 *__restrict__ pixdst)
 {
     typedef typename Px<PT>::T PX;
     // base = &src[i - H - 1][j - H]: neighbourhood row t, column 1;  row0w = &src[wrapped first row][j - H];
@@ -239,6 +246,18 @@ __device__ __forceinline__ float exact_ng_rows(const typename Px<PT>::T *__restr
             for (int q = 0; q < NP; q++) pk[r][q] = PT == PT_I16 ? t.v[q] ^ 0x80008000u : t.v[q];
         }
         first[r] = PT == PT_I16 ? (u32)row[c0w] ^ 0x8000u : (u32)row[c0w];
+    }
+    if constexpr (PT == PT_U16) {
+        // hand the box rows on: box row k = neighbourhood row k + 1, its pixels = the NP pairs (columns 1 .. BOX + 1).
+        // The first batch holds box rows 0 .. K1, the second K0 + 1 .. BOX - 1.
+        if (pixdst) {
+            constexpr int KLO = K0 == 0 ? 0 : K0 + 1, KHI = K0 == 0 ? K1 : BOX - 1;
+#pragma unroll
+            for (int k = KLO; k <= KHI; k++) {
+#pragma unroll
+                for (int q = 0; q < NP; q++) pixdst[k * NP + q] = pk[k + 1 - R0][q];
+            }
+        }
     }
     auto px = [&](int r, int b) -> float {
         r -= R0;
@@ -267,7 +286,8 @@ __device__ __forceinline__ float exact_ng_rows(const typename Px<PT>::T *__restr
 }
 
 template <int H, int PT>
-__device__ __forceinline__ float exact_ng(const typename Px<PT>::T *__restrict__ src, int64_t X, int cy, int cx, int i, int j, bool &first_max)
+__device__ __forceinline__ float exact_ng(const typename Px<PT>::T *__restrict__ src, int64_t X, int cy, int cx, int i, int j, bool &first_max,
+                                          u32 *__restrict__ pixdst)
 {
     typedef typename Px<PT>::T PX;
     constexpr int BOX = 2 * H + 1, KM = (BOX + 1) / 2;
@@ -277,11 +297,11 @@ __device__ __forceinline__ float exact_ng(const typename Px<PT>::T *__restrict__
     int c0w = j - H - 1 < 0 ? cx - 1 - (j - H) : -1;
     float vc = 0.0f;
     first_max = true;
-    float ng = exact_ng_rows<H, 0, KM, PT>(base, row0w, X, c0w, 0.0f, vc, first_max);
+    float ng = exact_ng_rows<H, 0, KM, PT>(base, row0w, X, c0w, 0.0f, vc, first_max, pixdst);
     // the second batch starts only when the first sum is done (keeps its loads from being hoisted
     // above the first batch, which would double the live registers)
     asm volatile("" : "+v"(ng), "+v"(base), "+v"(c0w));
-    return exact_ng_rows<H, KM, BOX, PT>(base, row0w, X, c0w, ng, vc, first_max);
+    return exact_ng_rows<H, KM, BOX, PT>(base, row0w, X, c0w, ng, vc, first_max, pixdst);
 }
 
 // One wavefront per workgroup, persistent: it owns p.upw consecutive UNITS.  A unit is rbu rows x 512 columns of one
@@ -381,8 +401,8 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
 
     // ---- results: buffered in registers, appended KBUF rounds at a time with ONE slot-allocating atomic per flush
     // per wave on the counter of this block's shard (a single hot counter costs ~11 ns per atomic)
-    constexpr int KBUF = 4;
-    int buf_i[KBUF], buf_j[KBUF], buf_f[KBUF], nbuf = 0, rounds = 0;
+    constexpr int KBUF = 2;      // (2 / 4 / 8 rounds per flush measured alike; two keep the buffers at ten registers with the pixel slot)
+    int buf_i[KBUF], buf_j[KBUF], buf_f[KBUF], buf_s[KBUF], nbuf = 0, rounds = 0;
     float buf_ng[KBUF];
     const int shard = blockIdx.x & 7;
     auto flush = [&]() {
@@ -417,8 +437,8 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
                     if (pos < cap) {
                         Record rec;
                         rec.frame = (int32_t)(p.f_lo + buf_f[k] + p.label_off);
-                        rec.y = buf_i[k] + p.y0;
-                        rec.x = buf_j[k] + p.x0;
+                        rec.yx = pack_yx(buf_i[k] + p.y0, buf_j[k] + p.x0);
+                        rec.slot = buf_s[k];
                         rec.ng = buf_ng[k];
                         recs[(long long)shard * cap + pos] = rec;
                     }
@@ -428,10 +448,10 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
         }
         nbuf = 0;
     };
-    auto append = [&](int fi, int i, int j, float ng) {
+    auto append = [&](int fi, int i, int j, float ng, int slot) {
         if ((double)ng > p.min_ng) {                   // localize.py:288
 #pragma unroll
-            for (int k = 0; k < KBUF; k++) if (k == nbuf) { buf_f[k] = fi; buf_i[k] = i; buf_j[k] = j; buf_ng[k] = ng; }
+            for (int k = 0; k < KBUF; k++) if (k == nbuf) { buf_f[k] = fi; buf_i[k] = i; buf_j[k] = j; buf_ng[k] = ng; buf_s[k] = slot; }
             nbuf++;
         }
     };
@@ -469,21 +489,33 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
                 ng = add_rn(ng, sacc);
             }
         }
-        append(fi, i, j, ng);
+        append(fi, i, j, ng, -1);
     };
     // exact float32 net gradient of the n (<= 64) oldest ring entries
     auto exact_round = [&](int n) {
+        // pixel slots of the round's candidates: one atomic per round on the shard's counter
+        unsigned pixbase = 0xffffffffu;
+        if (PT == PT_U16 && p.pix) {
+            if (lane == 0) pixbase = atomicAdd(&p.pix_cnt[shard], (unsigned)n);
+            pixbase = (unsigned)__builtin_amdgcn_readfirstlane((int)pixbase);
+        }
         if (lane < n) {
             const int q = (head + lane) & (LIST - 1);
             const unsigned e = s_pos[q];
             const int fi = (int)s_fi[q];
             const int i = (int)(e >> 16), j = (int)(e & 0xffffu) - xoff;
             const PX *src = frame_src(fi);
-            if (p.dbg & 1) append(fi, i, j, (e & 7) == 0 ? 1e9f : 0.0f);
+            int slot = -1;
+            u32 *pixdst = nullptr;
+            if (PT == PT_U16 && p.pix && pixbase + (unsigned)lane < p.pix_cap) {       // (pixbase = ~0 without a buffer: never below the capacity)
+                slot = (int)((unsigned)shard * p.pix_cap + pixbase + (unsigned)lane);
+                pixdst = p.pix + (size_t)slot * (size_t)(BOX * (H + 1));
+            }
+            if (p.dbg & 1) append(fi, i, j, (e & 7) == 0 ? 1e9f : 0.0f, -1);
             else {
                 bool first_max;
-                const float ng = exact_ng<H, PT>(src, p.X, p.cy, p.cx, i, j, first_max);
-                if (first_max) append(fi, i, j, ng);
+                const float ng = exact_ng<H, PT>(src, p.X, p.cy, p.cx, i, j, first_max, pixdst);
+                if (first_max) append(fi, i, j, ng, slot);
             }
         }
         head += n;
@@ -925,7 +957,7 @@ static int g_fast_cus = 0;
 int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
                          int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
                          long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled,
-                         const int *gate)
+                         const int *gate, uint32_t *pix, unsigned *pix_cnt, unsigned pix_cap)
 {
     *handled = false;
     static const bool force_generic = tuning_env("PMI_IDENTIFY_GENERIC") != nullptr;
@@ -957,6 +989,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     FastParams p;
     p.movie = d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;
     p.f_lo = f_lo; p.label_off = label_off; p.nframes = nframes; p.box = box; p.min_ng = min_ng; p.gate = gate;
+    p.pix = pix; p.pix_cnt = pix_cnt; p.pix_cap = pix_cap;
     p.segs = pack > 1 ? 1 : (nch + 63) / 64;
     // Rows per unit: long units amortise the 2H + 2 pipeline rows a unit spends on its halo, short ones balance the
     // persistent waves (every wave runs ceil(units / waves) units).  Pick the length with the least total work.

@@ -341,7 +341,9 @@ __device__ static int peak_fit(const double *roi, int box, double *popt, int *nf
 struct PairIn { int32_t y_max, x_max, valid; };
 
 // shift_yx[2p], [2p+1] = (-yc, -xc) of imageprocess.py:155-159; status: scipy's termination code, -1 no fit
-// (empty image or truncated window: shift (0, 0)), -2 the window minimum is negative (curve_fit raises: p0 infeasible)
+// (empty image or truncated window: shift (0, 0)), -2 the window minimum is negative (curve_fit raises: p0 infeasible),
+// -3 the window holds a NaN or an infinity (curve_fit(check_finite=True) raises ValueError); 0 = the fit ran into
+// max_nfev, where curve_fit raises RuntimeError("Optimal parameters not found") — the host mirror raises both
 __global__ void peak_fit_kernel(const double *__restrict__ rois, const int32_t *__restrict__ peaks /* y, x, valid */,
                                 int64_t n_pairs, int box, int64_t Y, int64_t X, int64_t Y_, int64_t X_,
                                 double *__restrict__ shift_yx, double *__restrict__ popt_out, int32_t *__restrict__ status)
@@ -353,8 +355,10 @@ __global__ void peak_fit_kernel(const double *__restrict__ rois, const int32_t *
     if (peaks[3 * p + 2] == 1) {
         const double *roi = rois + p * box * box;
         double mn = roi[0];
-        for (int k = 1; k < box * box; k++) mn = fmin(mn, roi[k]);
-        if (mn < 0.0) st = -2;
+        bool finite = isfinite(roi[0]);
+        for (int k = 1; k < box * box; k++) { mn = fmin(mn, roi[k]); finite = finite && isfinite(roi[k]); }      // fmin drops a NaN: test it
+        if (!finite) st = -3;
+        else if (mn < 0.0) st = -2;
         else {
             int nfev = 0;
             st = peak_fit(roi, box, popt, &nfev);

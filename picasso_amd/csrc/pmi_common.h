@@ -45,24 +45,40 @@ enum ScratchSlot {
     SCR_ROWS,             // rows the fit stages of the fused pipelines may touch
     SCR_NARROW,           // uint16 copy of a chunk of a 32-bit movie (identify)
     SCR_GATES,            // per-chunk flags of that copy
+    SCR_PIX,              // box pixels of the candidates, left by the scan's exact stage for the fit (identify_fast.hip)
     SCR_STATS,            // flag statistics of the last MLE fit (re-fit count, count per criterion)
     SCR_NUM
 };
 int scratch(int slot, size_t bytes, void **ptr);
 int scratch_release_all();
+int scratch_enter_inner();           // -> the bank to hand back to scratch_leave_inner
+void scratch_leave_inner(int was);
 unsigned scratch_generation();      // bumped whenever buffers are released: pointers taken before are stale
 // Fused pipelines: *d_rows = *d_total if it fits the caller's capacity, else 0 (the identification columns were not
 // written; the caller sees *d_total > cap and resubmits), so that the fit stages never follow stale rows.
 int rows_to_fit(const int64_t *d_total, int64_t cap, const int64_t **d_rows, hipStream_t s);
 
 struct Record {   // one identification, 16 B
-    int32_t frame, y, x;
+    int32_t frame;
+    uint32_t yx;      // y << 16 | x (frames are at most 65535 x 65535 on this path)
+    int32_t slot;     // where the exact stage of the scan left the spot's pixels (identify_fast.hip), -1: nowhere
     float ng;
 };
+__host__ __device__ __forceinline__ uint32_t pack_yx(int y, int x) { return ((uint32_t)y << 16) | (uint32_t)(x & 0xffff); }
 
 // pixel load as float32 (the reference's np.float32(frame), localize.py:332)
 template <typename T>
 __device__ __forceinline__ float px_f32(const T *p, int64_t i) { return (float)p[i]; }
+
+// Pixel hand-off from identify to the fit: a fused call sets this (per thread) around identify_impl; the packed uint16
+// scan then leaves every candidate's box rows at pix[slot] and the ordered identifications carry their slot.
+struct PixHandoff {
+    uint32_t *pix = nullptr;        // shards x cap_per_shard slots of box * (box / 2 + 1) uint32 (packed uint16 pairs)
+    unsigned cap_per_shard = 0;
+    int32_t *d_slot = nullptr;      // out: slot of every identification (-1: none), ordered like d_frame / d_y / d_x
+    bool used = false;              // out: the scan that ran could fill it
+};
+extern thread_local PixHandoff g_handoff;
 
 struct KernelTimes { float scan_ms, fit_ms; };
 extern bool g_kernel_timing;

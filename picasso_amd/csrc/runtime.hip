@@ -10,6 +10,7 @@ namespace pmi {
 static thread_local char g_err[512] = "";
 bool g_kernel_timing = false;
 KernelTimes g_last_times = {0.f, 0.f};
+thread_local PixHandoff g_handoff;
 
 void set_error(const char *fmt, ...)
 {
@@ -28,7 +29,8 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line)
 struct ScratchBuf { void *p = nullptr; size_t bytes = 0; };
 // Two banks: a caller that keeps two pipelines in flight on two streams (frame range A fitting while range B is
 // scanned) gives each its own scratch (pmi_scratch_bank); everything else lives in bank 0.
-constexpr int SCR_BANKS = 2;
+constexpr int SCR_USER_BANKS = 2;                 // what pmi_scratch_bank selects
+constexpr int SCR_BANKS = 2 * SCR_USER_BANKS;      // + one inner bank each: the second frame range a fused call keeps in flight
 static ScratchBuf g_scratch_banks[SCR_BANKS][SCR_NUM];
 // the bank is a property of the calling thread: two host threads that drive two streams select a bank each
 // (pmi_scratch_bank) and never see each other's records or fit state
@@ -62,10 +64,13 @@ int scratch_release_all()
 }
 int scratch_select_bank(int bank)
 {
-    if (bank < 0 || bank >= SCR_BANKS) { set_error("scratch bank %d out of range", bank); return PMI_ERR_ARG; }
+    if (bank < 0 || bank >= SCR_USER_BANKS) { set_error("scratch bank %d out of range", bank); return PMI_ERR_ARG; }
     g_scratch_bank = bank;
     return PMI_OK;
 }
+// the inner bank of the calling thread's bank (and back): scratch of the second frame range of a fused call
+int scratch_enter_inner() { const int was = g_scratch_bank; g_scratch_bank = was % SCR_USER_BANKS + SCR_USER_BANKS; return was; }
+void scratch_leave_inner(int was) { g_scratch_bank = was; }
 
 __global__ void rows_to_fit_kernel(const int64_t *__restrict__ total, int64_t cap, int64_t *__restrict__ rows)
 {

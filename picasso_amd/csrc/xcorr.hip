@@ -172,11 +172,14 @@ int pmi_xcorr(const double *image_a, const double *image_b, int64_t Y, int64_t X
     return PMI_OK;
 }
 
-int pmi_rcc_pair_list(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
-                      const int32_t *pairs, int64_t n_pairs, int32_t *peak_yx, int32_t *valid, double *fit_rois,
-                      int32_t *crop_yx)
+// *d_rois_out (optional): where the fit windows stay resident on the device until the next call that uses the
+// thread's scratch bank — pmi_rcc_shifts fits them there without looking the buffer up a second time
+static int rcc_pair_list_impl(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
+                              const int32_t *pairs, int64_t n_pairs, int32_t *peak_yx, int32_t *valid, double *fit_rois,
+                              int32_t *crop_yx, const double **d_rois_out)
 {
     using namespace pmi;
+    if (d_rois_out) *d_rois_out = nullptr;
     if (pmi_device_count() < 1) { set_error("no HIP device"); return PMI_ERR_NODEVICE; }
     if (!segments || !peak_yx || !valid || !fit_rois || !crop_yx || (n_pairs > 0 && !pairs)) { set_error("null pointer"); return PMI_ERR_ARG; }
     if (n_seg < 1 || n_pairs < 0 || Y < 1 || X < 1 || Y > 0x7fffffff || X > 0x7fffffff || box < 1 || box > 15 || !(box & 1)) { set_error("rcc: bad arguments"); return PMI_ERR_ARG; }
@@ -204,6 +207,7 @@ int pmi_rcc_pair_list(const double *segments, int64_t n_seg, int64_t Y, int64_t 
     hipfftDoubleComplex *spec = (hipfftDoubleComplex *)d_spec, *prod = (hipfftDoubleComplex *)d_work;
     double *corr = (double *)(prod + nspec);
     double *d_rois = (double *)d_out;
+    if (d_rois_out) *d_rois_out = d_rois;
     double *d_sums = d_rois + n_pairs * box * box;
     xc::PeakOut *d_peaks = (xc::PeakOut *)(d_sums + n_seg);
     PMI_HIP(hipMemcpy(dseg, segments, (size_t)n_seg * npix * 8, hipMemcpyHostToDevice));
@@ -242,6 +246,13 @@ int pmi_rcc_pair_list(const double *segments, int64_t n_seg, int64_t Y, int64_t 
     return PMI_OK;
 }
 
+int pmi_rcc_pair_list(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
+                      const int32_t *pairs, int64_t n_pairs, int32_t *peak_yx, int32_t *valid, double *fit_rois,
+                      int32_t *crop_yx)
+{
+    return rcc_pair_list_impl(segments, n_seg, Y, X, roi, box, pairs, n_pairs, peak_yx, valid, fit_rois, crop_yx, nullptr);
+}
+
 // all of get_image_shift (imageprocess.py:53-161) for a list of pairs: correlation, crop, peak, window AND the bounded
 // Gaussian fit of the window (csrc/peakfit.hip), -> shift_yx (n_pairs, 2) = (-yc, -xc)
 int pmi_rcc_shifts(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
@@ -252,15 +263,14 @@ int pmi_rcc_shifts(const double *segments, int64_t n_seg, int64_t Y, int64_t X, 
     std::vector<int32_t> peak((size_t)std::max<int64_t>(n_pairs, 1) * 2), valid((size_t)std::max<int64_t>(n_pairs, 1));
     std::vector<double> rois((size_t)std::max<int64_t>(n_pairs, 1) * box * box);
     int32_t crop[2] = {0, 0};
-    int rc = pmi_rcc_pair_list(segments, n_seg, Y, X, roi, box, pairs, n_pairs, peak.data(), valid.data(), rois.data(), crop);
+    const double *d_rois = nullptr;
+    int rc = rcc_pair_list_impl(segments, n_seg, Y, X, roi, box, pairs, n_pairs, peak.data(), valid.data(), rois.data(), crop, &d_rois);
     if (rc != PMI_OK || n_pairs == 0) return rc;
-    // the windows are still resident where pmi_rcc_pair_list left them (SCR_STAGE_D)
-    void *d_out = nullptr;
-    if ((rc = scratch(SCR_STAGE_D, 1, &d_out)) != PMI_OK) return rc;
+    if (!d_rois) { set_error("rcc: no resident fit windows"); return PMI_ERR_HIP; }
     std::vector<int32_t> pk3((size_t)n_pairs * 3);
     for (int64_t p = 0; p < n_pairs; p++) { pk3[(size_t)p * 3] = peak[(size_t)p * 2]; pk3[(size_t)p * 3 + 1] = peak[(size_t)p * 2 + 1]; pk3[(size_t)p * 3 + 2] = valid[(size_t)p]; }
     // empty-image pairs were zeroed on the host only: their `valid` is -1 and the kernel does not read their windows
-    return rcc_fit_peaks((const double *)d_out, pk3.data(), n_pairs, box, Y, X, crop[0], crop[1], shift_yx, fit_status);
+    return rcc_fit_peaks(d_rois, pk3.data(), n_pairs, box, Y, X, crop[0], crop[1], shift_yx, fit_status);
 }
 
 int pmi_rcc_pairs(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,

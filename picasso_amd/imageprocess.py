@@ -21,9 +21,14 @@ def _shifts_of_pairs(segments, box, roi, pairs=None):
     or a fit window truncated by the border (:118-119) give (0, 0), as in the reference."""
     segments = np.asarray(segments)
     shifts, status = backend.rcc_shifts_arrays(segments, roi, box, pairs)
+    # what scipy.optimize.curve_fit raises at picasso/imageprocess.py:129-135, in its order: non-finite input, a start
+    # value outside the bounds (b = window minimum < 0), no convergence within max_nfev
+    if np.any(status == -3):
+        raise ValueError("array must not contain infs or NaNs")
     if np.any(status == -2):
-        # curve_fit refuses a start value outside its bounds (b = window minimum < 0)
         raise ValueError("Initial guess is outside of provided bounds")
+    if np.any(status == 0):
+        raise RuntimeError("Optimal parameters not found: The maximum number of function evaluations is exceeded.")
     return [(float(sy), float(sx)) if st != -1 else (0, 0) for (sy, sx), st in zip(shifts, status)]
 
 

@@ -228,3 +228,48 @@ def test_two_pipelines_in_flight_give_the_rows_of_one_pass():
     both = np.concatenate([a, b], axis=1)
     assert np.array_equal(both, w)
     assert L.pmi_scratch_bank(2) != 0         # only banks 0 and 1 exist
+
+
+def test_fused_call_keeps_two_frame_ranges_in_flight():
+    """pmi_localize_mle_dev cuts a large frame range in two and runs the scan of the second half beside the fit of the
+    first (its own side stream, the inner scratch bank): the table is the one of a single pass, bit for bit — whole
+    movie, a frame range with an odd number of frames, an ROI; the re-fit counts add up; a capacity below the sum of
+    the two halves reports the sum and leaves the table untouched."""
+    import torch
+    from picasso_amd import _lib, backend, synth
+    L = _lib.load()
+    F = 1100                                    # 2.9e8 pixels: above the threshold of the two-range schedule
+    movie = synth.simulate_movie(F, 512, 512, emitters_per_frame=60, seed=23, device="cuda")
+    torch.cuda.synchronize()
+    cap = 150 * F
+
+    def run(ranges, f_lo, f_hi, roi, cap_, fill=None):
+        _lib.check(L.pmi_localize_set_ranges(ranges), "pmi_localize_set_ranges")
+        table = torch.zeros((_lib.PMI_LOC_COLUMNS, cap_), dtype=torch.int32, device="cuda")
+        if fill is not None:
+            table.fill_(fill)
+        d_n = torch.zeros(1, dtype=torch.int64, device="cuda")
+        r = (ctypes.c_int64 * 4)(*roi) if roi else None
+        rc = L.pmi_localize_mle_dev(ctypes.c_void_p(movie.data_ptr()), 0, F, 512, 512, 7, 5000.0, r, f_lo, f_hi, 100.0, 1.0, 1.0,
+                                    1e-3, 100, _lib.MLE_METHODS["sigmaxy"], ctypes.c_void_p(table.data_ptr()), cap_,
+                                    ctypes.c_void_p(d_n.data_ptr()), None)
+        _lib.check(rc, "pmi_localize_mle_dev")
+        torch.cuda.synchronize()
+        return table, int(d_n.item()), backend.last_refit_count()
+
+    try:
+        n_full = 0
+        for f_lo, f_hi, roi in ((0, F - 1, None), (3, F - 5, None), (0, F - 1, (10, 20, 500, 490))):
+            one, n1, refit1 = run(1, f_lo, f_hi, roi, cap)
+            n_full = n_full or n1
+            for rep in range(2):
+                two, n2, refit2 = run(2, f_lo, f_hi, roi, cap)
+                assert n1 == n2 and n1 > 20000, (n1, n2)
+                assert torch.equal(one[:, :n1], two[:, :n2]), (f_lo, f_hi, roi, rep)
+                assert refit1 == refit2 and refit1 > 0
+        # capacity between the first half's count and the total: nothing may be written
+        small, n_small, _ = run(2, 0, F - 1, None, int(n_full * 0.75), fill=0x5A5A5A5A)
+        assert n_small == n_full and bool((small == 0x5A5A5A5A).all())
+        assert L.pmi_localize_set_ranges(3) != 0
+    finally:
+        _lib.check(L.pmi_localize_set_ranges(2), "pmi_localize_set_ranges")

@@ -114,3 +114,18 @@ def test_regression_tiny_boxes(be, orc):
     for seed in (3, 33, 333):
         spots = knob_spots(3, 30000, seed)
         check_case(be, orc, spots, 1e-3, 100, "sigma", f"box 3 sigma seed {seed}")
+
+
+@pytest.mark.xfail(strict=False, reason="known residuals of the 30-minute fuzz run of round 3 (DESIGN.md section 2): 3 spots of 2.3e7")
+def test_fuzz_residuals_round3(be, orc):
+    """The three spots tools/fuzz_parity.py left after 23.2 million (tests/golden/mle_fuzz_regressions): two 3x3 fits whose
+    width collapses to 0.034 px and that run 87+ iterations — there even the strict mode differs from the oracle (the
+    device's float64 erf / exp are not glibc's to the last ulp, and the trajectory is chaotic) — and one 13x13 fit at
+    max_it = 20 whose iteration has an alternating mode of factor -1.35 that had not grown out of the rounding noise
+    when the fit stopped.  Kept as inputs so that a later flag rule can be tried against them."""
+    import glob
+    import os
+    from conftest import GOLDEN
+    for path in sorted(glob.glob(os.path.join(GOLDEN, "mle_fuzz_regressions", "mle_*.npz"))):
+        z = np.load(path)
+        check_case(be, orc, z["spots"], float(z["eps"]), int(z["max_it"]), str(z["method"]), os.path.basename(path))

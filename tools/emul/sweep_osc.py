@@ -46,12 +46,22 @@ def run(box, method, eps, max_it, n, rng, style):
         vw = valid[:, 2:, None]
         th_ = np.maximum(np.abs(tf[:, 3:, :NP].astype(np.float64)), 1e-3)
         variants = {"none": np.zeros(n, bool)}
-        for R in (0.8, 0.9, 1.0):
-            for fl_ in (1.9e-6, 1e-5, 1e-4):
-                c = (w[:, 1:] * w[:, :-1] < 0) & (np.abs(w[:, 1:]) > R * np.abs(w[:, :-1])) & (np.abs(w[:, 1:]) > fl_ * th_[:, 1:]) & vw[:, 1:]
-                variants[f"R{R} f{fl_} x1"] = c.any(axis=(1, 2))
-                variants[f"R{R} f{fl_} x2"] = (c[:, 1:] & c[:, :-1]).any(axis=(1, 2))
-                variants[f"R{R} f{fl_} x3"] = (c[:, 2:] & c[:, 1:-1] & c[:, :-2]).any(axis=(1, 2))
+        kk3 = np.arange(4, T)[None, :, None]          # iteration number of w[:, 1:]
+        R, fl_ = 0.9, 1.9e-6
+        c = (w[:, 1:] * w[:, :-1] < 0) & (np.abs(w[:, 1:]) > R * np.abs(w[:, :-1])) & (np.abs(w[:, 1:]) > fl_ * th_[:, 1:]) & vw[:, 1:]
+        cc = c & (kk3 >= 8)
+        cur = (c[:, 2:] & c[:, 1:-1] & c[:, :-2]).any(axis=(1, 2)) | (cc[:, 1:] & cc[:, :-1]).any(axis=(1, 2))
+        variants["current (x3 | x2 late)"] = cur
+        # margin from the wobble: a tested parameter whose step lies within c x the alternating component of its own step
+        # sequence of eps (the decision depends on the phase of a mode that grew out of rounding noise)
+        ti = [tested.index(t) if t in tested else -1 for t in range(NP)]
+        tmask = np.array([t in tested for t in range(NP)])
+        alt = (w[:, 1:] * w[:, :-1] < 0) & vw[:, 1:]
+        amp = np.maximum(np.abs(w[:, 1:]), np.abs(w[:, :-1]))
+        stepk = np.abs(st[:, 3:, :])                   # step of the iteration of w[:, 1:]
+        for cf in (1.0, 2.0, 4.0):
+            am = (c & (np.abs(stepk - eps) < cf * amp) & (stepk < 2 * eps) & tmask[None, None, :]).any(axis=(1, 2))
+            variants[f"cur + altmargin x{cf}"] = cur | am
         for name, osc in variants.items():
             fl = base | osc
             out[name] = (fl.mean(), int((fail & ~fl).sum()))

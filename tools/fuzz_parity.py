@@ -116,26 +116,30 @@ while time.time() < t_end:
                 np.savez_compressed(f"gpurun_out/fuzz_fail/mle_{seed}_{counts['mle']}.npz", spots=spots[rows], box=box, method=method, eps=eps,
                                     max_it=max_it, theta_gpu=th[rows], theta_orc=oth[rows], it_gpu=it[rows], it_orc=oit[rows])
         elif which < 9:
-            box = int(rng.choice([3, 5, 7, 9, 11, 13]))
-            n = 64
+            box = int(rng.choice([3, 5, 7, 9, 11, 13, 15, 21]))
+            n = 2048 if box <= 13 else 512
             c = box // 2
             idx = np.arange(box) - c
-            spots = np.empty((n, box, box), np.float32)
-            for i in range(n):
-                x0, y0 = rng.uniform(-1.2, 1.2, 2)
-                sx, sy = rng.uniform(0.6, 0.25 * box + 0.5, 2)
-                gx = np.exp(-0.5 * ((idx - x0) / sx) ** 2) / (np.sqrt(2 * np.pi) * sx)
-                gy = np.exp(-0.5 * ((idx - y0) / sy) ** 2) / (np.sqrt(2 * np.pi) * sy)
-                spots[i] = rng.poisson(rng.uniform(100, 9000) * np.outer(gy, gx) + rng.uniform(0.5, 60))
+            x0 = rng.uniform(-1.2, 1.2, n); y0 = rng.uniform(-1.2, 1.2, n)
+            sx = rng.uniform(0.6, 0.25 * box + 0.5, n); sy = rng.uniform(0.6, 0.25 * box + 0.5, n)
+            gx = np.exp(-0.5 * ((idx[None, :] - x0[:, None]) / sx[:, None]) ** 2) / (np.sqrt(2 * np.pi) * sx[:, None])
+            gy = np.exp(-0.5 * ((idx[None, :] - y0[:, None]) / sy[:, None]) ** 2) / (np.sqrt(2 * np.pi) * sy[:, None])
+            spots = rng.poisson(rng.uniform(100, 9000, n)[:, None, None] * gy[:, :, None] * gx[:, None, :]
+                                + rng.uniform(0.5, 60, n)[:, None, None]).astype(np.float32)
             th, info, nfev = be.gausslq_arrays(spots, full_output=True)
-            oth, oinfo, onfev = orc.gausslq(spots, full=True, threads=4)
+            oth, oinfo, onfev = orc.gausslq(spots, full=True, threads=orc.max_threads())
             counts["lq"] += 1
             exact = np.all((th == oth) | (np.isnan(th) & np.isnan(oth)), axis=1)
             fin = np.all(np.isfinite(oth), axis=1)
             md = np.max(np.abs(th[fin][:, [0, 1, 4, 5]] - oth[fin][:, [0, 1, 4, 5]])) if fin.any() else 0
-            if exact.mean() < 0.9 or md > 2e-3 or (info != oinfo).mean() > 0.1:
+            counts["lq_spots"] = counts.get("lq_spots", 0) + n
+            counts["lq_not_identical"] = counts.get("lq_not_identical", 0) + int((~exact).sum())
+            # every spot inside the tolerance, MINPACK's verdict (info) on every spot; bit-identity is counted over the run
+            if md > 1e-3 or (info != oinfo).any():
                 fails += 1
-                print("LQ MISMATCH", box, "exact", exact.mean(), "maxdiff", md, "info", (info != oinfo).mean(), flush=True)
+                w = int(np.argmax(np.where(fin, np.abs(th[:, [0, 1, 4, 5]] - oth[:, [0, 1, 4, 5]]).max(axis=1), 0)))
+                print("LQ MISMATCH", box, "not identical", int((~exact).sum()), "of", n, "maxdiff", md, "info differs", int((info != oinfo).sum()),
+                      "row", w, "gpu", th[w].tolist(), "orc", oth[w].tolist(), "refit", be.last_lq_refit_count(), flush=True)
         else:
             N = int(rng.integers(1, 5000))
             H, W = int(rng.integers(8, 80)), int(rng.integers(8, 80))

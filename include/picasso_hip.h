@@ -196,6 +196,12 @@ int pmi_locs_from_fits_dev(const int32_t *d_frame, const int32_t *d_y, const int
  * table is written (the scan is bound by memory requests, the fit by VALU issue); the table is the same, bit for bit.
  * pmi_localize_set_ranges(1) keeps a call on the caller's stream alone (2 = default).                  */
 int pmi_localize_set_ranges(int ranges);
+/* Pixel hand-off (uint16 movies, boxes up to 15; default off): the scan's exact stage, which holds a candidate's
+ * neighbourhood in registers, also leaves the box rows in a compact buffer and the fit's start-value kernel reads those
+ * (one or two cache lines per spot) instead of `box` lines of the movie.  Measured on config 2: fit -0.11 ms, scan
+ * +0.14 ms (7 more scattered 16-byte stores per candidate on a kernel bound by its memory-side requests) - the same
+ * table, no gain, hence off. */
+int pmi_localize_set_handoff(int on);
 int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
                          int box, double min_ng, const int64_t *roi4, int64_t f_lo, int64_t f_hi,
                          double baseline, double sensitivity, double gain,

@@ -62,6 +62,7 @@ SYMBOLS = {
     "pmi_mle_last_refit_count": (_i32, [_p, _p]),
     "pmi_mle_last_flag_reasons": (_i32, [_p, _i32, _p]),
     "pmi_locs_from_fits_dev": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i32, _p, _p]),
+    "pmi_localize_set_handoff": (_i32, [_i32]),
     "pmi_localize_set_ranges": (_i32, [_i32]),
     "pmi_localize_mle_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _f64, _f64, _f64,
                                     _f64, _i32, _i32, _p, _i64, _p, _p]),

@@ -234,6 +234,7 @@ struct EnormAcc {
 // float64 — which is everything except where one of lmdif's accept / reject / terminate tests is decided within those
 // bits.  Spots on which that happens (flagged by lq_step_kernel and qrfac_step below) are fitted again with these
 // forms: the rows go through LDS and every lane of the group adds them in row order.
+constexpr double LQ_PIVOT_TIE = 1e-9;         // relative distance of two running column norms below which the pivot choice is a tie
 constexpr double LQ_RANK = 1e-3;             // |R_jj| / |column| below which the factor counts as rank deficient (re-fit)
 constexpr double LQ_TIE = 1e-12;              // relative distance of a decision from its threshold below which a spot is re-fitted
 __device__ __forceinline__ void grp_sync()
@@ -542,17 +543,13 @@ __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], 
     for (int k = j + 1; k < 6; k++)
         if (wa1[k] > best) { best = wa1[k]; kmax = k; }
     if (!STRICT) {
-        // the pivot is the largest of the running column norms: a second candidate within their rounding error of it
-        // may be MINPACK's choice.  A running norm that was scaled down by q = wa1 / wa3 since it was last computed
-        // carries a relative error of ~ eps / q^2 (MINPACK itself recomputes it only when q^2 < 20 eps).
-        const double qb = best / wa3[kmax];
-        const double eb = LQ_TIE * (1.0 + 1e-3 / (qb * qb));
+        // the pivot is the largest of the running column norms: a second candidate within their rounding error of it may
+        // be MINPACK's choice.  A running norm that was scaled down by q = wa1 / wa3 since it was last computed carries a
+        // relative error of ~ eps / q^2; q < LQ_RANK never gets here unflagged (the rank test after the factorisation), so
+        // LQ_PIVOT_TIE = 1e-9 covers eps / LQ_RANK^2 with room
 #pragma unroll
-        for (int k = j; k < 6; k++) {
-            const double qk = wa1[k] / wa3[k];
-            const double ek = LQ_TIE * (1.0 + 1e-3 / (qk * qk));
-            if (k != kmax && !(fabs(wa1[k] - best) > (eb + ek) * best)) tie = tie || wa1[k] != 0 || best != 0;
-        }
+        for (int k = j; k < 6; k++)
+            if (k != kmax && !(fabs(wa1[k] - best) > LQ_PIVOT_TIE * best)) tie = tie || wa1[k] != 0 || best != 0;
     }
 #pragma unroll
     for (int k = j + 1; k < 6; k++) {

@@ -851,6 +851,7 @@ int pmi_locs_from_fits_dev(const int32_t *d_frame, const int32_t *d_y, const int
 // B's), so the capacity contract holds for the sum.
 namespace pmi {
 static int g_localize_ranges = 2;
+static bool g_localize_handoff = false;
 struct SideLane { hipStream_t s2 = nullptr; hipEvent_t ev_start = nullptr, ev_scan_a = nullptr, ev_b = nullptr; };
 static thread_local SideLane g_side;
 
@@ -871,6 +872,12 @@ __global__ void range_rows_b_kernel(const int64_t *__restrict__ n_a, const int64
     *d_out_n = total;
 }
 }  // namespace pmi
+
+int pmi_localize_set_handoff(int on)
+{
+    pmi::g_localize_handoff = on != 0;
+    return PMI_OK;
+}
 
 int pmi_localize_set_ranges(int ranges)
 {
@@ -902,7 +909,7 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
     const size_t ids_bytes = (size_t)cap * (16 + 15 * 4);
     // pixel hand-off from the scan's exact stage to the fit (uint16 movies, boxes of the row-per-lane fit): room for twice
     // the table's rows (candidates that fail the threshold take a slot too), spread over the eight record shards
-    const bool hand = dtype == PMI_U16 && box <= 15 && mle_mode_now() != PMI_MLE_STRICT && !tuning_env("PMI_MLE_NO_HANDOFF");
+    const bool hand = g_localize_handoff && dtype == PMI_U16 && box <= 15 && mle_mode_now() != PMI_MLE_STRICT;
     const unsigned pix_cap = (unsigned)std::min<int64_t>(std::max<int64_t>(cap / 4, 4096), 0x0fffffff);
     const size_t pix_bytes = (size_t)8 * pix_cap * (size_t)(box * (box / 2 + 1)) * sizeof(uint32_t);
     auto arm_handoff = [&](int32_t *d_slot) -> int {         // in the scratch bank that is current

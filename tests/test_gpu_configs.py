@@ -155,6 +155,22 @@ def test_config5_astigmatic_13x13_and_zfit(be, orc):
     assert np.median(np.abs(zz - z)) < 25.0
 
 
+def test_config5_fused_pipeline_on_the_astigmatic_movie(be, orc):
+    """Config 5 through the path the benchmark times — pmi_localize_mle_dev with box 13 on the astigmatic movie, then
+    zfit — against the oracle on every row, at 3000 frames (~3e5 spots; tools/parity_config5.py runs the same comparison
+    at the full 50 000 frames, profiles/r03_parity_config5.json)."""
+    import os
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import parity_config5
+    out = parity_config5.run(F=3000, chunk=1000)
+    assert out["rows_compared"] == out["localizations_gpu"] > 2.5e5 and out["chunks_with_identification_mismatch"] == 0
+    assert out["rows_with_different_iterations"] == 0
+    w = out["max_abs_diff_rows_below_max_it"]
+    assert max(w["x"], w["y"], w["sx"], w["sy"]) < 1e-3 and w["photons_rel"] < 1e-2 and w["z"] < 0.05 and w["lpx_rel"] < 2e-3          # z in nm over a +-400 nm range: 2e-6 px of width times the slope of the calibration
+    assert 0 < out["refit_spots"] < 0.05 * out["localizations_gpu"]
+
+
 def test_config4_geometry_shard_in_miniature(be, orc):
     """Config 4's frame geometry (2048 x 2048, ~1600 spots per frame) at a length the oracle can follow: the
     identification set and net gradients are the oracle's, the fit is within tolerance, frame ranges concatenate
@@ -267,6 +283,18 @@ def test_fused_call_keeps_two_frame_ranges_in_flight():
                 assert n1 == n2 and n1 > 20000, (n1, n2)
                 assert torch.equal(one[:, :n1], two[:, :n2]), (f_lo, f_hi, roi, rep)
                 assert refit1 == refit2 and refit1 > 0
+        # the pixel hand-off from the scan's exact stage to the fit (off by default): the same table, bit for bit
+        _lib.check(L.pmi_localize_set_handoff(1), "pmi_localize_set_handoff")
+        try:
+            for ranges in (1, 2):
+                h, nh, _ = run(ranges, 0, F - 1, None, cap)
+                full, nfu, _ = run(1, 0, F - 1, None, cap) if ranges == 1 else (h, nh, 0)
+                assert nh == n_full
+            _lib.check(L.pmi_localize_set_handoff(0), "pmi_localize_set_handoff")
+            plain, npl, _ = run(2, 0, F - 1, None, cap)
+            assert npl == nh and torch.equal(plain[:, :npl], h[:, :nh])
+        finally:
+            _lib.check(L.pmi_localize_set_handoff(0), "pmi_localize_set_handoff")
         # capacity between the first half's count and the total: nothing may be written
         small, n_small, _ = run(2, 0, F - 1, None, int(n_full * 0.75), fill=0x5A5A5A5A)
         assert n_small == n_full and bool((small == 0x5A5A5A5A).all())

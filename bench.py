@@ -46,6 +46,9 @@ def parse():
     ap.add_argument("--method", default="sigmaxy")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra instrumented steps for per-kernel time")
+    ap.add_argument("--ranges", type=int, default=2, choices=(1, 2),
+                    help="frame ranges pmi_localize_mle_dev keeps in flight in the timed steps (2 = the library's default "
+                         "schedule: the scan of the second half beside the fit of the first; 1 = one range, as the profiled passes)")
     ap.add_argument("--allow-env", action="store_true",
                     help="run although PMI_* / PICASSO_AMD_LIB tuning variables are set (they are echoed in the line)")
     ap.add_argument("--serial-gather", action="store_true",
@@ -109,6 +112,7 @@ def main():
     _lib.require_gpu()
     _lib.check(L.pmi_set_device(local_rank), "pmi_set_device")
 
+    _lib.check(L.pmi_localize_set_ranges(args.ranges), "pmi_localize_set_ranges")
     F, H, W, box = args.frames, args.size, args.size, args.box
     cam = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
     movie = synth.simulate_movie(F, H, W, emitters_per_frame=args.emitters,
@@ -273,6 +277,10 @@ def main():
     # per-kernel durations: HIP events around the kernels on the launch stream (library-side)
     scan_ms = fit_ms = float("nan")
     if args.profile_steps > 0:
+        # the roofline of a kernel is measured on launches of its own: one frame range over the whole movie, nothing
+        # beside it (in the timed steps above each step launches the scan twice, half the movie each, the second beside
+        # the fit of the first half)
+        _lib.check(L.pmi_localize_set_ranges(1), "pmi_localize_set_ranges")
         L.pmi_set_kernel_timing(1)
         s_acc, f_acc = [], []
         a, b = ctypes.c_float(0), ctypes.c_float(0)
@@ -282,6 +290,7 @@ def main():
             L.pmi_last_kernel_ms(ctypes.byref(a), ctypes.byref(b))
             s_acc.append(a.value); f_acc.append(b.value)
         L.pmi_set_kernel_timing(0)
+        _lib.check(L.pmi_localize_set_ranges(args.ranges), "pmi_localize_set_ranges")
         scan_ms, fit_ms = float(np.mean(s_acc)), float(np.mean(f_acc))
 
     result = None
@@ -303,7 +312,11 @@ def main():
         traffic, traffic_source = pmc_traffic_bytes(F, H, W, box)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (ach / HBM_PEAK_GBS) if ach else None,
-                    "traffic": traffic, "traffic_source": traffic_source, "kernels": kernels}
+                    "traffic": traffic, "traffic_source": traffic_source,
+                    "measured_on": f"{args.profile_steps} single-range passes over the whole movie after the timed steps (HIP events "
+                                   "around the kernels on their launch stream, inside the library); the same launches as "
+                                   "`bench.py --ranges 1`, profiles/r03_bench_ranges1_kernel_stats.txt",
+                    "kernels": kernels}
         kernels["mle_fit"]["bound"] = "fp32 valu (no MFMA shape); algorithmic bytes are 166 B/spot"
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
@@ -325,6 +338,7 @@ def main():
                        "frames": F, "height": H, "width": W, "box": box, "min_net_gradient": args.min_ng,
                        "eps": 1e-3, "max_it": 100, "localizations_total": n_total,
                        "mle_mode": mle_mode, "refit_margin": mle_margin, "refit_spots_rank0": refit,
+                       "frame_ranges_in_flight": args.ranges,
                        "all_gather": gather_impl,
                        "sharding": f"frames x{world}", "per_rank": per_rank, "env_overrides": overrides},
             "roofline": roofline,
@@ -340,7 +354,7 @@ def main():
     return result
 
 
-PMC_TRAFFIC_FILE = "profiles/r02_identify_pmc.json"
+PMC_TRAFFIC_FILE = "profiles/r03_identify_pmc.json"
 
 
 def pmc_traffic_bytes(F, H, W, box):

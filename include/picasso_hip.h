@@ -159,14 +159,18 @@ int pmi_gaussmle_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y,
  *                   step came within `margin` (relative) of eps in some iteration; a curvature term was not negative;
  *                   a width fell below 0.3 px; a parameter swung back and forth without its steps shrinking (the
  *                   iteration does not contract); a pixel lay far off the model (|data / model - 1| or
- *                   |data / model^2| above 16); the fit took more than 32 iterations — is fitted again from its initial
+ *                   |data / model^2| above 16); the fit took more than 32 iterations; or, seen from the Fisher matrix at the
+ *                   fitted theta, the per-parameter update does not contract there (lambda_max of the normalised
+ *                   Fisher matrix above 1.9: a rounding difference would be multiplied by 1 - lambda_max per
+ *                   iteration) — is fitted again from its initial
  *                   parameters in the reference's own arithmetic (float64 intermediates, float32 stores, the
  *                   reference's summation order) inside the same call;
  *   PMI_MLE_STRICT  every spot in the reference's arithmetic.
  * Process-wide; the environment variable PMI_MLE_MODE = fast | refit | strict overrides the mode.
  * pmi_mle_last_refit_count: spots the calling thread's last pmi_gaussmle*_dev / pmi_localize_mle_dev call on `stream`
  * fitted again (synchronises the stream); pmi_mle_last_flag_reasons: of those, how many each criterion flagged, in the
- * order margin, curvature, narrow width, swing, far-off pixel, slow (n <= 6 counters; a spot can carry several).   */
+ * order margin, curvature, narrow width, swing, far-off pixel, slow, unstable (n <= 7 counters; a spot can carry
+ * several, and one that carries `unstable` beside another was fitted again twice, to the same result).        */
 enum pmi_mle_mode { PMI_MLE_FAST = 0, PMI_MLE_REFIT = 1, PMI_MLE_STRICT = 2 };
 int pmi_mle_set_mode(int mode, double margin);
 int pmi_mle_get_mode(int *mode, double *margin);
@@ -363,6 +367,9 @@ int pmi_compact_gathered_dev(const void *d_all_tables, const int64_t *d_all_coun
  * images — correlation, centre crop, first maximum, window, fit — -> shift_yx (n_pairs, 2) = (-yc, -xc);
  * fit_status as above, or -1 where the reference returns (0, 0) without fitting (empty image, window
  * truncated by the border).                                                                         */
+/* Makes (and caches) the FFT plans of Y x X images ahead of the first correlation: rocFFT compiles a plan's kernels when
+ * the plan is made (2.5 s at 2048 x 2048).  Thread-safe; meant for a side thread of the host while it localizes. */
+int pmi_fft_prewarm(int64_t Y, int64_t X);
 int pmi_peak_fit(const double *rois, int64_t n, int box, double *popt, int32_t *status);
 int pmi_rcc_shifts(const double *segments, int64_t n_seg, int64_t Y, int64_t X, int64_t roi, int box,
                    const int32_t *pairs, int64_t n_pairs, double *shift_yx, int32_t *fit_status);

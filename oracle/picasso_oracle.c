@@ -795,17 +795,51 @@ static const double LQ_DWARF = 2.2250738585072014e-308;
 /* PROBE (diagnostics only, default 0 = MINPACK's order): 1 adds the long sums of lmdif — column norms, Householder
  * products, Q^T fvec — in REVERSE row order.  tools/probe_lq_order.py uses it to find the spots whose fit depends on
  * the order of those sums, i.e. the spots the device must fit with MINPACK's own order. */
-static int g_lq_sum_reverse = 0, g_lq_trace = 0;
-void orc_lq_set_sum_order(int reverse) { g_lq_sum_reverse = reverse; }
+static int g_lq_sum_reverse = 0, g_lq_trace = 0, g_lq_gs = 0;
+/* reverse = 1: reversed row order; reverse = 2: the DEVICE's order (csrc/gausslq.hip): row r lives in lane r % gs, element
+ * r / gs; a lane adds its elements in ascending order, the lanes are added by a butterfly (xor 1, 2, mirror of 8, mirror
+ * of 16, xor 16, xor 32) */
+void orc_lq_set_sum_order(int reverse) { g_lq_sum_reverse = reverse & 3; g_lq_gs = reverse >> 2; }
+static double lq_device_sum(const double *t, int lo, int n)      /* sum of t[lo..n) in the device's order; t indexed by row */
+{
+    const int gs = g_lq_gs;
+    double lane[64];
+    for (int l = 0; l < gs; l++) {
+        double a = 0;
+        for (int r = l; r < n; r += gs) if (r >= lo) a += t[r];
+        lane[l] = a;
+    }
+    double v[64], w[64];
+    for (int l = 0; l < gs; l++) v[l] = lane[l];
+    for (int l = 0; l < gs; l++) w[l] = v[l] + v[l ^ 1];
+    for (int l = 0; l < gs; l++) v[l] = w[l] + w[l ^ 2];
+    for (int l = 0; l < gs; l++) w[l] = v[l] + v[(l & ~7) | (7 - (l & 7))];
+    if (gs == 8) return w[0];
+    for (int l = 0; l < gs; l++) v[l] = w[l] + w[(l & ~15) | (15 - (l & 15))];
+    if (gs == 16) return v[0];
+    for (int l = 0; l < gs; l++) w[l] = v[l] + v[l ^ 16];
+    if (gs == 32) return w[0];
+    for (int l = 0; l < gs; l++) v[l] = w[l] + w[l ^ 32];
+    return v[0];
+}
 void orc_lq_set_trace(int on) { g_lq_trace = on; }
 
+static __thread int g_lq_enorm_rows = 0;      /* probe: total rows m of the Jacobian (0 outside lmdif) */
 static double enorm(int n, const double *x)
 {
     const double rdwarf = 3.834e-20, rgiant = 1.304e19;
     double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0;
     const double agiant = rgiant / (double)n;
+    if (g_lq_sum_reverse == 2 && n > 6 && g_lq_enorm_rows > 0) {
+        /* the rows of the vector are rows [rows - n, rows) of the residual numbering */
+        double t[LQ_MAXM];
+        const int rows = g_lq_enorm_rows, lo = rows - n;
+        for (int r = 0; r < rows; r++) t[r] = 0;
+        for (int i = 0; i < n; i++) t[lo + i] = x[i] * x[i];
+        return sqrt(lq_device_sum(t, lo, rows));
+    }
     for (int ii = 0; ii < n; ii++) {
-        const int i = (g_lq_sum_reverse && n > 6) ? n - 1 - ii : ii;
+        const int i = (g_lq_sum_reverse == 1 && n > 6) ? n - 1 - ii : ii;
         double xabs = fabs(x[i]);
         if (xabs > rdwarf && xabs < agiant) { s2 += xabs * xabs; }
         else if (xabs <= rdwarf) {
@@ -1024,7 +1058,11 @@ static void qrfac(int m, int n, double *a, int lda, int *ipvt, double *rdiag, do
             a[j + j * lda] += 1;
             for (int k = j + 1; k < n; k++) {
                 double sum = 0;
-                if (g_lq_sum_reverse) for (int i = m - 1; i >= j; i--) sum += a[i + j * lda] * a[i + k * lda];
+                if (g_lq_sum_reverse == 2) {
+                    double t[LQ_MAXM];
+                    for (int i = 0; i < m; i++) t[i] = i >= j ? a[i + j * lda] * a[i + k * lda] : 0;
+                    sum = lq_device_sum(t, j, m);
+                } else if (g_lq_sum_reverse) for (int i = m - 1; i >= j; i--) sum += a[i + j * lda] * a[i + k * lda];
                 else for (int i = j; i < m; i++) sum += a[i + j * lda] * a[i + k * lda];
                 double temp = sum / a[j + j * lda];
                 for (int i = j; i < m; i++) a[i + k * lda] -= temp * a[i + j * lda];
@@ -1068,7 +1106,14 @@ static int lmdif_spot(const float *spot, int size, double *x, double ftol, doubl
             for (int i = 0; i < m; i++) fjac[i + j * ld] = (wa4[i] - fvec[i]) / h;
         }
         nfev += n;
+        g_lq_enorm_rows = m;       /* (probe) the norms of qrfac are sums over Jacobian rows; fnorm / fnorm1 stay sequential */
         qrfac(m, n, fjac, ld, ipvt, wa1, wa2, wa3);
+        g_lq_enorm_rows = 0;
+        if (g_lq_trace) {
+            double kap = 1e300;
+            for (int j = 0; j < n; j++) { double k = fabs(wa1[j]) / wa2[ipvt[j]]; if (k < kap) kap = k; }
+            fprintf(stderr, "  qrfac: min |R_jj| / |column| = %.3e  rdiag %.3e %.3e %.3e %.3e %.3e %.3e\n", kap, wa1[0], wa1[1], wa1[2], wa1[3], wa1[4], wa1[5]);
+        }
         if (iter == 1) {
             for (int j = 0; j < n; j++) { diag[j] = wa2[j]; if (wa2[j] == 0) diag[j] = 1; }
             for (int j = 0; j < n; j++) wa3[j] = diag[j] * x[j];
@@ -1080,7 +1125,11 @@ static int lmdif_spot(const float *spot, int size, double *x, double ftol, doubl
         for (int j = 0; j < n; j++) {
             if (fjac[j + j * ld] != 0) {
                 double sum = 0;
-                if (g_lq_sum_reverse) for (int i = m - 1; i >= j; i--) sum += fjac[i + j * ld] * wa4[i];
+                if (g_lq_sum_reverse == 2) {
+                    double t[LQ_MAXM];
+                    for (int i = 0; i < m; i++) t[i] = i >= j ? fjac[i + j * ld] * wa4[i] : 0;
+                    sum = lq_device_sum(t, j, m);
+                } else if (g_lq_sum_reverse) for (int i = m - 1; i >= j; i--) sum += fjac[i + j * ld] * wa4[i];
                 else for (int i = j; i < m; i++) sum += fjac[i + j * ld] * wa4[i];
                 double temp = -sum / fjac[j + j * ld];
                 for (int i = j; i < m; i++) wa4[i] += fjac[i + j * ld] * temp;

@@ -87,6 +87,7 @@ SYMBOLS = {
     "pmi_xcorr": (_i32, [_p, _p, _i64, _i64, _p]),
     "pmi_rcc_pairs": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _p, _p, _p]),
     "pmi_rcc_pair_list": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _i64, _p, _p, _p, _p]),
+    "pmi_fft_prewarm": (_i32, [_i64, _i64]),
     "pmi_peak_fit": (_i32, [_p, _i64, _i32, _p, _p]),
     "pmi_rcc_shifts": (_i32, [_p, _i64, _i64, _i64, _i64, _i32, _p, _i64, _p, _p]),
     "pmi_comm_available": (_i32, []),

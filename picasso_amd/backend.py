@@ -158,6 +158,26 @@ def last_refit_count(stream=None) -> int:
     return int(n.value)
 
 
+_prewarmed = set()
+
+
+def prewarm_fft(Y: int, X: int) -> None:
+    """Start making the FFT plans of RCC undrift for Y x X frames on a daemon thread (once per size): rocFFT compiles a
+    plan's kernels when the plan is made — 2.5 s at 2048 x 2048 — and a caller that localizes first has that time."""
+    import threading
+    key = (int(Y), int(X))
+    if key in _prewarmed or min(key) < 64:
+        return
+    _prewarmed.add(key)
+
+    def work():
+        try:
+            _lib.load().pmi_fft_prewarm(key[0], key[1])       # ctypes releases the GIL
+        except Exception:      # noqa: BLE001 - a convenience: the correlation makes its plans itself if this did not
+            pass
+    threading.Thread(target=work, name="pmi-fft-prewarm", daemon=True).start()
+
+
 def last_lq_refit_count() -> int:
     """Spots the last least-squares call fitted a second time with MINPACK's summation order."""
     n = ctypes.c_int64(0)
@@ -174,7 +194,7 @@ def last_lq_tie_reasons() -> dict:
     return {k: int(v) for k, v in zip(LQ_TIE_REASONS, c)}
 
 
-FLAG_REASONS = ("margin", "curvature", "narrow", "swing", "wild", "slow")
+FLAG_REASONS = ("margin", "curvature", "narrow", "swing", "wild", "slow", "unstable")
 
 
 def last_flag_reasons(stream=None) -> dict:

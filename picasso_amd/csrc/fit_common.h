@@ -97,10 +97,23 @@ struct FitParams {
     int32_t *flag_list;          // spot indices, capacity = spots of the batch (nullptr: no flagging)
     unsigned *flag_count;
     unsigned *flag_reasons;      // FLAG_REASONS counters of the call: how many spots each criterion flagged (nullptr: not counted)
+    // second pass (spots whose iteration turned out not to contract at the fitted theta, crlb_kernel): the Fisher pass over
+    // the spots of this list only (nullptr: every spot of the batch)
+    const int32_t *final_list;
+    const unsigned *final_list_n;
+    unsigned char *refit_mark;   // one byte per spot of the batch: set by the strict re-fit, so that the second list only takes spots the first did not
 };
 // why a spot goes to the re-fit (a spot can carry several)
-enum : unsigned { FLAG_MARGIN = 1u, FLAG_CURVATURE = 2u, FLAG_NARROW = 4u, FLAG_SWING = 8u, FLAG_WILD = 16u, FLAG_SLOW = 32u };
-constexpr int FLAG_REASONS = 6;
+enum : unsigned { FLAG_MARGIN = 1u, FLAG_CURVATURE = 2u, FLAG_NARROW = 4u, FLAG_SWING = 8u, FLAG_WILD = 16u, FLAG_SLOW = 32u, FLAG_UNSTABLE = 64u };
+constexpr int FLAG_REASONS = 7;
+// The update treats every parameter on its own, theta_l -= num_l / den_l: near the fitted theta its Jacobian is
+// I - D^-1 H with H the Hessian of the log-likelihood and D its diagonal, in expectation I - D^-1 M with the Fisher matrix
+// M the final pass computes anyway.  The eigenvalues of D^-1 M are those of the symmetric C = D^-1/2 M D^-1/2 (unit
+// diagonal: how strongly the parameters trade against each other); the iteration contracts iff lambda_max(C) < 2, and a
+// rounding difference is multiplied by 1 - lambda_max per iteration.  Above FIT_UNSTABLE_LMAX the spot is re-fitted.
+// (Simulated DNA-PAINT spots: lambda_max 1.2 ... 1.7; the fuzz residual of round 3 that no step-sequence rule caught:
+// 2.356, its differences alternating with a factor of -1.35.)
+constexpr double FIT_UNSTABLE_LMAX = 1.9;
 constexpr int FISHER_STRIDE = 21;
 enum { FIT_STAGE_NEWTON = 1, FIT_STAGE_FINAL = 2, FIT_STAGE_INIT_ONLY = 4, FIT_STAGE_ITERATE_ONLY = 8 };
 // a fit that takes more iterations than this is re-fitted whatever its steps were: it spent dozens of iterations

@@ -73,8 +73,13 @@ __global__ __launch_bounds__(FIT_NT) void mle_fit_kernel(FitParams p, int stages
         if (lane == 0) sidx = atomicAdd(p.queue, 1ull);
         sidx = ((unsigned long long)__builtin_amdgcn_readfirstlane((int)(sidx >> 32)) << 32) |
                (unsigned)__builtin_amdgcn_readfirstlane((int)(sidx & 0xffffffffu));
-        sidx += (unsigned long long)p.first;
-        if ((int64_t)sidx >= n) break;
+        if (p.final_list && !(stages & FIT_STAGE_NEWTON)) {      // the spots of the second re-fit only
+            if (sidx >= (unsigned long long)*p.final_list_n) break;
+            sidx = (unsigned long long)p.final_list[sidx];
+        } else {
+            sidx += (unsigned long long)p.first;
+            if ((int64_t)sidx >= n) break;
+        }
 
         // ---- load the spot (photons) -----------------------------------
         float data[PPL];
@@ -351,15 +356,24 @@ __device__ void pinv_diag_jacobi(const double *Min, double *diag)
     }
 }
 
+// list / list_n: only these spots (the second re-fit); unstable / unstable_n (first pass, re-fit mode): spots whose iteration
+// does not contract at the fitted theta (FIT_UNSTABLE_LMAX, fit_common.h) are appended for that second re-fit
 template <int NP>
 __global__ __launch_bounds__(256) void crlb_kernel(const double *__restrict__ fisher, int64_t first, int64_t N,
-                                                   const int64_t *__restrict__ d_n, float *__restrict__ crlbs)
+                                                   const int64_t *__restrict__ d_n, float *__restrict__ crlbs,
+                                                   const int32_t *__restrict__ list, const unsigned *__restrict__ list_n,
+                                                   int32_t *__restrict__ unstable, unsigned *__restrict__ unstable_n,
+                                                   unsigned *__restrict__ reasons, const unsigned char *__restrict__ refit_mark)
 {
     int64_t n = N;
     if (d_n) { int64_t dn = *d_n; n = dn < n ? dn : n; }
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const int64_t sidx = first + t;
-    if (sidx >= n) return;
+    int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    int64_t sidx = first + t;
+    if (list) {
+        if (t >= (int64_t)*list_n) return;
+        sidx = (int64_t)list[t];
+        t = sidx - first;
+    } else if (sidx >= n) return;
     const double *f = fisher + t * FISHER_STRIDE;
     double M[36];
     {
@@ -368,6 +382,36 @@ __global__ __launch_bounds__(256) void crlb_kernel(const double *__restrict__ fi
         for (int k = 0; k < NP; k++)
 #pragma unroll
             for (int l = k; l < NP; l++) { const double v = f[e++]; M[k * NP + l] = v; M[l * NP + k] = v; }
+    }
+    if (unstable && !(refit_mark && refit_mark[t])) {      // (a spot the Newton loop flagged carries the reference's bits already)
+        // lambda_max of C = D^-1/2 M D^-1/2 by power iteration (C is symmetric, positive semi-definite, unit diagonal)
+        double dinv[NP], v[NP], lam = 0.0;
+        bool ok = true;
+#pragma unroll
+        for (int i = 0; i < NP; i++) { const double m = M[i * NP + i]; ok = ok && m > 0.0 && m < 1e300; dinv[i] = 1.0 / sqrt(m); v[i] = 1.0 + 0.125 * (double)i; }
+        if (ok) {
+            for (int it = 0; it < 16; it++) {          // (second eigenvalue / first <= 0.7 on ill-conditioned fits: 0.7^16 = 3e-3)
+                double u[NP], w[NP], nrm = 0.0, vn = 0.0;
+#pragma unroll
+                for (int i = 0; i < NP; i++) { u[i] = dinv[i] * v[i]; vn += v[i] * v[i]; }
+#pragma unroll
+                for (int i = 0; i < NP; i++) {
+                    double a = 0.0;
+#pragma unroll
+                    for (int k = 0; k < NP; k++) a += M[i * NP + k] * u[k];
+                    w[i] = dinv[i] * a; nrm += w[i] * w[i];
+                }
+                nrm = sqrt(nrm);
+                lam = nrm / sqrt(vn);
+                const double inv = 1.0 / nrm;
+#pragma unroll
+                for (int i = 0; i < NP; i++) v[i] = w[i] * inv;
+            }
+            if (lam > FIT_UNSTABLE_LMAX) {
+                unstable[atomicAdd(unstable_n, 1u)] = (int32_t)sidx;
+                if (reasons) atomicAdd(reasons + 6, 1u);
+            }
+        }
     }
     double L[36], D[6], diag[6];
     bool bad = false;
@@ -488,16 +532,19 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     const int64_t nb = (p.N + BATCH - 1) / BATCH;
     void *ptr = nullptr, *fptr = nullptr;
     int rc;
-    // per batch: two queue words (Newton stage, final stage) and the flag counter
-    if ((rc = scratch(SCR_FIT, (size_t)nb * 24 + 64, &ptr)) != PMI_OK) return rc;
-    // per spot of a batch: 21 doubles of Fisher triangle + 12 floats of Newton start state + a flag-list slot
+    // per batch: three queue words (Newton stage, final stage, final stage of the second re-fit) and two counters (spots
+    // flagged by the Newton loop, spots found unstable by the Fisher pass)
+    if ((rc = scratch(SCR_FIT, (size_t)nb * 32 + 64, &ptr)) != PMI_OK) return rc;
+    // per spot of a batch: 21 doubles of Fisher triangle + 12 floats of Newton start state + a slot in each of the two lists
     const size_t per_batch = (size_t)std::min<int64_t>(p.N, BATCH);
-    if ((rc = scratch(SCR_STAGE_D, per_batch * (FISHER_STRIDE * sizeof(double) + 12 * sizeof(float) + sizeof(int32_t)), &fptr)) != PMI_OK) return rc;
+    if ((rc = scratch(SCR_STAGE_D, per_batch * (FISHER_STRIDE * sizeof(double) + 12 * sizeof(float) + 2 * sizeof(int32_t) + 1) + 16, &fptr)) != PMI_OK) return rc;
     float *state = reinterpret_cast<float *>((char *)fptr + per_batch * FISHER_STRIDE * sizeof(double));
     int32_t *flag_list = reinterpret_cast<int32_t *>(state + per_batch * 12);
-    PMI_HIP(hipMemsetAsync(ptr, 0, (size_t)nb * 24, s));
+    int32_t *unstable_list = flag_list + per_batch;
+    unsigned char *refit_mark = reinterpret_cast<unsigned char *>(unstable_list + per_batch);
+    PMI_HIP(hipMemsetAsync(ptr, 0, (size_t)nb * 32, s));
     unsigned long long *queues = (unsigned long long *)ptr;
-    unsigned *flag_counts = (unsigned *)(queues + 2 * nb);
+    unsigned *flag_counts = (unsigned *)(queues + 3 * nb);           // [0, nb): flagged, [nb, 2 nb): unstable
     void *sptr = nullptr;
     if ((rc = scratch(SCR_STATS, 64, &sptr)) != PMI_OK) return rc;
     unsigned *stats = (unsigned *)sptr;
@@ -531,11 +578,13 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         p.N = std::min<int64_t>(Ntotal, p.first + BATCH);
         p.flag_list = mode == PMI_MLE_REFIT ? flag_list : nullptr;
         p.flag_count = flag_counts + bi;
+        p.refit_mark = mode == PMI_MLE_REFIT ? refit_mark : nullptr;
+        if (p.refit_mark) PMI_HIP(hipMemsetAsync(refit_mark, 0, (size_t)(p.N - p.first), s));
         const int64_t count = p.N - p.first;
         const int64_t blocks = std::min<int64_t>((count + FIT_WAVES - 1) / FIT_WAVES, (int64_t)g_cu_count * 8);
         const dim3 grid((unsigned)std::max<int64_t>(blocks, 1));
         auto wave_per_spot = [&](int stages) {
-            p.queue = queues + 2 * bi + (stages == FIT_STAGE_FINAL ? 1 : 0);
+            p.queue = queues + 3 * bi + (stages == FIT_STAGE_FINAL ? (p.final_list ? 2 : 1) : 0);
             if (method == PMI_MLE_SIGMAXY) {
                 if (from_movie) launch_fit_ppl<6, true>(ppl, grid, s, p, stages); else launch_fit_ppl<6, false>(ppl, grid, s, p, stages);
             } else {
@@ -577,13 +626,39 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         }
         PMI_HIP(hipGetLastError());
         const unsigned cb = (unsigned)((count + 255) / 256);
-        if (method == PMI_MLE_SIGMAXY)
-            hipLaunchKernelGGL((crlb_kernel<6>), dim3(cb), dim3(256), 0, s, p.fisher, p.first, p.N, p.d_n, p.crlbs);
-        else
-            hipLaunchKernelGGL((crlb_kernel<5>), dim3(cb), dim3(256), 0, s, p.fisher, p.first, p.N, p.d_n, p.crlbs);
+        unsigned *unstable_n = flag_counts + nb + bi;
+        auto crlb = [&](const int32_t *list, const unsigned *list_n, int32_t *out, unsigned *out_n) {
+            if (method == PMI_MLE_SIGMAXY)
+                hipLaunchKernelGGL((crlb_kernel<6>), dim3(cb), dim3(256), 0, s, p.fisher, p.first, p.N, p.d_n, p.crlbs, list, list_n, out, out_n, p.flag_reasons, p.refit_mark);
+            else
+                hipLaunchKernelGGL((crlb_kernel<5>), dim3(cb), dim3(256), 0, s, p.fisher, p.first, p.N, p.d_n, p.crlbs, list, list_n, out, out_n, p.flag_reasons, p.refit_mark);
+        };
+        const bool second = mode == PMI_MLE_REFIT;
+        crlb(nullptr, nullptr, second ? unstable_list : nullptr, second ? unstable_n : nullptr);
         PMI_HIP(hipGetLastError());
+        if (second) {
+            // Second re-fit: the spots whose iteration does not contract at the fitted theta (known only now, from the Fisher
+            // matrix) — reference arithmetic, Fisher pass and inverse for these spots alone.  On photon data the list is empty
+            // and the three launches exit at once.
+            FitParams r = p;
+            if (cut) { r.spots = cut - p.first * (int64_t)(p.box * p.box); }
+            const bool r_movie = cut ? false : from_movie;
+            launch_fit_strict(r, method, r_movie, unstable_list, unstable_n, count, g_cu_count, s);
+            PMI_HIP(hipGetLastError());
+            r.final_list = unstable_list; r.final_list_n = unstable_n;
+            if (g8) launch_fit_g8(r, method, r_movie, g_cu_count, state, FIT_STAGE_FINAL, s);
+            else {
+                FitParams keep = p;
+                p = r;
+                wave_per_spot(FIT_STAGE_FINAL);
+                p = keep;
+            }
+            PMI_HIP(hipGetLastError());
+            crlb(unstable_list, unstable_n, nullptr, nullptr);
+            PMI_HIP(hipGetLastError());
+        }
     }
-    hipLaunchKernelGGL(flag_stats_kernel, dim3(1), dim3(1), 0, s, flag_counts, mode == PMI_MLE_REFIT ? nb : 0, stats);
+    hipLaunchKernelGGL(flag_stats_kernel, dim3(1), dim3(1), 0, s, flag_counts, mode == PMI_MLE_REFIT ? 2 * nb : 0, stats);
     PMI_HIP(hipGetLastError());
     g_last_stats[g_stats_second ? 1 : 0] = stats;
     if (!g_stats_second) g_last_stats[1] = nullptr;

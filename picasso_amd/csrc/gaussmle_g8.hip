@@ -634,9 +634,14 @@ __global__ __launch_bounds__(FIT_NT) void g8_final_kernel(FitParams p)
     const float jf = (float)j;
     int64_t n = p.N;
     if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
-    const int64_t sidx = p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW + g;
-    const bool spot_ok = sidx < n;
-    if (__builtin_amdgcn_readfirstlane((int)(p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW >= n))) return;
+    int64_t sidx = p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW + g;
+    bool spot_ok = sidx < n;
+    if (p.final_list) {      // the spots of the second re-fit only
+        const int64_t w0 = ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW, items = (int64_t)*p.final_list_n;
+        if (__builtin_amdgcn_readfirstlane((int)(w0 >= items))) return;
+        spot_ok = w0 + g < items;
+        sidx = spot_ok ? (int64_t)p.final_list[w0 + g] : p.first;
+    } else if (__builtin_amdgcn_readfirstlane((int)(p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW >= n))) return;
 
     float d[B], th[6];
     load_row<B, FROM_MOVIE>(p, sidx, j, spot_ok && rowok, d);

@@ -338,6 +338,7 @@ __global__ __launch_bounds__(FIT_NT) void mle_strict_kernel(FitParams p, const i
             for (int l = 0; l < 5; l++) to[l] = th[l];
             to[5] = NP == 6 ? th[5] : th[4];
             p.iterations[sidx] = kk;
+            if (p.refit_mark) p.refit_mark[sidx - p.first] = 1;
         }
         lds_sync();
     }

@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -28,9 +29,11 @@ namespace xc {
 
 struct Plans { hipfftHandle fwd, inv; };
 static std::map<std::pair<int64_t, int64_t>, Plans> g_plans;
+static std::mutex g_plans_mu;        // pmi_fft_prewarm makes plans from a side thread of the host
 
 static int get_plans(int64_t Y, int64_t X, Plans *out)
 {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
     auto key = std::make_pair(Y, X);
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(256) void peak_kernel(const double *__restrict__ r,
 
 void release_fft_plans()
 {
+    std::lock_guard<std::mutex> lk(xc::g_plans_mu);
     for (auto &kv : xc::g_plans) { hipfftDestroy(kv.second.fwd); hipfftDestroy(kv.second.inv); }
     xc::g_plans.clear();
 }
@@ -145,6 +149,18 @@ void release_fft_plans()
 }  // namespace pmi
 
 extern "C" {
+
+// rocFFT compiles the kernels of a plan when the plan is made: 2.5 s for 2048 x 2048, the larger part of a first RCC
+// undrift.  A host that knows the frame size early (it localizes the movie first) makes the plans from a side thread
+// meanwhile; the correlations then find them in the cache.
+int pmi_fft_prewarm(int64_t Y, int64_t X)
+{
+    using namespace pmi;
+    if (pmi_device_count() < 1) { set_error("no HIP device"); return PMI_ERR_NODEVICE; }
+    if (Y < 1 || X < 1 || Y > 0x7fffffff || X > 0x7fffffff) { set_error("fft prewarm: bad size"); return PMI_ERR_ARG; }
+    xc::Plans pl;
+    return xc::get_plans(Y, X, &pl);
+}
 
 int pmi_xcorr(const double *image_a, const double *image_b, int64_t Y, int64_t X, double *out)
 {

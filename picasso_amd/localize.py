@@ -555,6 +555,9 @@ def localize_streamed(movie, camera_info: dict, parameters: dict, *, roi=None, f
     if hi >= lo:
         from concurrent.futures import ThreadPoolExecutor
         first = np.asarray(movie[lo])
+        # `picasso localize --drift` undrifts right after this: its FFT plans (seconds of kernel compilation inside
+        # rocFFT for large frames) are made on a side thread meanwhile
+        backend.prewarm_fft(first.shape[0], first.shape[1])
         per = max(1, int(chunk_bytes) // max(first.nbytes, 1))
         # Two staging allocations.  This thread uploads chunk i + 1 (a blocking default-stream copy; ctypes
         # releases the GIL) while a worker thread runs chunk i on a non-blocking stream of its own — kernels,

@@ -33,10 +33,12 @@ for box in boxes:
     spots = lq_spots(box, n, 40 + box)
     L.orc_lq_set_sum_order(0)
     a = orc.gausslq(spots, full=True, threads=8)
-    L.orc_lq_set_sum_order(1)
-    b = orc.gausslq(spots, full=True, threads=8)
-    L.orc_lq_set_sum_order(0)
-    diff = np.flatnonzero(~np.all((a[0] == b[0]) | (np.isnan(a[0]) & np.isnan(b[0])), axis=1))
-    d = np.abs(a[0] - b[0])[:, [0, 1, 4, 5]].max(axis=1)
-    print("box", box, "order-dependent spots", len(diff), "rows", diff[:12].tolist(), "worst", float(np.nanmax(d)),
-          "info differs", int((a[1] != b[1]).sum()), "nfev differs", int((a[2] != b[2]).sum()), flush=True)
+    gs = 8 if box <= 7 else (32 if box <= 15 else 64)
+    for label, mode in (("reversed", 1), (f"device order (groups of {gs})", 2 | (gs << 2))):
+        L.orc_lq_set_sum_order(mode)
+        b = orc.gausslq(spots, full=True, threads=8)
+        L.orc_lq_set_sum_order(0)
+        diff = np.flatnonzero(~np.all((a[0] == b[0]) | (np.isnan(a[0]) & np.isnan(b[0])), axis=1))
+        d = np.abs(a[0] - b[0])[:, [0, 1, 4, 5]].max(axis=1)
+        print("box", box, label, ": order-dependent spots", len(diff), "rows", diff[:12].tolist(), "worst", float(np.nanmax(d)),
+              "info differs", int((a[1] != b[1]).sum()), "nfev differs", int((a[2] != b[2]).sum()), flush=True)

@@ -123,7 +123,9 @@ def test_gaussmle_vs_goldens_and_oracle(be, orc, name, method):
     _check_fit(th, cr, ll, it, d[method + "_theta"], d[method + "_crlb"], d[method + "_loglik"],
                d[method + "_iterations"], loose)
     o = orc.gaussmle(d["spots"], 1e-3, 100, method, threads=4)
-    _check_fit(th, cr, ll, it, *o, loose)
+    # against the oracle (numba's promotion, which the device follows) NO row is loose:
+    # the chaotic rows are flagged and carry the oracle's bits
+    _check_fit(th, cr, ll, it, *o, ())
     if method == "sigma":
         assert np.array_equal(th[:, 4], th[:, 5])
 

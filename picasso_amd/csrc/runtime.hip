@@ -95,7 +95,7 @@ void release_fft_plans();   // xcorr.hip
 
 extern "C" {
 
-int pmi_version(void) { return 100; }   // 0.1.0
+int pmi_version(void) { return 102; }   // 0.1.2: round 3 (flag reasons, gausslq re-fit counters, localize schedule knobs, pmi_comm_available, pmi_fft_prewarm)
 
 const char *pmi_last_error(void) { return pmi::g_err; }
 

@@ -330,3 +330,16 @@ def test_older_locs_from_fits_and_futures_collation():
     got = localize.identifications_from_futures([localize.gausslq._DoneFuture(parts[:1]), localize.gausslq._DoneFuture(parts[1:])])
     assert np.all(np.diff(got["frame"].to_numpy()) >= 0) and len(got) == len(ids)
     assert sorted(map(tuple, got.to_numpy().tolist())) == sorted(map(tuple, ids.to_numpy().tolist()))
+
+
+def test_bench_refuses_tuning_variables():
+    """bench.py must not produce a line under PMI_* / PICASSO_AMD_LIB overrides unless told to (and then echoes them):
+    the library's tuning variables select other kernels or another build."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, PMI_MLE_MODE="fast")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "tuning variables are set" in (r.stderr + r.stdout) and "PMI_MLE_MODE" in (r.stderr + r.stdout)
+    assert r.stdout.strip() == ""          # no JSON line

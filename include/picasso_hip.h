@@ -159,7 +159,7 @@ int pmi_gaussmle_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y,
  *                   step came within `margin` (relative) of eps in some iteration; a curvature term was not negative;
  *                   a width fell below 0.3 px; a parameter swung back and forth without its steps shrinking (the
  *                   iteration does not contract); a pixel lay far off the model (|data / model - 1| or
- *                   |data / model^2| above 16); the fit took more than 32 iterations; or, seen from the Fisher matrix at the
+ *                   |data / model^2| above 16); the fit took more than 64 iterations; or, seen from the Fisher matrix at the
  *                   fitted theta, the per-parameter update does not contract there (lambda_max of the normalised
  *                   Fisher matrix above 1.9: a rounding difference would be multiplied by 1 - lambda_max per
  *                   iteration) — is fitted again from its initial

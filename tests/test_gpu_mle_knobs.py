@@ -130,7 +130,7 @@ def test_fuzz_residual_unstable_iteration_box13(be, orc):
 
 @pytest.mark.xfail(strict=False, reason="known residuals of the 30-minute fuzz run of round 3 (DESIGN.md section 2): two 3x3 fits on which strict mode itself differs from the oracle")
 def test_fuzz_residuals_round3(be, orc):
-    """The 3x3 spots tools/fuzz_parity.py left after 34.6 million (tests/golden/mle_fuzz_regressions): fits whose width
+    """The 3x3 spots tools/fuzz_parity.py left after 65 million (tests/golden/mle_fuzz_regressions): fits whose width
     collapses to 0.02 ... 0.03 px and that run 87+ iterations — there even the strict mode differs from the oracle (the
     device's float64 erf / exp are not glibc's to the last ulp, and the trajectory is chaotic).  Kept as inputs."""
     import glob

@@ -157,11 +157,17 @@ struct FastParams {
 #ifndef FAST_D_H4
 #define FAST_D_H4 4
 #endif
+#ifndef FAST_U_H4
+#define FAST_U_H4 8
+#endif
+#ifndef FAST_U_H6
+#define FAST_U_H6 12
+#endif
 #ifndef FAST_D_H5
 #define FAST_D_H5 5
 #endif
 #ifndef FAST_D_H6
-#define FAST_D_H6 3
+#define FAST_D_H6 6
 #endif
 #ifndef FAST_ROUND
 #define FAST_ROUND 64         // candidates per in-loop round of exact net gradients (lanes busy vs. rows still in the Infinity Cache)
@@ -170,15 +176,27 @@ struct FastParams {
 #define FAST_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for
 #endif
 #ifndef FAST_WAVES_H4
-#define FAST_WAVES_H4 2
+#define FAST_WAVES_H4 4
 #endif
-#ifndef FAST_WAVES_H56
-#define FAST_WAVES_H56 2
+#ifndef FAST_WAVES_H5
+#define FAST_WAVES_H5 3
 #endif
-// Waves per SIMD the register allocator must leave room for.  Boxes 9 to 13 at four / three waves spilled a few values
-// INSIDE the row loop; a scratch reload is a vector-memory load, and waiting for it drains the prefetched rows at every
-// step (box 11: 1.45 -> 2.94 TB/s, box 9: 2.13 -> 2.73, box 13: 1.93 -> 2.42 with one wave less and no spill).
-constexpr int fast_waves_per_simd(int H) { return H <= 3 ? FAST_MIN_WAVES : (H == 4 ? FAST_WAVES_H4 : (H <= 6 ? FAST_WAVES_H56 : 2)); }
+#ifndef FAST_WAVES_H6
+#define FAST_WAVES_H6 3
+#endif
+// Waves per SIMD the register allocator must leave room for (and the number of persistent waves launched).  A value
+// spilled INSIDE the row loop costs more than a wave: a scratch reload is a vector-memory load, and waiting for it
+// drains the prefetched rows at every step (round 1, box 11: 1.45 -> 2.94 TB/s with one wave less and no spill).
+// Round 3: with the rows in flight and the pixel history in one register ring (below) box 9 fits four waves (123 VGPRs),
+// boxes 11 and 13 three (145 / 161) — except the variants for frames wider than a wave and for two row ranges side by
+// side at box 13 (and the latter at box 11), which would spill at three and stay at two.
+constexpr int fast_waves_per_simd(int H, int P, bool EDGE)
+{
+    return H <= 3 ? FAST_MIN_WAVES : (H == 4 ? FAST_WAVES_H4 : (H == 5 ? (P == 1 ? FAST_WAVES_H5 : 2) : (H == 6 ? (P == 1 && !EDGE ? FAST_WAVES_H6 : 2) : 2)));
+}
+#ifndef FAST_UNI_MIN_H
+#define FAST_UNI_MIN_H 3      // smallest half-width whose scan keeps rows in flight and pixel history in one ring (box 5: 4.6 -> 4.3 TB/s with it, its two rows in flight are issued too late in the step)
+#endif
 
 // pair `s` = pixels (s, s+1) relative to the lane's first pixel.  A holds NA packed pairs: the lane's
 // own four in the middle, NB = NA - 4 neighbour pixels on either side (4 for boxes up to 9, 8 for
@@ -191,16 +209,40 @@ __device__ __forceinline__ u32 pair_at(const u32 (&A)[NA], const u32 (&Bp)[NA])
     else return Bp[(S + NB + 1) / 2];
 }
 
-// maximum of the LEN packed pairs at offsets S .. S + LEN - 1, by doubling (overlapping halves when LEN is not a
-// power of two); identical sub-windows of neighbouring pixel pairs are shared by common-subexpression elimination
+// maximum of the LEN packed pairs at offsets S .. S + LEN - 1: powers of two by doubling, other lengths as the largest
+// power of two below them followed by the rest (13 = 8 + 4 + 1).  Every sub-window then starts an EVEN number of pixels
+// after S, so a box touches only the aligned pairs (even H: the odd ones, and the v_alignbit that makes them, drop out)
+// or only the odd ones; identical sub-windows of neighbouring pixel pairs are shared by common-subexpression
+// elimination (box 13: 29 v_pk_max_u16 for the four windows of a row, 38 + 11 v_alignbit with overlapping halves).
 template <int LEN, int S, int NA>
 __device__ __forceinline__ u32 wmax(const u32 (&A)[NA], const u32 (&Bp)[NA])
 {
     if constexpr (LEN == 1) return pair_at<S, NA>(A, Bp);
+    else if constexpr ((LEN & (LEN - 1)) == 0) return pk_max(wmax<LEN / 2, S, NA>(A, Bp), wmax<LEN / 2, S + LEN / 2, NA>(A, Bp));
     else {
-        constexpr int P2 = (LEN & (LEN - 1)) == 0 ? LEN / 2 : (LEN >= 16 ? 16 : (LEN >= 8 ? 8 : (LEN >= 4 ? 4 : 2)));
-        return pk_max(wmax<P2, S, NA>(A, Bp), wmax<P2, S + LEN - P2, NA>(A, Bp));
+        constexpr int P2 = LEN > 16 ? 16 : (LEN > 8 ? 8 : (LEN > 4 ? 4 : 2));
+        return pk_max(wmax<P2, S, NA>(A, Bp), wmax<LEN - P2, S + P2, NA>(A, Bp));
     }
+}
+
+// The four (2H+1)-pixel window maxima of a lane's row (pixel pairs q = 0..3, windows at pair offsets 2q-H .. 2q+H) for
+// H >= 4: the offsets 6-H .. H are common to all four (the core), window q adds 6-2q offsets on the left and 2q on the
+// right, and those are suffix / prefix maxima of pair maxima — 18 / 20 / 22 v_pk_max_u16 for boxes 9 / 11 / 13
+// (21 / 26 / 29 by doubling each window).
+template <int H, int NA>
+__device__ __forceinline__ void window_maxima(const u32 (&A)[NA], const u32 (&Bp)[NA], u32 (&hrow)[4])
+{
+    const u32 l2 = pk_max(pair_at<4 - H, NA>(A, Bp), pair_at<5 - H, NA>(A, Bp));
+    const u32 l1 = pk_max(pk_max(pair_at<2 - H, NA>(A, Bp), pair_at<3 - H, NA>(A, Bp)), l2);
+    const u32 l0 = pk_max(pk_max(pair_at<0 - H, NA>(A, Bp), pair_at<1 - H, NA>(A, Bp)), l1);
+    const u32 r1 = pk_max(pair_at<H + 1, NA>(A, Bp), pair_at<H + 2, NA>(A, Bp));
+    const u32 r2 = pk_max(pk_max(pair_at<H + 3, NA>(A, Bp), pair_at<H + 4, NA>(A, Bp)), r1);
+    const u32 r3 = pk_max(pk_max(pair_at<H + 5, NA>(A, Bp), pair_at<H + 6, NA>(A, Bp)), r2);
+    const u32 core = wmax<2 * H - 5, 6 - H, NA>(A, Bp);
+    hrow[0] = pk_max(core, l0);
+    hrow[1] = pk_max(pk_max(core, l1), r1);
+    hrow[2] = pk_max(pk_max(core, l2), r2);
+    hrow[3] = pk_max(core, r3);
 }
 
 struct RowRegs { uint4 m; uint4 e; };   // 8 own pixels + (lanes 0 / 63 only) the 4 or 8 pixels beyond the wave's edge (e.z, e.w: boxes 11, 13)
@@ -208,6 +250,20 @@ struct RowRegs { uint4 m; uint4 e; };   // 8 own pixels + (lanes 0 / 63 only) th
 // value of lane-1 / lane+1 across the whole wavefront; `edge` is returned where no such lane exists
 __device__ __forceinline__ u32 from_lane_below(u32 v, u32 edge) { return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x138, 0xf, 0xf, false); }   // wave_shr:1
 __device__ __forceinline__ u32 from_lane_above(u32 v, u32 edge) { return (u32)__builtin_amdgcn_update_dpp((int)edge, (int)v, 0x130, 0xf, 0xf, false); }   // wave_shl:1
+// the same for the row pixels: ZF = nobody reads what lanes 0 / 63 receive (frames no wider than the wave), so the
+// instruction may fill in zeros itself (bound_ctrl) — with a fill VALUE the destination has to be preset by a v_mov
+// in front of every DPP move, eight per row for boxes 11 and 13
+template <bool ZF> __device__ __forceinline__ u32 px_from_lane_below(u32 v, u32 edge)
+{
+    if constexpr (ZF) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x138, 0xf, 0xf, true);
+    else return from_lane_below(v, edge);
+}
+template <bool ZF> __device__ __forceinline__ u32 px_from_lane_above(u32 v, u32 edge)
+{
+    if constexpr (ZF) return (u32)__builtin_amdgcn_update_dpp(0, (int)v, 0x130, 0xf, 0xf, true);
+    else return from_lane_above(v, edge);
+}
+__device__ __forceinline__ u32 quad(const uint4 &v, int q) { return q == 0 ? v.x : (q == 1 ? v.y : (q == 2 ? v.z : v.w)); }
 
 // Exact float32 net gradient of one candidate in the reference's (k, l) order (picasso/localize.py:202-244).
 // The (2H+3)^2 neighbourhood is fetched as its first column (one 2-byte load per row) plus 2H + 2 pixels as packed
@@ -326,7 +382,7 @@ __device__ __forceinline__ float exact_ng(const typename Px<PT>::T *__restrict__
 // the compiler then counts two loads per row and waits with the exact vmcnt — as a run-time branch it has to assume
 // the smaller count on every path and the wide frames ran at half their prefetch depth.
 template <int H, int D, int P = 1, int PT = PT_U16, bool EDGE = false>
-__global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_fast_kernel(
+__global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_scan_u16_fast_kernel(
     FastParams p, const float *__restrict__ uxy, Record *__restrict__ recs, long long cap,
     unsigned long long *__restrict__ shard_cnt, int *__restrict__ frame_count)
 {
@@ -339,8 +395,10 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
     // the slot about to be overwritten is skipped: both rings then share the period H.
     constexpr bool WIDE = H >= 5;
     constexpr int NB = WIDE ? 8 : 4, NA = 4 + NB, OWN = NB / 2;
-    constexpr int U_ = H <= 2 ? 4 : (H == 3 ? FAST_U_H3 : (H == 4 ? 4 : (H == 5 ? 10 : (H == 6 ? 6 : 2 * H))));   // unroll period: a multiple of the ring period H
+    constexpr int U_ = H <= 2 ? 4 : (H == 3 ? FAST_U_H3 : (H == 4 ? FAST_U_H4 : (H == 5 ? 10 : (H == 6 ? FAST_U_H6 : 2 * H))));   // unroll period: a multiple of the ring period H
     static_assert(U_ % D == 0, "prefetch depth must divide the unroll period");
+    constexpr bool UNI = H >= FAST_UNI_MIN_H && U_ % (D + H) == 0;               // one register ring for the rows in flight and the last H rows' pixels
+    constexpr int RP = UNI ? D + H : D;
     constexpr int NWL = (H + 1 + 7) / 8;                   // neighbour lanes (8 columns each) a stencil reaches on either side
     // Candidate ring: entries (row << 16 | column in the aligned row) + frame index.  A chunk of rows ends early when
     // the ring holds THRESH entries (only without the floor filter, i.e. min_ng <= 0: 2 % of the pixels are maxima).
@@ -581,6 +639,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
         // a sub-band's row lies wholly inside its lanes, and so does the row of a frame at most 512 pixels wide: the
         // pixels lanes 0 and 63 would take from beyond the wave then only feed masked positions
         constexpr bool any_edge = EDGE && P == 1;
+        constexpr bool ZF = !any_edge;
         // num_records bounds the descriptor at the end of the frames of this call: when the width is not a
         // multiple of 8 the last chunk of a row reads into the next row (masked columns), and on the very last
         // row it would read past the movie — the buffer unit returns 0 there instead
@@ -674,26 +733,35 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
             const float beta_r = fmaf(p.filt_kr, (float)cfloor, p.filt_t), beta_c = fmaf(p.filt_kc, (float)cfloor, p.filt_t),
                         beta_rc = fmaf(p.filt_krc, (float)cfloor, p.filt_t);
 
-            RowRegs pf[D];
+            // Rows in flight and the pixel history are ONE ring of D + H slots where the unroll period allows it: the row
+            // loaded now lands in the slot whose pixels (row r - H) were used for the last time in this very step, and no
+            // row is ever copied from the registers it was loaded into (four v_mov per row otherwise).
+            RowRegs pf[RP];
 #pragma unroll
-            for (int d = 0; d < D; d++) pf[d] = load_row(rs0 + d);
+            for (int d = 0; d < RP; d++) {
+                if (d < D) pf[d] = load_row(rs0 + d);
+                else pf[d].m = make_uint4(0u, 0u, 0u, 0u);
+            }
 
             int sb = 0;
             for (; sb < nr; sb += U_) {
 #pragma unroll
                 for (int u = 0; u < U_; u++) {
                     const int st = sb + u;                    // pipeline step; row r = rs0 + st
-                    const RowRegs cur = pf[u % D];
-                    pf[u % D] = load_row(rs0 + st + D);
+                    const RowRegs cur = pf[u % RP];
+                    if constexpr (!UNI) pf[u % RP] = load_row(rs0 + st + D);
+                    u32 dvq[4];                               // the pixels of row r - H
+#pragma unroll
+                    for (int q = 0; q < 4; q++) dvq[q] = UNI ? quad(pf[(u + D) % RP].m, q) : Dv[u % H][q];
                     u32 A[NA], Bp[NA];
                     if constexpr (WIDE) {
-                        A[0] = from_lane_below(cur.m.x, cur.e.x); A[1] = from_lane_below(cur.m.y, cur.e.y);
-                        A[2] = from_lane_below(cur.m.z, cur.e.z); A[3] = from_lane_below(cur.m.w, cur.e.w);
-                        A[8] = from_lane_above(cur.m.x, cur.e.x); A[9] = from_lane_above(cur.m.y, cur.e.y);
-                        A[10] = from_lane_above(cur.m.z, cur.e.z); A[11] = from_lane_above(cur.m.w, cur.e.w);
+                        A[0] = px_from_lane_below<ZF>(cur.m.x, cur.e.x); A[1] = px_from_lane_below<ZF>(cur.m.y, cur.e.y);
+                        A[2] = px_from_lane_below<ZF>(cur.m.z, cur.e.z); A[3] = px_from_lane_below<ZF>(cur.m.w, cur.e.w);
+                        A[8] = px_from_lane_above<ZF>(cur.m.x, cur.e.x); A[9] = px_from_lane_above<ZF>(cur.m.y, cur.e.y);
+                        A[10] = px_from_lane_above<ZF>(cur.m.z, cur.e.z); A[11] = px_from_lane_above<ZF>(cur.m.w, cur.e.w);
                     } else {
-                        A[0] = from_lane_below(cur.m.z, cur.e.x); A[1] = from_lane_below(cur.m.w, cur.e.y);
-                        A[6] = from_lane_above(cur.m.x, cur.e.x); A[7] = from_lane_above(cur.m.y, cur.e.y);
+                        A[0] = px_from_lane_below<ZF>(cur.m.z, cur.e.x); A[1] = px_from_lane_below<ZF>(cur.m.w, cur.e.y);
+                        A[6] = px_from_lane_above<ZF>(cur.m.x, cur.e.x); A[7] = px_from_lane_above<ZF>(cur.m.y, cur.e.y);
                     }
                     A[OWN] = cur.m.x; A[OWN + 1] = cur.m.y; A[OWN + 2] = cur.m.z; A[OWN + 3] = cur.m.w;
                     Bp[0] = 0;
@@ -745,15 +813,33 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
                         for (int q = 0; q < 4; q++) t2[q] = pk_max(t1[q], F);
                         asm volatile("" : "+v"(t2[0]), "+v"(t2[1]), "+v"(t2[2]), "+v"(t2[3]));
 #pragma unroll
-                        for (int q = 0; q < 4; q++) d[q] = pk_sub_sat(t2[q], Dv[u % H][q]);
+                        for (int q = 0; q < 4; q++) d[q] = pk_sub_sat(t2[q], dvq[q]);
                         asm volatile("" : "+v"(d[0]), "+v"(d[1]), "+v"(d[2]), "+v"(d[3]));
 #pragma unroll
                         for (int q = 0; q < 4; q++) {
                             tq[q] = pk_min(d[q], 0x00010001u);
-                            Dv[u % H][q] = A[q + OWN];
                             Uring[u % H][q] = uc[q];
                             Hring[0][q] = hrow[q];
                             Hring[1 + u % 2][q] = p2[q];
+                        }
+                    } else if constexpr (H >= 4 && H <= 6) {
+                        // boxes 9 to 13.  Vertical by doubling, as box 7: P2(r) = max(Hrow r, r-1), P4(r) = max(P2(r), P2(r-2)),
+                        // U(r) = max(P4(r), P4(r - (H-3))) = rows r-H .. r in three instructions per pixel pair instead of H.
+                        // The H ring slots hold Hrow(r-1), P2 of the last two rows and P4 of the last H-3 rows.
+                        constexpr int PQ = H - 3;
+                        static_assert(U_ % 2 == 0 && U_ % PQ == 0, "the unroll period covers the periods of the P2 and P4 rings");
+                        window_maxima<H, NA>(A, Bp, hrow);
+#pragma unroll
+                        for (int q = 0; q < 4; q++) {
+                            const u32 p2 = pk_max(hrow[q], Hring[0][q]);
+                            const u32 p4 = pk_max(p2, Hring[1 + u % 2][q]);
+                            const u32 Ucur = pk_max(p4, Hring[3 + u % PQ][q]);                 // rows r - H .. r
+                            const u32 thr = pk_max(pk_max(Ucur, Uring[u % H][q]), F);       // slot u % H: the row H steps back
+                            tq[q] = pk_min(pk_sub_sat(thr, dvq[q]), 0x00010001u);     // 0 in a half = candidate
+                            Uring[u % H][q] = Ucur;
+                            Hring[0][q] = hrow[q];
+                            Hring[1 + u % 2][q] = p2;
+                            Hring[3 + u % PQ][q] = p4;
                         }
                     } else {
                         hrow[0] = wmax<BOX, 0 - H, NA>(A, Bp); hrow[1] = wmax<BOX, 2 - H, NA>(A, Bp);
@@ -764,11 +850,17 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H)) void identify_scan_u16_
 #pragma unroll
                             for (int t = 0; t < H; t++) Ucur = pk_max(Ucur, Hring[t][q]);
                             const u32 thr = pk_max(pk_max(Ucur, Uring[u % H][q]), F);       // slot u % H: the row H steps back
-                            tq[q] = pk_min(pk_sub_sat(thr, Dv[u % H][q]), 0x00010001u);     // 0 in a half = candidate
-                            Dv[u % H][q] = A[q + OWN];
+                            tq[q] = pk_min(pk_sub_sat(thr, dvq[q]), 0x00010001u);     // 0 in a half = candidate
                             Uring[u % H][q] = Ucur;
                             Hring[u % H][q] = hrow[q];
                         }
+                    }
+                    if constexpr (UNI) {
+                        asm volatile("" ::: "memory");         // the load below stays behind the last use of the slot it refills
+                        pf[(u + D) % RP] = load_row(rs0 + st + D);
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; q++) Dv[u % H][q] = A[q + OWN];
                     }
                     const int t4 = u % 4;                      // row slot inside the accumulator
                     acc |= (tq[0] | (tq[1] << 1) | (tq[2] << 2) | (tq[3] << 3)) << (4 * t4);
@@ -915,12 +1007,14 @@ static int launch_fast(const FastParams &p, int pt, const float *d_tab, Record *
     const long long blocks = (p.units + p.upw - 1) / p.upw;
     if (blocks > 0x7fffffffLL) { set_error("identify: too many blocks (%lld)", blocks); return PMI_ERR_ARG; }
     const dim3 g((unsigned)blocks), b(64);
-    if (P == 1 && p.segs > 1) {       // frames wider than a wave: the variant with the edge loads
-        if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_U8, P == 1>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
-        else if (pt == PT_I16) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_I16, P == 1>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
-        else hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_U16, P == 1>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
-        PMI_HIP(hipGetLastError());
-        return PMI_OK;
+    if constexpr (P == 1) {
+        if (p.segs > 1) {             // frames wider than a wave: the variant with the edge loads
+            if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_U8, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+            else if (pt == PT_I16) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_I16, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+            else hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_U16, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+            PMI_HIP(hipGetLastError());
+            return PMI_OK;
+        }
     }
     if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_U8>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
     else if (pt == PT_I16) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_I16>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
@@ -993,7 +1087,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     p.segs = pack > 1 ? 1 : (nch + 63) / 64;
     // Rows per unit: long units amortise the 2H + 2 pipeline rows a unit spends on its halo, short ones balance the
     // persistent waves (every wave runs ceil(units / waves) units).  Pick the length with the least total work.
-    const long long waves = (long long)g_fast_cus * 4 * fast_waves_per_simd(h);
+    const long long waves = (long long)g_fast_cus * 4 * fast_waves_per_simd(h, pack, pack == 1 && p.segs > 1);
     static const int force_rbu = tuning_env("PMI_IDENTIFY_RBU") ? atoi(tuning_env("PMI_IDENTIFY_RBU")) : 0;
     int best_rbu = 0;
     double best_cost = 0.0;

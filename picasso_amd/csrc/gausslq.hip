@@ -328,40 +328,48 @@ __device__ __forceinline__ double enorm_rows(const double (&v)[E], int lane, int
     return x3max * sqrt(s3);
 }
 
-// Residuals of the float32-stored model (gausslq.py:151-203).  The 2 * size profile values of an evaluation (x
-// profile at flat index f < size, y profile at f - size) are spread over the lanes of the group, NPROF per lane
-// (one, except for the 8-lane groups: 14 values on 8 lanes); every row then fetches its two factors.
-template <int GS, int E>
-__device__ __forceinline__ void residuals(const double (&th)[6], const float (&sp)[E], const int (&ri)[E],
-                                          const int (&rj)[E], const bool (&act)[E], int size, int lane,
-                                          float (&out)[E])
+// Residuals of the float32-stored model (gausslq.py:151-203).  The 2 * size profile values of an evaluation are spread
+// over the lanes of the group: one per lane (x profile at flat index f = lane < size, y profile at f - size), except for
+// the 8-lane groups, where lane l holds x-profile value l in slot 0 and y-profile value l in slot 1.  `which` = the
+// slots to evaluate (bit 0: x / the only slot, bit 1: y): a forward difference in x0 or sx leaves the y profile as it
+// is, one in the photons or the background leaves both — the values are the same function of the same arguments, so
+// what is reused is bit for bit what would have been recomputed (6 instead of 14 float64 exp per lane and Jacobian in
+// the 8-lane groups, 5 instead of 7 in the others).
+template <int GS>
+__device__ __forceinline__ void profiles(const double (&th)[6], int size, int lane, int which, float (&prof)[GS == 8 ? 2 : 1])
 {
     constexpr int NPROF = GS == 8 ? 2 : 1;
     const int hsz = size / 2;
     const double th0 = th[0], th1 = th[1], th4 = th[4], th5 = th[5];   // values, not an lvalue select
-    float prof[NPROF];
 #pragma unroll
     for (int k = 0; k < NPROF; k++) {
-        const int f = lane + GS * k;
-        const bool isy = f >= size;
-        const int idx = isy ? f - size : f;
+        if (!((which >> k) & 1)) continue;
+        const bool isy = NPROF == 2 ? k == 1 : lane >= size;
+        const int idx = NPROF == 2 ? lane : (isy ? lane - size : lane);
         const double mu = isy ? th1 : th0, sg = isy ? th5 : th4;
         const double g = (double)(float)(idx - hsz);
         const double t = (g - mu) / sg;
         const double nrm = 0.3989422804014327 / sg;
         prof[k] = (float)(nrm * exp(-0.5 * (t * t)));
     }
+}
+
+template <int GS, int E>
+__device__ __forceinline__ void residuals(const double (&th)[6], const float (&prof)[GS == 8 ? 2 : 1], const float (&sp)[E],
+                                          const int (&ri)[E], const int (&rj)[E], const bool (&act)[E], int size, int lane,
+                                          float (&out)[E])
+{
+    constexpr int NPROF = GS == 8 ? 2 : 1;
     const int gbase = GS == 64 ? 0 : (int)((threadIdx.x & 63u) & ~(unsigned)(GS - 1));     // first lane of this group
 #pragma unroll
     for (int e = 0; e < E; e++) {
-        const int fx = rj[e], fy = size + ri[e];
-        float mxv = __shfl(prof[0], gbase + (fx & (GS - 1)));
-        float myv = __shfl(prof[0], gbase + (fy & (GS - 1)));
+        float mxv, myv;
         if (NPROF > 1) {
-            const float mx1 = __shfl(prof[NPROF - 1], gbase + (fx & (GS - 1)));
-            const float my1 = __shfl(prof[NPROF - 1], gbase + (fy & (GS - 1)));
-            mxv = fx >= GS ? mx1 : mxv;
-            myv = fy >= GS ? my1 : myv;
+            mxv = __shfl(prof[0], gbase + (rj[e] & (GS - 1)));
+            myv = __shfl(prof[NPROF - 1], gbase + (ri[e] & (GS - 1)));
+        } else {
+            mxv = __shfl(prof[0], gbase + (rj[e] & (GS - 1)));
+            myv = __shfl(prof[0], gbase + ((size + ri[e]) & (GS - 1)));
         }
         const float model = (float)(th[2] * (double)myv * (double)mxv + th[3]);
         const float res = sp[e] - model;
@@ -562,8 +570,19 @@ __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], 
             a[j][e] = sw ? u : t;
             a[k][e] = sw ? t : u;
         }
-        wa1[k] = sw ? wa1[j] : wa1[k];
-        wa3[k] = sw ? wa3[j] : wa3[k];
+        // Left to itself the compiler turns these selects on kmax into an indexed access and keeps the six norms in
+        // scratch memory (48 B per lane, 35 scratch loads / stores per Jacobian); opaque operands keep them in registers
+        // — except in the three instantiations that sit at 256 VGPRs, where the twelve registers come back as spills
+        // inside the factorisation (7x7: 8.40 ms per 1e6 spots with the norms in scratch, 8.51 in registers; boxes 5,
+        // 9, 13: 1 % the other way; alternating runs on one box).
+        constexpr bool NORMS_IN_REGS = !((GS == 8 && E == 7) || (GS == 32 && E == 8) || (GS == 64 && E == 7));
+        if constexpr (NORMS_IN_REGS) {
+            wa1[k] = sw ? opaque(wa1[j]) : opaque(wa1[k]);
+            wa3[k] = sw ? opaque(wa3[j]) : opaque(wa3[k]);
+        } else {
+            wa1[k] = sw ? wa1[j] : wa1[k];
+            wa3[k] = sw ? wa3[j] : wa3[k];
+        }
         const int t = ipvt[j], u = ipvt[k];
         ipvt[j] = sw ? u : t;
         ipvt[k] = sw ? t : u;
@@ -690,7 +709,9 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kerne
         float fv[E], fp[E];                   // residuals at x and at the perturbed x (float32 values, gausslq.py:203)
         double wa1[6], wa2[6], wa3[6];
         int ipvt[6];
-        residuals<GS, E>(x, sp, ri, rj, act, size, lane, fv);
+        float prof0[GS == 8 ? 2 : 1], profj[GS == 8 ? 2 : 1];
+        profiles<GS>(x, size, lane, 3, prof0);
+        residuals<GS, E>(x, prof0, sp, ri, rj, act, size, lane, fv);
         // fdjac2
 #pragma unroll
         for (int j = 0; j < 6; j++) {
@@ -698,7 +719,12 @@ __global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kerne
             double hstep = eps * fabs(temp);
             if (hstep == 0) hstep = eps;
             x[j] = temp + hstep;
-            residuals<GS, E>(x, sp, ri, rj, act, size, lane, fp);
+#pragma unroll
+            for (int k = 0; k < (GS == 8 ? 2 : 1); k++) profj[k] = prof0[k];
+            // x0, sx move the x profile, y0, sy the y profile, photons and background neither
+            if (j == 0 || j == 4) profiles<GS>(x, size, lane, GS == 8 ? 1 : 3, profj);
+            if (j == 1 || j == 5) profiles<GS>(x, size, lane, GS == 8 ? 2 : 3, profj);
+            residuals<GS, E>(x, profj, sp, ri, rj, act, size, lane, fp);
             x[j] = temp;
 #pragma unroll
             for (int e = 0; e < E; e++) a[j][e] = ((double)fp[e] - (double)fv[e]) / hstep;

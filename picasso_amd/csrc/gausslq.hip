@@ -650,8 +650,11 @@ struct LqState {                                 // structure of arrays, stride 
 #define LQI(st, f, ls) (st).i[(int64_t)(f) * (st).stride + (ls)]
 
 // (a): residuals at x, Jacobian, QR.  list == nullptr: spots [first, min(first + count, n)).
+// Waves per SIMD the Jacobian kernel leaves room for: three where a lane holds at most four rows of a small box (boxes
+// 3 and 5: 4 / 35 spilled values, 5x5 5.67 -> 5.42 ms per 1e6 spots), two elsewhere (7x7 at three: 230 spills, 7.6 -> 11.6 ms).
+constexpr int lq_jacobian_min_waves(int GS, int E) { return GS * E <= 32 ? 3 : LQ_MIN_WAVES; }
 template <int GS, int E, bool FROM_MOVIE, bool STRICT>
-__global__ __launch_bounds__(LQ_WAVES * 64, LQ_MIN_WAVES) void lq_jacobian_kernel(Params p, LqState st, const int32_t *__restrict__ list,
+__global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E)) void lq_jacobian_kernel(Params p, LqState st, const int32_t *__restrict__ list,
                                                                       const unsigned *__restrict__ list_n, int64_t count)
 {
     constexpr int NGRP = 64 / GS;                              // spots per wavefront
@@ -898,11 +901,18 @@ __global__ __launch_bounds__(256) void lq_init_kernel(Params p, LqState st, int6
 }
 
 constexpr int LQ_STEP_NT = 128;
+// One spot per lane, float64 throughout: chains of dependent divisions and square roots, i.e. latency, and left alone
+// the kernel takes 256 VGPRs + 54 AGPRs = one wave per SIMD.  Asked to leave room for two, the compiler spills 59
+// values (216 B of scratch per lane) and the kernel is still the faster for it: 7x7 8.40 -> 7.60 ms per 1e6 spots, 5x5
+// and 13x13 -5 % / -4 % (alternating runs on one box).
+#ifndef LQ_STEP_MIN_WAVES
+#define LQ_STEP_MIN_WAVES 2
+#endif
 
 // (b): one spot per lane — the Levenberg-Marquardt step(s) on the factor lq_jacobian_kernel left, until the fit ends
 // or needs a new Jacobian.  Spots that go on are appended to next_list.
 template <bool FROM_MOVIE>
-__global__ __launch_bounds__(LQ_STEP_NT) void lq_step_kernel(Params p, LqState st, const int32_t *__restrict__ list,
+__global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(Params p, LqState st, const int32_t *__restrict__ list,
                                                              const unsigned *__restrict__ list_n, int64_t count,
                                                              int32_t *__restrict__ next_list, unsigned *__restrict__ next_n,
                                                              int32_t *__restrict__ tie_list, unsigned *__restrict__ tie_n)

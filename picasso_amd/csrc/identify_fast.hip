@@ -169,9 +169,18 @@ struct FastParams {
 #ifndef FAST_D_H6
 #define FAST_D_H6 6
 #endif
-#ifndef FAST_ROUND
-#define FAST_ROUND 64         // candidates per in-loop round of exact net gradients (lanes busy vs. rows still in the Infinity Cache)
+// Candidates per in-loop round of exact net gradients: lanes busy (a round costs the same whatever it holds) against rows
+// still near (a candidate's rows are re-read 100 ... 250 rows after they streamed with rounds of 64).  Round 3, on the
+// kernel with the common row ring, alternating runs on one box: box 7 1.180 / 1.147 / 1.190 ms with rounds of 64 / 32 / 16
+// (six runs each, 32 ahead in every one), boxes 5 and 9 alike at 64 and 32, box 13 8 % slower at 32 (its rounds cost
+// three times box 7's).
+#ifndef FAST_ROUND_SMALL
+#define FAST_ROUND_SMALL 32
 #endif
+#ifndef FAST_ROUND_WIDE
+#define FAST_ROUND_WIDE 64
+#endif
+constexpr int fast_round(int H) { return H <= 4 ? FAST_ROUND_SMALL : FAST_ROUND_WIDE; }
 #ifndef FAST_MIN_WAVES
 #define FAST_MIN_WAVES 4      // waves per SIMD the register allocator must leave room for
 #endif
@@ -455,7 +464,8 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
     // lane window — and a chunk that saw a lower pixel is run again: with four times the slack first, then without.
     u32 cfloor = 0u;
     bool redo = false;
-    int trigger = filter ? 8 + (FAST_ROUND / 8) * (int)(blockIdx.x % 7u) : THRESH;
+    constexpr int ROUND = fast_round(H);
+    int trigger = filter ? 8 + (ROUND / 8) * (int)(blockIdx.x % 7u) : THRESH;
 
     // ---- results: buffered in registers, appended KBUF rounds at a time with ONE slot-allocating atomic per flush
     // per wave on the counter of this block's shard (a single hot counter costs ~11 ns per atomic)
@@ -985,11 +995,11 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
             if (!filter || tail - head >= trigger) {
                 while (tail - head >= 64) exact_round(64);
                 if (filter) {
-                    if (tail - head >= FAST_ROUND || (trigger < FAST_ROUND && tail > head)) exact_round(tail - head);
+                    if (tail - head >= ROUND || (trigger < ROUND && tail > head)) exact_round(tail - head);
                     // A threshold so low that most maxima pass the floor (two and more candidates per row): ending the
-                    // chunk every FAST_ROUND candidates would replay the 2H + 2 halo rows every dozen rows — the ring
+                    // chunk every ROUND candidates would replay the 2H + 2 halo rows every dozen rows — the ring
                     // is then drained only when nearly full, as without a floor.
-                    trigger = (dn > 0 && added >= 2 * dn) ? THRESH : FAST_ROUND;
+                    trigger = (dn > 0 && added >= 2 * dn) ? THRESH : ROUND;
                 }
             }
             o += dn;

@@ -900,7 +900,7 @@ __global__ __launch_bounds__(256) void lq_init_kernel(Params p, LqState st, int6
     LQI(st, 9, ls) = 0;
 }
 
-constexpr int LQ_STEP_NT = 128;
+constexpr int LQ_STEP_NT = 64;        // one wave per workgroup: 7.58 -> 7.46 ms per 1e6 7x7 spots against 128 (256: 7.8), 13x13 -6 %; the tile of a wave's spots is its own
 // One spot per lane, float64 throughout: chains of dependent divisions and square roots, i.e. latency, and left alone
 // the kernel takes 256 VGPRs + 54 AGPRs = one wave per SIMD.  Asked to leave room for two, the compiler spills 59
 // values (216 B of scratch per lane) and the kernel is still the faster for it: 7x7 8.40 -> 7.60 ms per 1e6 spots, 5x5

@@ -237,8 +237,18 @@ int pmi_net_gradient(const float *image, int64_t Y, int64_t X, const int32_t *y,
  * fitted AGAIN from its start values with the sums in MINPACK's order, inside the same call.
  * pmi_gausslq_last_refit_count: how many spots of the calling thread's last call were.                       */
 int pmi_gausslq(const float *spots, int64_t N, int box, float *thetas, int32_t *info, int32_t *nfev);
+/* How those sums run (the counterpart of pmi_mle_set_mode for scipy.optimize.leastsq, picasso/gausslq.py:240-242):
+ *   PMI_LQ_FAST    tree sums only: theta within ~1e-3 px on all but ~2e-5 of adversarial spots, no second fit;
+ *   PMI_LQ_REFIT   tree sums, and the spots with a decision inside rounding distance of its threshold, a pivot tie or a
+ *                  nearly rank-deficient Jacobian fitted again in MINPACK's order;
+ *   PMI_LQ_STRICT  every spot with MINPACK's sequential sums from the first Jacobian on: theta, info and nfev are
+ *                  lmdif's on every spot.
+ * Process-wide; the environment variable PMI_LQ_MODE = fast | refit | strict overrides the mode.                 */
+enum pmi_lq_mode { PMI_LQ_FAST = 0, PMI_LQ_REFIT = 1, PMI_LQ_STRICT = 2 };
+int pmi_gausslq_set_mode(int mode);
+int pmi_gausslq_get_mode(int *mode);
 int pmi_gausslq_last_refit_count(int64_t *n_refit);
-/* ... and which test sent them there (n <= 7 counters: pivot choice, lmpar's band, 0.1 fnorm1 < fnorm, the gain-ratio
+/* ... and which test sent them there (n <= 9 counters: pivot choice, lmpar's band, 0.1 fnorm1 < fnorm, the gain-ratio
  * thresholds, the ftol tests, a reduction at the noise level, the xtol test; a spot can carry several)        */
 int pmi_gausslq_last_tie_reasons(int64_t *counts, int n);
 int pmi_gausslq_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box, float *d_thetas,

@@ -66,6 +66,8 @@ SYMBOLS = {
     "pmi_localize_set_ranges": (_i32, [_i32]),
     "pmi_localize_mle_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _f64, _f64, _f64,
                                     _f64, _i32, _i32, _p, _i64, _p, _p]),
+    "pmi_gausslq_set_mode": (_i32, [_i32]),
+    "pmi_gausslq_get_mode": (_i32, [_p]),
     "pmi_gausslq_last_refit_count": (_i32, [_p]),
     "pmi_gausslq_last_tie_reasons": (_i32, [_p, _i32]),
     "pmi_gausslq": (_i32, [_p, _i64, _i32, _p, _p, _p]),

@@ -20,6 +20,7 @@
 // except when it flips a float32 rounding of the stored model.
 #include <algorithm>
 #include <cstdlib>
+#include <cstring>
 
 #include "fit_common.h"
 
@@ -1164,6 +1165,20 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
 #ifndef LQ_BATCH_LOG2
 #define LQ_BATCH_LOG2 21      // spots per batch (state: 552 B per spot); every batch ends with one host synchronisation
 #endif
+// How the sums over the residual rows are run (pmi_gausslq_set_mode): PMI_LQ_FAST tree sums only, PMI_LQ_REFIT tree sums
+// and a second fit in MINPACK's order for the spots with a decision near its threshold, PMI_LQ_STRICT every spot in
+// MINPACK's order from the start
+static int g_lq_mode = PMI_LQ_REFIT;
+static int lq_mode_now()
+{
+    static const char *env = getenv("PMI_LQ_MODE");       // "fast" | "refit" | "strict" overrides pmi_gausslq_set_mode
+    if (env) {
+        if (!strcmp(env, "fast")) return PMI_LQ_FAST;
+        if (!strcmp(env, "strict")) return PMI_LQ_STRICT;
+        if (!strcmp(env, "refit")) return PMI_LQ_REFIT;
+    }
+    return g_lq_mode;
+}
 static thread_local int64_t g_last_lq_strict = 0;       // spots of the calling thread's last fit that were fitted again
 static thread_local int64_t g_last_lq_why[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // [7], [8]: rounds queued in the first / second pass
 
@@ -1190,7 +1205,8 @@ static int launch(Params p, hipStream_t s)
     unsigned *counters = (unsigned *)(tie_list + cap);           // one per round + the tie counter, zeroed per batch
     constexpr int NCTR = 64;
     unsigned *tie_n = counters + NCTR;
-    static const bool no_strict = tuning_env("PMI_LQ_NO_STRICT") != nullptr;      // A/B: the tree sums only
+    const int mode = lq_mode_now();
+    const bool no_strict = mode == PMI_LQ_FAST, all_strict = mode == PMI_LQ_STRICT;
     float *cut = nullptr;
     const int mpix = p.box * p.box;
     if (FROM_MOVIE_IN) {
@@ -1217,12 +1233,13 @@ static int launch(Params p, hipStream_t s)
         // pass 0: every spot of the batch, tree sums, decisions near a threshold collected in tie_list;
         // pass 1: the spots of tie_list again from their start values, sequential sums, no flagging
         unsigned hw[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // tie count and its reasons, read with the first pass's last look at the stream
-        for (int pass = 0; pass < 2; pass++) {
-            const int32_t *cur = pass == 0 ? nullptr : tie_list;
-            const unsigned *cur_n = pass == 0 ? nullptr : tie_n;
+        // strict mode: one pass over every spot with the sequential sums, nothing to flag
+        for (int pass = all_strict ? 1 : 0; pass < 2; pass++) {
+            const int32_t *cur = pass == 0 || all_strict ? nullptr : tie_list;
+            const unsigned *cur_n = pass == 0 || all_strict ? nullptr : tie_n;
             int64_t bound = count;                                   // spots the next round may hold
             unsigned h[3] = {0, 0, 0};                               // spots left, spots tied, (first batch) device row count
-            if (pass == 1) {
+            if (pass == 1 && !all_strict) {
                 h[1] = hw[0];
                 for (int b = 0; b < 7; b++) g_last_lq_why[b] += hw[1 + b];
                 if (h[1] == 0 || no_strict) break;
@@ -1255,7 +1272,7 @@ static int launch(Params p, hipStream_t s)
                 PMI_HIP(hipMemcpyAsync(&h[0], cur_n, sizeof(unsigned), hipMemcpyDeviceToHost, s));
                 if (pass == 0) PMI_HIP(hipMemcpyAsync(hw, tie_n, sizeof(hw), hipMemcpyDeviceToHost, s));
                 int64_t dn = -1;
-                if (pass == 0 && first == 0 && p.d_n) PMI_HIP(hipMemcpyAsync(&dn, p.d_n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+                if ((pass == 0 || all_strict) && first == 0 && p.d_n) PMI_HIP(hipMemcpyAsync(&dn, p.d_n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
                 PMI_HIP(hipStreamSynchronize(s));
                 // the caller's N is a capacity when the row count lives on the device: no batch is queued past the rows that exist
                 if (dn >= 0 && dn < Ntotal) Ntotal = dn;
@@ -1330,6 +1347,20 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
 }  // namespace pmi
 
 extern "C" {
+
+int pmi_gausslq_set_mode(int mode)
+{
+    using namespace pmi;
+    if (mode != PMI_LQ_FAST && mode != PMI_LQ_REFIT && mode != PMI_LQ_STRICT) { set_error("unknown gausslq mode %d", mode); return PMI_ERR_ARG; }
+    lq::g_lq_mode = mode;
+    return PMI_OK;
+}
+
+int pmi_gausslq_get_mode(int *mode)
+{
+    if (mode) *mode = pmi::lq::lq_mode_now();
+    return PMI_OK;
+}
 
 int pmi_gausslq_last_refit_count(int64_t *n_refit)
 {

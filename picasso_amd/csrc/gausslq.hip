@@ -630,6 +630,161 @@ __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], 
     wa1[j] = -ajnorm;
 }
 
+// ---- strict mode: MINPACK's m-long sums as chains, one column per lane ---------------------------------------------
+// A column's rows go to LDS padded to MP = GS * E slots (zeros before row_lo and from row m on: adding +0 to a sum that
+// started at +0 never changes it), and a lane adds ITS column's slots one after the other in row order — lmdif's own
+// order (enorm, qrfac's Householder products, Q^T fvec) — while the other lanes of the group do the same for the other
+// columns of the step.  The LDS reads of sixteen slots are issued together (a dependent add per read pays the LDS
+// latency per element otherwise: measured 100+ cycles per element).
+typedef double d2_t __attribute__((ext_vector_type(2)));
+template <int GS, int E>
+__device__ __forceinline__ void col_to_lds(const double (&v)[E], int lane, int row_lo, int m, double *col)
+{
+    const int mp = (m + 1) & ~1;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int r = lane + GS * e;
+        if (r < mp) col[r] = (r >= row_lo && r < m) ? v[e] : 0.0;
+    }
+}
+// does enorm have to leave its common branch for this lane's rows of the column? (a component that is tiny, huge or NaN)
+template <int GS, int E>
+__device__ __forceinline__ bool col_is_odd(const double (&v)[E], int lane, int row_lo, int m)
+{
+    const double agiant = RGIANT / (double)(m - row_lo);
+    bool odd = false;
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int r = lane + GS * e;
+        const double xabs = fabs(v[e]);
+        odd = odd || (r >= row_lo && r < m && !((xabs > RDWARF && xabs < agiant) || xabs == 0));
+    }
+    return odd;
+}
+template <int NB, bool SQUARE>
+__device__ __forceinline__ double chain_batch(const __attribute__((address_space(3))) d2_t *p, double acc)
+{
+    d2_t v[NB];
+#pragma unroll
+    for (int i = 0; i < NB; i++) v[i] = p[i];
+    if constexpr (NB == 8)
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
+    else
+        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+        acc += SQUARE ? v[i].x * v[i].x : v[i].x;
+        acc += SQUARE ? v[i].y * v[i].y : v[i].y;
+    }
+    return acc;
+}
+// sum (SQUARE: of the squares) of the mp slots (mp even) of an LDS column, in slot order
+template <bool SQUARE>
+__device__ __forceinline__ double chain_sum(const double *col, int mp)
+{
+    const __attribute__((address_space(3))) d2_t *p = (const __attribute__((address_space(3))) d2_t *)col;
+    double acc = 0;
+    int b = 0;
+#pragma unroll 1
+    for (; b + 16 <= mp; b += 16) acc = chain_batch<8, SQUARE>(p + b / 2, acc);
+    if (b + 8 <= mp) { acc = chain_batch<4, SQUARE>(p + b / 2, acc); b += 8; }
+#pragma unroll 1
+    for (; b < mp; b += 2) {
+        const d2_t v = p[b / 2];
+        acc += SQUARE ? v.x * v.x : v.x;
+        acc += SQUARE ? v.y * v.y : v.y;
+    }
+    return acc;
+}
+// MINPACK enorm of an LDS column holding n = m - row_lo components (zeros elsewhere): the common branch as a chain of
+// squares; `odd` (this lane's column has a component outside (RDWARF, agiant)) takes the published scaled accumulators
+__device__ __forceinline__ double chain_enorm(const double *col, int mp, int n, bool odd)
+{
+    const double s2 = chain_sum<true>(col, mp);
+    double res = sqrt(s2);
+    if (odd) {
+        EnormAcc acc(n);
+#pragma unroll 1
+        for (int r = 0; r < mp; r++) acc.add(col[r]);        // (a zero leaves the accumulators as they are)
+        res = acc.norm();
+    }
+    return res;
+}
+
+// Strict mode, one column of qrfac.  The rows of every trailing column k > j — and of the residual vector, which the
+// Householder vectors transform exactly as they transform a column (lmdif's Q^T fvec loop: sum / a_jj with the sign
+// moved, the same bits) — go to LDS as products a_ij * a_ik, and lane k - j - 1 of the group adds ITS column: one chain
+// per step instead of one per column.  a[6] is the residual column.  sbuf: 6 columns of m (rounded up to even) doubles per group.
+template <int GS, int E, int j>
+__device__ __forceinline__ void qrfac_strict_step(double (&a)[7][E], double (&wa1)[6], double (&wa3)[6], int (&ipvt)[6],
+                                                  int lane, int m, double *sbuf)
+{
+    const int MP = (m + 1) & ~1;
+    int kmax = j;
+    double best = wa1[j];
+#pragma unroll
+    for (int k = j + 1; k < 6; k++)
+        if (wa1[k] > best) { best = wa1[k]; kmax = k; }
+#pragma unroll
+    for (int k = j + 1; k < 6; k++) {
+        const bool sw = kmax == k;
+#pragma unroll
+        for (int e = 0; e < E; e++) {
+            const double t = a[j][e], u = a[k][e];
+            a[j][e] = sw ? u : t;
+            a[k][e] = sw ? t : u;
+        }
+        wa1[k] = sw ? opaque(wa1[j]) : opaque(wa1[k]);
+        wa3[k] = sw ? opaque(wa3[j]) : opaque(wa3[k]);
+        const int t = ipvt[j], u = ipvt[k];
+        ipvt[j] = sw ? u : t;
+        ipvt[k] = sw ? t : u;
+    }
+    col_to_lds<GS, E>(a[j], lane, j, m, sbuf);
+    const bool odd_j = Grp<GS>::any(col_is_odd<GS, E>(a[j], lane, j, m));
+    grp_sync();
+    double ajnorm = chain_enorm(sbuf, MP, m - j, odd_j);        // every lane of the group: the reads are broadcasts
+    grp_sync();
+    if (ajnorm != 0) {
+        if (Grp<GS>::bcast_d(a[j][0], j) < 0) ajnorm = -ajnorm;
+#pragma unroll
+        for (int e = 0; e < E; e++)
+            if (e > 0 || lane >= j) a[j][e] /= ajnorm;
+        if (lane == j) a[j][0] += 1;
+        const double ajj = Grp<GS>::bcast_d(a[j][0], j);
+        // the 6 - j sums of this step as parallel chains
+#pragma unroll
+        for (int k = j + 1; k < 7; k++) {
+            double prod[E];
+#pragma unroll
+            for (int e = 0; e < E; e++) prod[e] = a[j][e] * a[k][e];
+            col_to_lds<GS, E>(prod, lane, j, m, sbuf + (size_t)(k - j - 1) * MP);
+        }
+        grp_sync();
+        const double acc = chain_sum<false>(sbuf + (size_t)(lane < 6 - j ? lane : 5 - j) * MP, MP);   // lanes beyond the columns repeat the last one
+        grp_sync();
+#pragma unroll
+        for (int k = j + 1; k < 7; k++) {
+            const double sum = Grp<GS>::bcast_d(acc, k - j - 1);
+            double temp = sum / ajj;
+#pragma unroll
+            for (int e = 0; e < E; e++)
+                if (e > 0 || lane >= j) a[k][e] -= temp * a[j][e];
+            if (k < 6 && wa1[k] != 0) {
+                temp = Grp<GS>::bcast_d(a[k][0], j) / wa1[k];
+                const double t2 = 1 - temp * temp;
+                wa1[k] *= sqrt(t2 > 0 ? t2 : 0);
+                const double q = wa1[k] / wa3[k];
+                if (0.05 * (q * q) <= EPSMCH) {
+                    wa1[k] = seq_enorm<GS, E>(a[k], lane, j + 1, m, sbuf);
+                    wa3[k] = wa1[k];
+                }
+            }
+        }
+    }
+    wa1[j] = -ajnorm;
+}
+
 // ---- the fit as two kernels per outer iteration ----------------------------------------------------------------
 // lmdif alternates two kinds of work: (a) residuals, forward-difference Jacobian and its pivoted QR factorisation —
 // m x 6 data, done by a GROUP of lanes per spot (DPP reductions, the Jacobian columns in registers); (b) the
@@ -659,8 +814,8 @@ __global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E)) void l
                                                                       const unsigned *__restrict__ list_n, int64_t count)
 {
     constexpr int NGRP = 64 / GS;                              // spots per wavefront
-    extern __shared__ __attribute__((aligned(16))) char s_rows[];      // strict mode: m doubles per group of the workgroup
-    double *sbuf = STRICT ? reinterpret_cast<double *>(s_rows) + (size_t)(((threadIdx.x >> 6) * NGRP) + (threadIdx.x & 63) / GS) * (size_t)(p.box * p.box)
+    extern __shared__ __attribute__((aligned(16))) char s_rows[];      // strict mode: 6 columns of box^2 (+ 1) doubles per group of the workgroup (the columns a step sums, side by side)
+    double *sbuf = STRICT ? reinterpret_cast<double *>(s_rows) + (size_t)(((threadIdx.x >> 6) * NGRP) + (threadIdx.x & 63) / GS) * (size_t)(6 * ((p.box * p.box + 1) & ~1))
                           : nullptr;
     const int lane = (threadIdx.x & 63) % GS;                  // lane inside the group
     const int grp = (threadIdx.x & 63) / GS;
@@ -709,7 +864,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E)) void l
 #pragma unroll
         for (int j = 0; j < 6; j++) x[j] = LQD(st, j, ls);
 
-        double a[6][E], w4[E];
+        double a[STRICT ? 7 : 6][E], w4[E];
         float fv[E], fp[E];                   // residuals at x and at the perturbed x (float32 values, gausslq.py:203)
         double wa1[6], wa2[6], wa3[6];
         int ipvt[6];
@@ -734,21 +889,57 @@ __global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E)) void l
             for (int e = 0; e < E; e++) a[j][e] = ((double)fp[e] - (double)fv[e]) / hstep;
         }
         // qrfac with column pivoting: rdiag = wa1, acnorm = wa2, wa = wa3
+        bool tie = false;
+        if constexpr (STRICT) {
+            // every sum over the rows in MINPACK's order; the six column norms as six chains side by side
+            const int MP = (m + 1) & ~1;
+            unsigned oddmask = 0;
+#pragma unroll
+            for (int c = 0; c < 6; c++) {
+                col_to_lds<GS, E>(a[c], lane, 0, m, sbuf + (size_t)c * MP);
+                oddmask |= Grp<GS>::any(col_is_odd<GS, E>(a[c], lane, 0, m)) ? 1u << c : 0u;
+            }
+            grp_sync();
+            const int myc = lane < 6 ? lane : 5;
+            const double mynorm = chain_enorm(sbuf + (size_t)myc * MP, MP, m, (oddmask >> myc) & 1u);
+            grp_sync();
+#pragma unroll
+            for (int j = 0; j < 6; j++) {
+                wa2[j] = Grp<GS>::bcast_d(mynorm, j);
+                wa1[j] = wa2[j];
+                wa3[j] = wa1[j];
+                ipvt[j] = j;
+            }
+            double (&a7)[7][E] = a;
+#pragma unroll
+            for (int e = 0; e < E; e++) a7[6][e] = (double)fv[e];
+            qrfac_strict_step<GS, E, 0>(a7, wa1, wa3, ipvt, lane, m, sbuf);
+            qrfac_strict_step<GS, E, 1>(a7, wa1, wa3, ipvt, lane, m, sbuf);
+            qrfac_strict_step<GS, E, 2>(a7, wa1, wa3, ipvt, lane, m, sbuf);
+            qrfac_strict_step<GS, E, 3>(a7, wa1, wa3, ipvt, lane, m, sbuf);
+            qrfac_strict_step<GS, E, 4>(a7, wa1, wa3, ipvt, lane, m, sbuf);
+            qrfac_strict_step<GS, E, 5>(a7, wa1, wa3, ipvt, lane, m, sbuf);
+            // R: row i in lane i; (Q^T fvec)[j] in lane j of the residual column
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+                if (lane == j) a[j][0] = wa1[j];
+#pragma unroll
+            for (int e = 0; e < E; e++) w4[e] = a7[6][e];
+        } else {
 #pragma unroll
         for (int j = 0; j < 6; j++) {
-            wa2[j] = STRICT ? seq_enorm<GS, E>(a[j], lane, 0, m, sbuf) : enorm_rows<GS, E>(a[j], lane, 0, m);
+            wa2[j] = enorm_rows<GS, E>(a[j], lane, 0, m);
             wa1[j] = wa2[j];
             wa3[j] = wa1[j];
             ipvt[j] = j;
         }
-        bool tie = false;
-        qrfac_step<GS, E, 0, STRICT>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
-        qrfac_step<GS, E, 1, STRICT>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
-        qrfac_step<GS, E, 2, STRICT>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
-        qrfac_step<GS, E, 3, STRICT>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
-        qrfac_step<GS, E, 4, STRICT>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
-        qrfac_step<GS, E, 5, STRICT>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
-        if (!STRICT) {
+        qrfac_step<GS, E, 0, false>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
+        qrfac_step<GS, E, 1, false>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
+        qrfac_step<GS, E, 2, false>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
+        qrfac_step<GS, E, 3, false>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
+        qrfac_step<GS, E, 4, false>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
+        qrfac_step<GS, E, 5, false>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
+        {
             // a column of which less than LQ_RANK survives the projection on the columns before it: the Jacobian is
             // close to rank deficient, the Gauss-Newton step amplifies the last bits of R and Q^T f by 1 / that ratio, and
             // every later decision inherits the difference (a width that collapses or turns negative, nine residuals
@@ -764,23 +955,17 @@ __global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E)) void l
             const double ajj = Grp<GS>::bcast_d(a[j][0], j);
             if (ajj != 0) {
                 double sum = 0;
-                if (STRICT) {
-                    double prod[E];
 #pragma unroll
-                    for (int e = 0; e < E; e++) prod[e] = a[j][e] * w4[e];
-                    sum = seq_sum<GS, E>(prod, lane, j, m, sbuf);
-                } else {
-#pragma unroll
-                    for (int e = 0; e < E; e++)
-                        if (e > 0 || lane >= j) sum += a[j][e] * w4[e];
-                    sum = Grp<GS>::sum_d(sum);
-                }
+                for (int e = 0; e < E; e++)
+                    if (e > 0 || lane >= j) sum += a[j][e] * w4[e];
+                sum = Grp<GS>::sum_d(sum);
                 const double temp = -sum / ajj;
 #pragma unroll
                 for (int e = 0; e < E; e++)
                     if (e > 0 || lane >= j) w4[e] += a[j][e] * temp;
             }
             if (lane == j) a[j][0] = wa1[j];
+        }
         }
         if (store && lane < 6) {
 #pragma unroll
@@ -1125,9 +1310,16 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
         return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
     };
     // strict mode: m doubles of LDS per group (the rows of one column at a time, summed in MINPACK's order)
-    auto lds_for = [&](int spots_per_wave) { return STRICT ? (size_t)LQ_WAVES * spots_per_wave * m * sizeof(double) : (size_t)0; };
+    auto lds_for = [&](int spots_per_wave) { return STRICT ? (size_t)LQ_WAVES * spots_per_wave * 6 * ((m + 1) & ~1) * sizeof(double) : (size_t)0; };
     static const bool g16 = tuning_env("PMI_LQ_GROUP16") != nullptr;      // A/B: the 16-lane groups for boxes up to 7
-#define LQ_JAC(GS, E, SPW) hipLaunchKernelGGL((lq_jacobian_kernel<GS, E, FROM_MOVIE, STRICT>), grid_for(SPW), block, lds_for(SPW), s, p, st, list, list_n, count)
+    // (more than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel)
+#define LQ_JAC(GS, E, SPW) do { \
+        if (lds_for(SPW) > 65536) { \
+            static bool asked = false; \
+            if (!asked) { (void)hipFuncSetAttribute((const void *)lq_jacobian_kernel<GS, E, FROM_MOVIE, STRICT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); asked = true; } \
+        } \
+        hipLaunchKernelGGL((lq_jacobian_kernel<GS, E, FROM_MOVIE, STRICT>), grid_for(SPW), block, lds_for(SPW), s, p, st, list, list_n, count); \
+    } while (0)
     if (p.box <= 7 && !g16) {
         // eight spots per wavefront: the scalar chains of the factorisation (norm updates, Householder scalings:
         // float64 divisions and square roots every lane of a group repeats) are shared by twice as many fits

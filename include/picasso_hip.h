@@ -73,6 +73,7 @@ int         pmi_version(void);
 const char *pmi_last_error(void);            /* gpufit_get_last_error analogue  */
 int         pmi_device_count(void);          /* gpufit_cuda_available analogue: 0 = no GPU */
 int         pmi_set_device(int device);
+int         pmi_get_device(int *device);     /* the calling thread's current device */
 int         pmi_device_info(char *name, size_t name_len, int *compute_units,
                             size_t *total_mem_bytes);
 
@@ -206,6 +207,14 @@ int pmi_localize_set_ranges(int ranges);
  * +0.14 ms (7 more scattered 16-byte stores per candidate on a kernel bound by its memory-side requests) - the same
  * table, no gain, hence off. */
 int pmi_localize_set_handoff(int on);
+/* Deferred exact stage (default on): on uint16 / uint8 / int16 movies, boxes up to 15 and a positive threshold the packed
+ * scan of pmi_localize_mle_dev only emits CANDIDATES (window maximum, floor, neighbour rule) and the start-value kernel
+ * of the fit — which reads a candidate's rows anyway — evaluates the float32 net gradient in the reference's (k, l)
+ * order, the first-argmax rule and the threshold (picasso/localize.py:97-134, 202-244, 288): the scan no longer re-reads
+ * nine lines per candidate.  Same table, bit for bit.  The identification / fit scratch then holds cap + cap / 2 + 4096
+ * candidates; if a call finds more, *d_out_n reports the number of CANDIDATES (an upper bound of the rows needed), nothing is
+ * fitted and the table is untouched, exactly as for a table that is too small.  0: the exact stage stays in the scan. */
+int pmi_localize_set_defer(int on);
 int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X,
                          int box, double min_ng, const int64_t *roi4, int64_t f_lo, int64_t f_hi,
                          double baseline, double sensitivity, double gain,
@@ -230,19 +239,24 @@ int pmi_net_gradient(const float *image, int64_t Y, int64_t X, const int32_t *y,
  * residual evaluations, what leastsq(full_output=1) would report.
  * The _dev forms queue five rounds of (Jacobian, step) and then WAIT for the stream once per batch of 2 Mi spots to
  * read how many fits need more (on photon data: none); they are asynchronous up to that point only.
- * Arithmetic: the sums over the box^2 residual rows (column norms, Householder products, Q^T f) are tree
- * reductions over the lanes of a spot's group; MINPACK adds them one after the other.  The two differ in the last
- * bits of float64, which matters only where one of lmdif's tests (the gain ratio against 1e-4 / 0.25 / 0.75, the
- * termination tests, lmpar's 10 % band, qrfac's pivot choice) is decided within those bits: every such spot is
- * fitted AGAIN from its start values with the sums in MINPACK's order, inside the same call.
- * pmi_gausslq_last_refit_count: how many spots of the calling thread's last call were.                       */
+ * Arithmetic (modes below): MINPACK adds the box^2 residual rows of a column norm, a Householder product or Q^T f one
+ * after the other; tree reductions over the lanes of a spot's group differ from that in the last bits of float64, which
+ * matters where one of lmdif's tests (the gain ratio against 1e-4 / 0.25 / 0.75, the termination tests, lmpar's 10 %
+ * band, qrfac's pivot choice) is decided within those bits.  REFIT fits every such spot AGAIN from its start values with
+ * the sums in MINPACK's order, inside the same call (pmi_gausslq_last_refit_count: how many spots of the calling thread's
+ * last call were); STRICT, the default, uses MINPACK's order for every spot from the start.                    */
 int pmi_gausslq(const float *spots, int64_t N, int box, float *thetas, int32_t *info, int32_t *nfev);
 /* How those sums run (the counterpart of pmi_mle_set_mode for scipy.optimize.leastsq, picasso/gausslq.py:240-242):
  *   PMI_LQ_FAST    tree sums only: theta within ~1e-3 px on all but ~2e-5 of adversarial spots, no second fit;
  *   PMI_LQ_REFIT   tree sums, and the spots with a decision inside rounding distance of its threshold, a pivot tie or a
- *                  nearly rank-deficient Jacobian fitted again in MINPACK's order;
- *   PMI_LQ_STRICT  every spot with MINPACK's sequential sums from the first Jacobian on: theta, info and nfev are
- *                  lmdif's on every spot.
+ *                  nearly rank-deficient Jacobian fitted again in MINPACK's order.  theta, info and nfev are lmdif's on
+ *                  99.998 % of adversarial spots; 5e-6 of them end beyond 1e-3 px (up to 2.4 px measured) with the same
+ *                  `info` — a float32 rounding of the stored model flipped by the last bits of a tree sum, which no
+ *                  test of the fit sees;
+ *   PMI_LQ_STRICT  (default) every sum over the residual rows — enorm, qrfac's Householder products, Q^T fvec — in
+ *                  MINPACK's sequential order from the first Jacobian on (one chain per column, side by side in the lanes
+ *                  of a spot's group): theta, info and nfev are lmdif's on EVERY spot, bit for bit.  1.2x the time of
+ *                  REFIT on 7x7 boxes, 1.3x on 5x5, 1.5x on 13x13.
  * Process-wide; the environment variable PMI_LQ_MODE = fast | refit | strict overrides the mode.                 */
 enum pmi_lq_mode { PMI_LQ_FAST = 0, PMI_LQ_REFIT = 1, PMI_LQ_STRICT = 2 };
 int pmi_gausslq_set_mode(int mode);

@@ -36,6 +36,7 @@ SYMBOLS = {
     "pmi_last_error": (ctypes.c_char_p, []),
     "pmi_device_count": (_i32, []),
     "pmi_set_device": (_i32, [_i32]),
+    "pmi_get_device": (_i32, [_p]),
     "pmi_device_info": (_i32, [_p, _sz, _p, _p]),
     "pmi_malloc": (_i32, [_p, _sz]),
     "pmi_free": (_i32, [_p]),
@@ -64,6 +65,7 @@ SYMBOLS = {
     "pmi_locs_from_fits_dev": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i32, _p, _p]),
     "pmi_localize_set_handoff": (_i32, [_i32]),
     "pmi_localize_set_ranges": (_i32, [_i32]),
+    "pmi_localize_set_defer": (_i32, [_i32]),
     "pmi_localize_mle_dev": (_i32, [_p, _i32, _i64, _i64, _i64, _i32, _f64, _p, _i64, _i64, _f64, _f64, _f64,
                                     _f64, _i32, _i32, _p, _i64, _p, _p]),
     "pmi_gausslq_set_mode": (_i32, [_i32]),

@@ -158,24 +158,44 @@ def last_refit_count(stream=None) -> int:
     return int(n.value)
 
 
-_prewarmed = set()
+_prewarm_threads = {}      # (device, Y, X) -> the thread making that size's FFT plans
 
 
 def prewarm_fft(Y: int, X: int) -> None:
-    """Start making the FFT plans of RCC undrift for Y x X frames on a daemon thread (once per size): rocFFT compiles a
-    plan's kernels when the plan is made — 2.5 s at 2048 x 2048 — and a caller that localizes first has that time."""
+    """Start making the FFT plans of RCC undrift for Y x X frames on a side thread (once per device and size): rocFFT
+    compiles a plan's kernels when the plan is made — 2.5 s at 2048 x 2048 — and a caller that localizes first has that
+    time.  Call it only when an undrift will follow (`localize_file(drift=...)` does).  The worker sets the CALLER's
+    device before it makes the plans (plans belong to a device, and a new thread starts on device 0), is not a daemon,
+    and is joined by `join_fft_prewarm` — before the correlations run, and at interpreter exit — so it never outlives
+    the library it is calling into."""
     import threading
-    key = (int(Y), int(X))
-    if key in _prewarmed or min(key) < 64:
+    L = _lib.load()
+    dev = ctypes.c_int(0)
+    _lib.check(L.pmi_get_device(ctypes.byref(dev)), "pmi_get_device")
+    key = (int(dev.value), int(Y), int(X))
+    if key in _prewarm_threads or min(key[1:]) < 64:
         return
-    _prewarmed.add(key)
 
     def work():
         try:
-            _lib.load().pmi_fft_prewarm(key[0], key[1])       # ctypes releases the GIL
+            if L.pmi_set_device(key[0]) == 0:
+                L.pmi_fft_prewarm(key[1], key[2])       # ctypes releases the GIL
         except Exception:      # noqa: BLE001 - a convenience: the correlation makes its plans itself if this did not
             pass
-    threading.Thread(target=work, name="pmi-fft-prewarm", daemon=True).start()
+    t = threading.Thread(target=work, name="pmi-fft-prewarm", daemon=False)
+    _prewarm_threads[key] = t
+    t.start()
+
+
+def join_fft_prewarm() -> None:
+    """Wait for the plan-making threads (a finished thread stays in the table: its size is not made again)."""
+    for t in list(_prewarm_threads.values()):
+        if t.is_alive():
+            t.join()
+
+
+import atexit as _atexit      # noqa: E402
+_atexit.register(join_fft_prewarm)
 
 
 def last_lq_refit_count() -> int:

@@ -102,6 +102,16 @@ struct FitParams {
     const int32_t *final_list;
     const unsigned *final_list_n;
     unsigned char *refit_mark;   // one byte per spot of the batch: set by the strict re-fit, so that the second list only takes spots the first did not
+    // Deferred exact stage of identify (a fused call whose scan emitted CANDIDATES, pmi_common.h NG_DEFERRED_BITS): the
+    // start-value kernel (g8_init) computes the float32 net gradient in the reference's (k, l) order and the first-argmax
+    // test from the rows it reads for the fit anyway (picasso/localize.py:97-134, 202-244, 288), writes ng_io[i] and
+    // accept[i]; the later stages skip the rejected, the Newton loop runs over the accepted (alist), the table compacts.
+    float *ng_io;                // in: a net gradient, or NG_DEFERRED_BITS; out: the net gradient (nullptr: every row is an identification)
+    unsigned char *accept;       // one byte per spot (absolute index)
+    int crop_y0, crop_x0, crop_cy, crop_cx;      // the crop identify scanned: a stencil's row / column -1 wraps to the crop's last one
+    double min_ng;
+    const int32_t *alist;        // accepted spots of the batch (absolute indices), ascending; nullptr: all spots of the batch
+    const unsigned *alist_n;
 };
 // why a spot goes to the re-fit (a spot can carry several)
 enum : unsigned { FLAG_MARGIN = 1u, FLAG_CURVATURE = 2u, FLAG_NARROW = 4u, FLAG_SWING = 8u, FLAG_WILD = 16u, FLAG_SLOW = 32u, FLAG_UNSTABLE = 64u };

@@ -450,6 +450,7 @@ __device__ __forceinline__ void qrsolv(double *R, const int (&ipvt)[6], const do
 // MINPACK lmpar.
 // tie: set when one of its tests (the Gauss-Newton step inside the region? the 10 % band around it reached?) is decided
 // within LQ_TIE of its threshold
+template <bool FLAG>
 __device__ __forceinline__ void lmpar(double *R, const int (&ipvt)[6], const double (&diag)[6],
                                       const double (&qtb)[6], double delta, double &par, double (&x)[6],
                                       double (&sdiag)[6], unsigned &tie)
@@ -478,7 +479,7 @@ __device__ __forceinline__ void lmpar(double *R, const int (&ipvt)[6], const dou
     for (int j = 0; j < 6; j++) wa2[j] = diag[j] * x[j];
     double dxnorm = enorm6(wa2);
     double fp = dxnorm - delta;
-    tie |= !(fabs(fp - 0.1 * delta) > LQ_TIE * (dxnorm + delta)) ? 2u : 0u;
+    if constexpr (FLAG) tie |= !(fabs(fp - 0.1 * delta) > LQ_TIE * (dxnorm + delta)) ? 2u : 0u;
     if (fp <= 0.1 * delta) { par = 0; return; }
     double parl = 0;
     if (nsing >= 6) {
@@ -519,8 +520,9 @@ __device__ __forceinline__ void lmpar(double *R, const int (&ipvt)[6], const dou
         dxnorm = enorm6(wa2);
         temp = fp;
         fp = dxnorm - delta;
-        tie |= (!(fabs(fabs(fp) - 0.1 * delta) > LQ_TIE * (dxnorm + delta))
-                || (parl == 0 && temp < 0 && !(fabs(fp - temp) > LQ_TIE * (dxnorm + delta)))) ? 2u : 0u;
+        if constexpr (FLAG)
+            tie |= (!(fabs(fabs(fp) - 0.1 * delta) > LQ_TIE * (dxnorm + delta))
+                    || (parl == 0 && temp < 0 && !(fabs(fp - temp) > LQ_TIE * (dxnorm + delta)))) ? 2u : 0u;
         if (fabs(fp) <= 0.1 * delta || (parl == 0 && fp <= temp && temp < 0) || iter == 10) break;
 #pragma unroll
         for (int j = 0; j < 6; j++) { const int l = ipvt[j]; wa1[j] = get6(diag, l) * (get6(wa2, l) / dxnorm); }
@@ -678,7 +680,9 @@ __device__ __forceinline__ double chain_batch(const __attribute__((address_space
     }
     return acc;
 }
-// sum (SQUARE: of the squares) of the mp slots (mp even) of an LDS column, in slot order
+// sum (SQUARE: of the squares) of the mp slots (mp even) of an LDS column, in slot order.  (Reading the next sixteen
+// slots while the current sixteen are added — 32 more registers in a kernel that sits at 256 — measured slower: 7x7 8.9 ->
+// 10.8 ms per 1e6 spots.)
 template <bool SQUARE>
 __device__ __forceinline__ double chain_sum(const double *col, int mp)
 {
@@ -1097,7 +1101,8 @@ constexpr int LQ_STEP_NT = 64;        // one wave per workgroup: 7.58 -> 7.46 ms
 
 // (b): one spot per lane — the Levenberg-Marquardt step(s) on the factor lq_jacobian_kernel left, until the fit ends
 // or needs a new Jacobian.  Spots that go on are appended to next_list.
-template <bool FROM_MOVIE>
+// FLAG: every decision is also tested against a band around its threshold (the spots of the first pass of the refit mode)
+template <bool FROM_MOVIE, bool FLAG>
 __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(Params p, LqState st, const int32_t *__restrict__ list,
                                                              const unsigned *__restrict__ list_n, int64_t count,
                                                              int32_t *__restrict__ next_list, unsigned *__restrict__ next_n,
@@ -1184,7 +1189,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
     // tie: a decision of this fit fell within LQ_TIE of its threshold — here, in lmpar or in the pivoting of the Jacobian
     // kernel (slot 9).  The group kernel's tree sums differ from MINPACK's sequential ones in the last bits of float64,
     // so such a decision may be MINPACK's other branch: the spot is fitted again with sequential sums (tie_list).
-    unsigned tie = tie_list ? (unsigned)LQI(st, 9, ls) : 0u;       // bit 0: the pivot choice of the Jacobian kernel; 1: lmpar; 2..6 below
+    unsigned tie = FLAG && tie_list ? (unsigned)LQI(st, 9, ls) : 0u;       // bit 0: the pivot choice of the Jacobian kernel; 1: lmpar; 2..6 below
     double gnorm = 0, fnorm1, actred, prered, dirder, ratio, pnorm;
     if (iter == 1) {
 #pragma unroll
@@ -1214,7 +1219,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
         for (int j = 0; j < 6; j++)
             if (wa2[j] > diag[j]) diag[j] = wa2[j];
         for (;;) {
-            lmpar(R, ipvt, diag, qtf, delta, par, wa1, wa2, tie);
+            lmpar<FLAG>(R, ipvt, diag, qtf, delta, par, wa1, wa2, tie);
 #pragma unroll
             for (int j = 0; j < 6; j++) { wa1[j] = -wa1[j]; wa2[j] = x[j] + wa1[j]; wa3[j] = diag[j] * wa1[j]; }
             pnorm = enorm6(wa3);
@@ -1236,7 +1241,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
             dirder = -(temp1 * temp1 + temp2 * temp2);
             ratio = 0;
             if (prered != 0) ratio = actred / prered;
-            {
+            if constexpr (FLAG) {
                 // actred = 1 - (fnorm1 / fnorm)^2 carries an absolute error of a few eps (1 + r^2); ratio divides it by prered
                 const double r1 = fnorm1 / fnorm;
                 const double ea = LQ_TIE * (1.0 + r1 * r1);
@@ -1265,7 +1270,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
                 fnorm = fnorm1;
                 iter++;
             }
-            tie |= !(fabs(delta - xtol * xnorm) > LQ_TIE * delta) ? 64u : 0u;
+            if constexpr (FLAG) tie |= !(fabs(delta - xtol * xnorm) > LQ_TIE * delta) ? 64u : 0u;
             if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1) info = 1;
             if (delta <= xtol * xnorm) info = 2;
             if (fabs(actred) <= ftol && prered <= ftol && 0.5 * ratio <= 1 && info == 2) info = 3;
@@ -1284,7 +1289,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
         if (p.info) p.info[s] = info;
         if (p.nfev) p.nfev[s] = nfev;
         LQI(st, 8, ls) = info;
-        if (tie && tie_list) {
+        if (FLAG && tie && tie_list) {
             tie_list[atomicAdd(tie_n, 1u)] = (int32_t)s;
             for (int b = 0; b < 7; b++)
                 if (tie & (1u << b)) atomicAdd(tie_n + 1 + b, 1u);      // why (diagnostics: pmi_gausslq_last_tie_reasons)
@@ -1294,7 +1299,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
         for (int j = 0; j < 6; j++) { LQD(st, j, ls) = x[j]; LQD(st, 6 + j, ls) = diag[j]; }
         LQD(st, 12, ls) = fnorm; LQD(st, 13, ls) = delta; LQD(st, 14, ls) = par; LQD(st, 15, ls) = xnorm;
         LQI(st, 6, ls) = iter; LQI(st, 7, ls) = nfev; LQI(st, 8, ls) = 0;
-        if (tie && tie_list) LQI(st, 9, ls) = (int32_t)tie;
+        if (FLAG && tie && tie_list) LQI(st, 9, ls) = (int32_t)tie;
         next_list[atomicAdd(next_n, 1u)] = (int32_t)s;
     }
 }
@@ -1358,9 +1363,9 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
 #define LQ_BATCH_LOG2 21      // spots per batch (state: 552 B per spot); every batch ends with one host synchronisation
 #endif
 // How the sums over the residual rows are run (pmi_gausslq_set_mode): PMI_LQ_FAST tree sums only, PMI_LQ_REFIT tree sums
-// and a second fit in MINPACK's order for the spots with a decision near its threshold, PMI_LQ_STRICT every spot in
-// MINPACK's order from the start
-static int g_lq_mode = PMI_LQ_REFIT;
+// and a second fit in MINPACK's order for the spots with a decision near its threshold, PMI_LQ_STRICT (default) every
+// spot in MINPACK's order from the start: theta, info and nfev are lmdif's on every spot, at 1.2x the time of REFIT on 7x7
+static int g_lq_mode = PMI_LQ_STRICT;
 static int lq_mode_now()
 {
     static const char *env = getenv("PMI_LQ_MODE");       // "fast" | "refit" | "strict" overrides pmi_gausslq_set_mode
@@ -1454,8 +1459,12 @@ static int launch(Params p, hipStream_t s)
                     if (pass == 0) launch_jacobian<FROM_MOVIE, false>(p, st, cur, cur_n, bound, cus, s);
                     else launch_jacobian<FROM_MOVIE, true>(p, st, cur, cur_n, bound, cus, s);
                     const unsigned sb = (unsigned)((bound + LQ_STEP_NT - 1) / LQ_STEP_NT);
-                    hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, cur, cur_n, bound, nxt, nxt_n,
-                                       pass == 0 ? tie_list : (int32_t *)nullptr, pass == 0 ? tie_n : (unsigned *)nullptr);
+                    if (pass == 0)
+                        hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE, true>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, cur, cur_n, bound, nxt, nxt_n,
+                                           tie_list, tie_n);
+                    else
+                        hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE, false>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, cur, cur_n, bound, nxt, nxt_n,
+                                           (int32_t *)nullptr, (unsigned *)nullptr);
                     PMI_HIP(hipGetLastError());
                     cur = nxt; cur_n = nxt_n;
                     round++;

@@ -363,7 +363,8 @@ __global__ __launch_bounds__(256) void crlb_kernel(const double *__restrict__ fi
                                                    const int64_t *__restrict__ d_n, float *__restrict__ crlbs,
                                                    const int32_t *__restrict__ list, const unsigned *__restrict__ list_n,
                                                    int32_t *__restrict__ unstable, unsigned *__restrict__ unstable_n,
-                                                   unsigned *__restrict__ reasons, const unsigned char *__restrict__ refit_mark)
+                                                   unsigned *__restrict__ reasons, const unsigned char *__restrict__ refit_mark,
+                                                   const unsigned char *__restrict__ accept)
 {
     int64_t n = N;
     if (d_n) { int64_t dn = *d_n; n = dn < n ? dn : n; }
@@ -374,6 +375,7 @@ __global__ __launch_bounds__(256) void crlb_kernel(const double *__restrict__ fi
         sidx = (int64_t)list[t];
         t = sidx - first;
     } else if (sidx >= n) return;
+    else if (accept && !accept[sidx]) return;            // a candidate identify's exact stage rejected: never fitted
     const double *f = fisher + t * FISHER_STRIDE;
     double M[36];
     {
@@ -480,6 +482,93 @@ bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count
 void launch_fit_strict(const FitParams &p, int method, bool from_movie, const int32_t *list, const unsigned *list_n,
                        int64_t max_items, int cu_count, hipStream_t s);                                                    // gaussmle_strict.hip
 
+// ---- the accepted candidates of a range of spots as an ascending list (deferred exact stage, fit_common.h) --------
+// three small launches: counts per block of ACC_BLOCK spots, one workgroup turns them into offsets (and the total), the
+// blocks write their spots' indices behind their offset
+constexpr int ACC_BLOCK = 1024;
+__global__ __launch_bounds__(256) void accept_count_kernel(const unsigned char *__restrict__ accept, int64_t first, int64_t N,
+                                                           const int64_t *__restrict__ d_n, unsigned *__restrict__ blk_cnt)
+{
+    int64_t n = N;
+    if (d_n) { const int64_t dn = *d_n; n = dn < n ? dn : n; }
+    __shared__ unsigned s_c[4];
+    const int64_t base = first + (int64_t)blockIdx.x * ACC_BLOCK;
+    unsigned c = 0;
+#pragma unroll
+    for (int q = 0; q < ACC_BLOCK / 256; q++) {
+        const int64_t sp = base + q * 256 + threadIdx.x;
+        c += (unsigned)__popcll(__ballot(sp < n && accept[sp] != 0));
+    }
+    if ((threadIdx.x & 63) == 0) s_c[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blk_cnt[blockIdx.x] = s_c[0] + s_c[1] + s_c[2] + s_c[3];
+}
+// counts -> exclusive offsets in place; *total = their sum (+ *carry_in when given: the accepted rows of an earlier range)
+__global__ __launch_bounds__(1024) void accept_scan_kernel(unsigned *__restrict__ blk, int nblk, unsigned *__restrict__ total)
+{
+    __shared__ unsigned s_w[16];
+    __shared__ unsigned s_carry;
+    if (threadIdx.x == 0) s_carry = 0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    for (int b0 = 0; b0 < nblk; b0 += 1024) {
+        const int i = b0 + (int)threadIdx.x;
+        const unsigned v = i < nblk ? blk[i] : 0u;
+        unsigned inc = v;                                   // inclusive scan inside the wave
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) { const unsigned t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        if (lane == 63) s_w[w] = inc;
+        __syncthreads();
+        unsigned before = s_carry;
+        for (int k = 0; k < w; k++) before += s_w[k];
+        if (i < nblk) blk[i] = before + inc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_carry = before + inc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total = s_carry;
+}
+__global__ __launch_bounds__(256) void accept_write_kernel(const unsigned char *__restrict__ accept, int64_t first, int64_t N,
+                                                           const int64_t *__restrict__ d_n, const unsigned *__restrict__ blk_off,
+                                                           int32_t *__restrict__ alist)
+{
+    int64_t n = N;
+    if (d_n) { const int64_t dn = *d_n; n = dn < n ? dn : n; }
+    __shared__ unsigned s_c[ACC_BLOCK / 64];
+    const int64_t base = first + (int64_t)blockIdx.x * ACC_BLOCK;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    unsigned long long bal[ACC_BLOCK / 256];
+#pragma unroll
+    for (int q = 0; q < ACC_BLOCK / 256; q++) {
+        const int64_t sp = base + q * 256 + threadIdx.x;
+        bal[q] = __ballot(sp < n && accept[sp] != 0);
+        if (lane == 0) s_c[q * 4 + w] = (unsigned)__popcll(bal[q]);
+    }
+    __syncthreads();
+    const unsigned off0 = blk_off[blockIdx.x];
+#pragma unroll
+    for (int q = 0; q < ACC_BLOCK / 256; q++) {
+        if ((bal[q] >> lane) & 1ull) {
+            unsigned off = off0;
+            for (int k = 0; k < q * 4 + w; k++) off += s_c[k];
+            off += (unsigned)__popcll(bal[q] & ((1ull << lane) - 1ull));
+            alist[off] = (int32_t)(base + q * 256 + threadIdx.x);
+        }
+    }
+}
+// blk: scratch of ceil(count / ACC_BLOCK) + 1 counters (the last one receives the total); list entries are absolute indices
+static int build_accept_list(const unsigned char *accept, int64_t first, int64_t N, const int64_t *d_n, unsigned *blk,
+                             int32_t *alist, hipStream_t s)
+{
+    const int64_t count = N - first;
+    const int nblk = (int)((count + ACC_BLOCK - 1) / ACC_BLOCK);
+    hipLaunchKernelGGL(accept_count_kernel, dim3((unsigned)nblk), dim3(256), 0, s, accept, first, N, d_n, blk);
+    hipLaunchKernelGGL(accept_scan_kernel, dim3(1), dim3(1024), 0, s, blk, nblk, blk + nblk);
+    hipLaunchKernelGGL(accept_write_kernel, dim3((unsigned)nblk), dim3(256), 0, s, accept, first, N, d_n, (const unsigned *)blk, alist);
+    PMI_HIP(hipGetLastError());
+    return PMI_OK;
+}
+
 // How the Newton loop is run (pmi_mle_set_mode):
 //   PMI_MLE_FAST    float32 loop only (round-1 behaviour; a borderline |delta| < eps decision may fall the other way
 //                   than in the reference's float64 arithmetic)
@@ -537,11 +626,15 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     if ((rc = scratch(SCR_FIT, (size_t)nb * 32 + 64, &ptr)) != PMI_OK) return rc;
     // per spot of a batch: 21 doubles of Fisher triangle + 12 floats of Newton start state + a slot in each of the two lists
     const size_t per_batch = (size_t)std::min<int64_t>(p.N, BATCH);
-    if ((rc = scratch(SCR_STAGE_D, per_batch * (FISHER_STRIDE * sizeof(double) + 12 * sizeof(float) + 2 * sizeof(int32_t) + 1) + 16, &fptr)) != PMI_OK) return rc;
+    // (+ with the deferred exact stage: the list of the accepted candidates of the batch and its block counters)
+    const size_t acc_blocks = (per_batch + ACC_BLOCK - 1) / ACC_BLOCK + 2;
+    if ((rc = scratch(SCR_STAGE_D, per_batch * (FISHER_STRIDE * sizeof(double) + 12 * sizeof(float) + 3 * sizeof(int32_t) + 1) + acc_blocks * sizeof(unsigned) + 32, &fptr)) != PMI_OK) return rc;
     float *state = reinterpret_cast<float *>((char *)fptr + per_batch * FISHER_STRIDE * sizeof(double));
     int32_t *flag_list = reinterpret_cast<int32_t *>(state + per_batch * 12);
     int32_t *unstable_list = flag_list + per_batch;
-    unsigned char *refit_mark = reinterpret_cast<unsigned char *>(unstable_list + per_batch);
+    int32_t *acc_list = unstable_list + per_batch;
+    unsigned *acc_blk = reinterpret_cast<unsigned *>(acc_list + per_batch);
+    unsigned char *refit_mark = reinterpret_cast<unsigned char *>(acc_blk + acc_blocks);
     PMI_HIP(hipMemsetAsync(ptr, 0, (size_t)nb * 32, s));
     unsigned long long *queues = (unsigned long long *)ptr;
     unsigned *flag_counts = (unsigned *)(queues + 3 * nb);           // [0, nb): flagged, [nb, 2 nb): unstable
@@ -573,6 +666,8 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         cut = (float *)cptr;
     }
     p.spots_out = nullptr;
+    // the deferred exact stage lives in g8_init on the path that keeps the cut spots; anywhere else the rows are identifications
+    if (p.ng_io && !(g8 && from_movie && cut)) { set_error("deferred exact stage outside the row-per-lane fit"); return PMI_ERR_ARG; }
     for (int64_t bi = 0; bi < nb; bi++) {
         p.first = bi * BATCH;
         p.N = std::min<int64_t>(Ntotal, p.first + BATCH);
@@ -604,6 +699,12 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
             PMI_HIP(hipGetLastError());
             FitParams q = p;
             q.spots = cut - p.first * (int64_t)(p.box * p.box);      // indexed by the absolute spot number
+            if (p.ng_io) {
+                // g8_init decided the candidates: the Newton loop takes the accepted ones as a list
+                if ((rc = build_accept_list(p.accept, p.first, p.N, p.d_n, acc_blk, acc_list, s)) != PMI_OK) return rc;
+                q.alist = acc_list;
+                q.alist_n = acc_blk + (count + ACC_BLOCK - 1) / ACC_BLOCK;
+            }
             launch_fit_g8(q, method, false, g_cu_count, state, FIT_STAGE_ITERATE_ONLY, s);
             PMI_HIP(hipGetLastError());
             if (mode == PMI_MLE_REFIT)
@@ -629,9 +730,9 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         unsigned *unstable_n = flag_counts + nb + bi;
         auto crlb = [&](const int32_t *list, const unsigned *list_n, int32_t *out, unsigned *out_n) {
             if (method == PMI_MLE_SIGMAXY)
-                hipLaunchKernelGGL((crlb_kernel<6>), dim3(cb), dim3(256), 0, s, p.fisher, p.first, p.N, p.d_n, p.crlbs, list, list_n, out, out_n, p.flag_reasons, p.refit_mark);
+                hipLaunchKernelGGL((crlb_kernel<6>), dim3(cb), dim3(256), 0, s, p.fisher, p.first, p.N, p.d_n, p.crlbs, list, list_n, out, out_n, p.flag_reasons, p.refit_mark, p.accept);
             else
-                hipLaunchKernelGGL((crlb_kernel<5>), dim3(cb), dim3(256), 0, s, p.fisher, p.first, p.N, p.d_n, p.crlbs, list, list_n, out, out_n, p.flag_reasons, p.refit_mark);
+                hipLaunchKernelGGL((crlb_kernel<5>), dim3(cb), dim3(256), 0, s, p.fisher, p.first, p.N, p.d_n, p.crlbs, list, list_n, out, out_n, p.flag_reasons, p.refit_mark, p.accept);
         };
         const bool second = mode == PMI_MLE_REFIT;
         crlb(nullptr, nullptr, second ? unstable_list : nullptr, second ? unstable_n : nullptr);
@@ -706,13 +807,15 @@ __global__ void locs_from_fits_kernel(const int32_t *__restrict__ frame, const i
                                       const int32_t *__restrict__ x, const float *__restrict__ ng,
                                       const float *__restrict__ th, const float *__restrict__ cr,
                                       const float *__restrict__ ll, const int32_t *__restrict__ it, int64_t N,
-                                      const int64_t *__restrict__ d_n, int box, LocCols cols, const int64_t *__restrict__ d_row0)
+                                      const int64_t *__restrict__ d_n, int box, LocCols cols, const int64_t *__restrict__ d_row0,
+                                      const int32_t *__restrict__ list)
 {
     int64_t n = N;
     if (d_n) { int64_t dn = *d_n; n = dn < n ? dn : n; }
-    const int64_t src = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;       // row of the fit arrays
-    if (src >= n) return;
-    const int64_t i = src + (d_row0 ? *d_row0 : 0);                            // row of the table: a second frame range follows the first
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= n) return;
+    const int64_t src = list ? (int64_t)list[r] : r;                          // row of the fit arrays (list: the accepted candidates)
+    const int64_t i = r + (d_row0 ? *d_row0 : 0);                              // row of the table: a second frame range follows the first
     const int off = box / 2;
     const float *t = th + src * 6, *c = cr + src * 6;
     // float32 theta + int64 coordinate -> float64 in pandas, then - offset, then cast
@@ -913,7 +1016,7 @@ int pmi_locs_from_fits_dev(const int32_t *d_frame, const int32_t *d_y, const int
     for (int c = 0; c < PMI_LOC_COLUMNS; c++) cols.c[c] = d_cols[c];
     unsigned blocks = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(locs_from_fits_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_frame, d_y, d_x,
-                       d_ng, d_thetas, d_crlbs, d_loglik, d_iterations, N, d_n, box, cols, (const int64_t *)nullptr);
+                       d_ng, d_thetas, d_crlbs, d_loglik, d_iterations, N, d_n, box, cols, (const int64_t *)nullptr, (const int32_t *)nullptr);
     PMI_HIP(hipGetLastError());
     return PMI_OK;
 }
@@ -924,13 +1027,23 @@ int pmi_locs_from_fits_dev(const int32_t *d_frame, const int32_t *d_y, const int
 // in two: stream s runs scan A, fit A; a side stream of the library runs scan B (started when scan A is done) and
 // fit B, with scratch from the inner bank; the table rows are written once both counts are known (A's rows, then
 // B's), so the capacity contract holds for the sum.
+//
+// Deferred exact stage (default, pmi_localize_set_defer): on uint16 / uint8 / int16 movies and boxes of the row-per-lane fit
+// the packed scan only emits CANDIDATES (window maximum, floor, neighbour rule) and the fit's start-value kernel, which
+// reads a candidate's rows anyway, computes the float32 net gradient in the reference's order, applies the first-argmax
+// rule and the threshold (gaussmle_g8.hip) — the scan no longer re-reads nine lines per candidate and never ends a chunk
+// for a round.  The rejected candidates (one in seven on a DNA-PAINT movie) are skipped by the later stages and the table
+// is compacted; the identification and fit arrays hold capc = cap + cap / 2 + 4096 candidates.  More candidates than
+// that: *d_out_n reports their number (an upper bound of the rows), nothing is fitted, the table is untouched — the same
+// contract as a table that is too small.
 namespace pmi {
 static int g_localize_ranges = 2;
 static bool g_localize_handoff = false;
+static bool g_localize_defer = true;
 struct SideLane { hipStream_t s2 = nullptr; hipEvent_t ev_start = nullptr, ev_scan_a = nullptr, ev_b = nullptr; };
 static thread_local SideLane g_side;
 
-// [0] rows of A to fit, [1] rows of B to fit, [2] rows of A for the table, [3] rows of B for the table, [4] row offset of B
+// rows: [0] rows of A to fit, [1] rows of B to fit, [2] rows of A for the table, [3] rows of B for the table, [4] row offset of B
 __global__ void range_rows_a_kernel(const int64_t *__restrict__ n_a, int64_t cap, int64_t *__restrict__ rows)
 {
     rows[0] = *n_a > cap ? 0 : *n_a;
@@ -946,11 +1059,36 @@ __global__ void range_rows_b_kernel(const int64_t *__restrict__ n_a, const int64
     rows[4] = a;
     *d_out_n = total;
 }
+// deferred exact stage: the candidates of a range that may be fitted (all of them, or none when they overflow capc)
+__global__ void cand_rows_kernel(const int64_t *__restrict__ n_cand, int64_t capc, int64_t *__restrict__ rows_fit)
+{
+    *rows_fit = *n_cand > capc ? 0 : *n_cand;
+}
+// ... and the table rows once the accepted candidates are counted (acc_b == nullptr: one range)
+__global__ void accepted_rows_kernel(const int64_t *__restrict__ cand_a, const unsigned *__restrict__ acc_a,
+                                     const int64_t *__restrict__ cand_b, const unsigned *__restrict__ acc_b, int64_t capc,
+                                     int64_t cap, int64_t *__restrict__ rows, int64_t *__restrict__ d_out_n)
+{
+    const int64_t ca = *cand_a, cb = cand_b ? *cand_b : 0;
+    const bool overflow = ca > capc || cb > capc;
+    const int64_t a = overflow ? 0 : (int64_t)*acc_a, b = (overflow || !acc_b) ? 0 : (int64_t)*acc_b;
+    const bool fits = !overflow && a + b <= cap;
+    rows[2] = fits ? a : 0;
+    rows[3] = fits ? b : 0;
+    rows[4] = a;
+    *d_out_n = overflow ? ca + cb : a + b;
+}
 }  // namespace pmi
 
 int pmi_localize_set_handoff(int on)
 {
     pmi::g_localize_handoff = on != 0;
+    return PMI_OK;
+}
+
+int pmi_localize_set_defer(int on)
+{
+    pmi::g_localize_defer = on != 0;
     return PMI_OK;
 }
 
@@ -968,23 +1106,34 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
 {
     using namespace pmi;
     if (cap <= 0) { set_error("capacity must be positive"); return PMI_ERR_ARG; }
+    if (dtype < 0 || dtype > PMI_F32) { set_error("unknown dtype code %d", dtype); return PMI_ERR_ARG; }
     hipStream_t s = (hipStream_t)stream;
     void *cols[PMI_LOC_COLUMNS];
     for (int c = 0; c < PMI_LOC_COLUMNS; c++) cols[c] = (char *)d_table + (size_t)c * cap * 4;
-    struct Ids { int32_t *f, *y, *x; float *ng, *th, *cr, *ll; int32_t *it, *slot; };
-    auto carve = [&](void *ptr) {
-        Ids d;
-        d.f = (int32_t *)ptr; d.y = d.f + cap; d.x = d.y + cap;
-        d.ng = (float *)(d.x + cap);
-        d.th = d.ng + cap; d.cr = d.th + cap * 6; d.ll = d.cr + cap * 6;
-        d.it = (int32_t *)(d.ll + cap);
-        d.slot = d.it + cap;
-        return d;
-    };
-    const size_t ids_bytes = (size_t)cap * (16 + 15 * 4);
     // pixel hand-off from the scan's exact stage to the fit (uint16 movies, boxes of the row-per-lane fit): room for twice
     // the table's rows (candidates that fail the threshold take a slot too), spread over the eight record shards
     const bool hand = g_localize_handoff && dtype == PMI_U16 && box <= 15 && mle_mode_now() != PMI_MLE_STRICT;
+    // the exact stage of identify in the fit's start-value kernel instead of the scan (see above)
+    const bool defer = g_localize_defer && !hand && box <= 15 && mle_mode_now() != PMI_MLE_STRICT &&
+                       (dtype == PMI_U16 || dtype == PMI_U8 || dtype == PMI_I16) && min_ng > 0.0 && std::isfinite(min_ng);
+    const int64_t capc = defer ? cap + cap / 2 + 4096 : cap;         // rows of the identification / fit arrays
+    int64_t cy0 = 0, cx0 = 0, cy1 = Y, cx1 = X;
+    if (roi4) { cy0 = roi4[0]; cx0 = roi4[1]; cy1 = roi4[2]; cx1 = roi4[3]; }
+    struct Ids { int32_t *f, *y, *x; float *ng, *th, *cr, *ll; int32_t *it, *slot, *tlist; unsigned *blk; unsigned char *acc; };
+    const size_t acc_blocks = (size_t)((capc + ACC_BLOCK - 1) / ACC_BLOCK) + 2;
+    auto carve = [&](void *ptr) {
+        Ids d;
+        d.f = (int32_t *)ptr; d.y = d.f + capc; d.x = d.y + capc;
+        d.ng = (float *)(d.x + capc);
+        d.th = d.ng + capc; d.cr = d.th + capc * 6; d.ll = d.cr + capc * 6;
+        d.it = (int32_t *)(d.ll + capc);
+        d.slot = d.it + capc;
+        d.tlist = d.slot + capc;
+        d.blk = (unsigned *)(d.tlist + capc);
+        d.acc = (unsigned char *)(d.blk + acc_blocks);
+        return d;
+    };
+    const size_t ids_bytes = (size_t)capc * (16 + 16 * 4 + 1) + acc_blocks * sizeof(unsigned) + 16;
     const unsigned pix_cap = (unsigned)std::min<int64_t>(std::max<int64_t>(cap / 4, 4096), 0x0fffffff);
     const size_t pix_bytes = (size_t)8 * pix_cap * (size_t)(box * (box / 2 + 1)) * sizeof(uint32_t);
     auto arm_handoff = [&](int32_t *d_slot) -> int {         // in the scratch bank that is current
@@ -996,24 +1145,64 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
         g_handoff.pix = (uint32_t *)pp; g_handoff.cap_per_shard = pix_cap; g_handoff.d_slot = d_slot;
         return PMI_OK;
     };
+    // identify (candidates when deferred) over frames [lo_, hi_] into d, count at d_cnt
+    auto scan_range = [&](const Ids &d, int64_t lo_, int64_t hi_, int64_t *d_cnt, hipStream_t st) -> int {
+        g_defer_exact = defer;
+        const int r = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, lo_, hi_, 0, d.f, d.y, d.x, d.ng, capc, d_cnt, st);
+        g_defer_exact = false;
+        return r;
+    };
+    // the fit of the rows *d_rows of d (with the exact stage of identify in its start-value kernel when deferred)
+    auto fit_range = [&](const Ids &d, const int64_t *d_rows, hipStream_t st) -> int {
+        FitParams p = {};
+        p.movie = d_movie; p.dtype = dtype; p.Y = Y; p.X = X; p.frame = d.f; p.y = d.y; p.x = d.x;
+        p.baseline = (float)baseline; p.sensitivity = (float)sensitivity; p.gain = (float)gain; p.gdiv = make_const_div((float)gain);
+        p.N = capc; p.d_n = d_rows; p.box = box; p.eps = eps; p.max_it = max_it;
+        p.thetas = d.th; p.crlbs = d.cr; p.loglik = d.ll; p.iterations = d.it;
+        if (g_handoff.used && g_handoff.d_slot && dtype == PMI_U16) { p.pix = g_handoff.pix; p.slot = g_handoff.d_slot; }
+        if (defer) {
+            p.ng_io = d.ng; p.accept = d.acc; p.min_ng = min_ng;
+            p.crop_y0 = (int)cy0; p.crop_x0 = (int)cx0; p.crop_cy = (int)(cy1 - cy0); p.crop_cx = (int)(cx1 - cx0);
+        }
+        int r = fit_impl(p, method, true, st);
+        if (r != PMI_OK || !defer) return r;
+        return build_accept_list(d.acc, 0, capc, d_rows, d.blk, d.tlist, st);       // the table's source rows; total at blk[nblk]
+    };
+    const unsigned *const no_acc = nullptr;
+    const int nblk_c = (int)((capc + ACC_BLOCK - 1) / ACC_BLOCK);
+    LocCols lc;
+    for (int c = 0; c < PMI_LOC_COLUMNS; c++) lc.c[c] = cols[c];
+    const unsigned tblocks = (unsigned)((cap + 255) / 256);
+
     const int64_t lo = f_lo < 0 ? 0 : f_lo, hi = f_hi > F - 1 ? F - 1 : f_hi, nf = hi - lo + 1;
     // two ranges pay when each keeps the chip busy for a while (below ~1e8 pixels a range is a few tens of microseconds)
     const bool two = g_localize_ranges == 2 && !g_kernel_timing && nf >= 16 && (double)nf * (double)Y * (double)X >= 2.5e8;
-    void *ptr = nullptr;
+    void *ptr = nullptr, *cptr = nullptr;
     int rc;
+    if ((rc = scratch(SCR_ROWS, 8 * sizeof(int64_t), &cptr)) != PMI_OK) return rc;
+    int64_t *d_na = (int64_t *)cptr, *d_nb = d_na + 1, *rows = d_na + 2;
     if (!two) {
         if ((rc = scratch(SCR_IDS, ids_bytes, &ptr)) != PMI_OK) return rc;
         const Ids d = carve(ptr);
         if ((rc = arm_handoff(d.slot)) != PMI_OK) return rc;
-        rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, f_lo, f_hi, 0, d.f, d.y, d.x, d.ng, cap, d_out_n, s);
+        int64_t *d_cnt = defer ? d_na : d_out_n;
+        rc = scan_range(d, f_lo, f_hi, d_cnt, s);
         if (rc != PMI_OK) { g_handoff = PixHandoff(); return rc; }
-        const int64_t *d_rows = nullptr;
-        if ((rc = rows_to_fit(d_out_n, cap, &d_rows, s)) != PMI_OK) { g_handoff = PixHandoff(); return rc; }
-        rc = pmi_gaussmle_movie_dev(d_movie, dtype, F, Y, X, d.f, d.y, d.x, cap, d_rows, box, baseline, sensitivity,
-                                    gain, eps, max_it, method, d.th, d.cr, d.ll, d.it, stream);
+        hipLaunchKernelGGL(cand_rows_kernel, dim3(1), dim3(1), 0, s, (const int64_t *)d_cnt, capc, rows + 0);
+        rc = fit_range(d, rows + 0, s);
         g_handoff = PixHandoff();
         if (rc != PMI_OK) return rc;
-        return pmi_locs_from_fits_dev(d.f, d.y, d.x, d.ng, d.th, d.cr, d.ll, d.it, cap, d_rows, box, cols, stream);
+        if (defer) {
+            hipLaunchKernelGGL(accepted_rows_kernel, dim3(1), dim3(1), 0, s, (const int64_t *)d_na, (const unsigned *)(d.blk + nblk_c),
+                               (const int64_t *)nullptr, no_acc, capc, cap, rows, d_out_n);
+            hipLaunchKernelGGL(locs_from_fits_kernel, dim3(tblocks), dim3(256), 0, s, d.f, d.y, d.x, d.ng, d.th, d.cr, d.ll, d.it, cap,
+                               (const int64_t *)(rows + 2), box, lc, (const int64_t *)nullptr, (const int32_t *)d.tlist);
+        } else {
+            hipLaunchKernelGGL(locs_from_fits_kernel, dim3(tblocks), dim3(256), 0, s, d.f, d.y, d.x, d.ng, d.th, d.cr, d.ll, d.it, cap,
+                               (const int64_t *)(rows + 0), box, lc, (const int64_t *)nullptr, (const int32_t *)nullptr);
+        }
+        PMI_HIP(hipGetLastError());
+        return PMI_OK;
     }
     SideLane &side = g_side;
     if (!side.s2) {
@@ -1024,21 +1213,23 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
     }
     const int64_t mid = lo + nf / 2 - 1;                      // A = [lo, mid], B = [mid + 1, hi]
     // counts of the two ranges and the row bookkeeping live in the OUTER bank (both streams read them)
-    void *cptr = nullptr;
-    if ((rc = scratch(SCR_ROWS, 8 * sizeof(int64_t), &cptr)) != PMI_OK) return rc;
-    int64_t *d_na = (int64_t *)cptr, *d_nb = d_na + 1, *rows = d_na + 2;
     if ((rc = scratch(SCR_IDS, ids_bytes, &ptr)) != PMI_OK) return rc;
     const Ids a = carve(ptr);
     PMI_HIP(hipEventRecord(side.ev_start, s));               // the side stream joins the caller's stream order here
     PMI_HIP(hipStreamWaitEvent(side.s2, side.ev_start, 0));
+    // From here on work may be queued on the side stream: whatever happens, the caller's stream is ordered after it
+    // before this call returns (a caller that frees or reuses its buffers on an error must not race kernels on s2).
+    struct Join {
+        SideLane &sd; hipStream_t st; bool done = false;
+        ~Join() { if (!done) { (void)hipEventRecord(sd.ev_b, sd.s2); (void)hipStreamWaitEvent(st, sd.ev_b, 0); } }
+    } join{side, s};
     // ---- range A on the caller's stream
     if ((rc = arm_handoff(a.slot)) != PMI_OK) return rc;
-    rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, lo, mid, 0, a.f, a.y, a.x, a.ng, cap, d_na, s);
+    rc = scan_range(a, lo, mid, d_na, s);
     if (rc != PMI_OK) { g_handoff = PixHandoff(); return rc; }
-    hipLaunchKernelGGL(range_rows_a_kernel, dim3(1), dim3(1), 0, s, (const int64_t *)d_na, cap, rows);
+    hipLaunchKernelGGL(range_rows_a_kernel, dim3(1), dim3(1), 0, s, (const int64_t *)d_na, capc, rows);
     PMI_HIP(hipEventRecord(side.ev_scan_a, s));
-    rc = pmi_gaussmle_movie_dev(d_movie, dtype, F, Y, X, a.f, a.y, a.x, cap, rows + 0, box, baseline, sensitivity,
-                                gain, eps, max_it, method, a.th, a.cr, a.ll, a.it, s);
+    rc = fit_range(a, rows + 0, s);
     g_handoff = PixHandoff();
     if (rc != PMI_OK) return rc;
     // ---- range B on the side stream, scratch from the inner bank; its scan starts when scan A is done
@@ -1050,12 +1241,12 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
         b2 = carve(ptr);
         rc = arm_handoff(b2.slot);
     }
-    if (rc == PMI_OK) rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, mid + 1, hi, 0, b2.f, b2.y, b2.x, b2.ng, cap, d_nb, side.s2);
+    if (rc == PMI_OK) rc = scan_range(b2, mid + 1, hi, d_nb, side.s2);
     if (rc == PMI_OK) {
-        hipLaunchKernelGGL(range_rows_b_kernel, dim3(1), dim3(1), 0, side.s2, (const int64_t *)d_na, (const int64_t *)d_nb, cap, rows, d_out_n);
+        if (defer) hipLaunchKernelGGL(cand_rows_kernel, dim3(1), dim3(1), 0, side.s2, (const int64_t *)d_nb, capc, rows + 1);
+        else hipLaunchKernelGGL(range_rows_b_kernel, dim3(1), dim3(1), 0, side.s2, (const int64_t *)d_na, (const int64_t *)d_nb, cap, rows, d_out_n);
         g_stats_second = true;
-        rc = pmi_gaussmle_movie_dev(d_movie, dtype, F, Y, X, b2.f, b2.y, b2.x, cap, rows + 1, box, baseline, sensitivity,
-                                    gain, eps, max_it, method, b2.th, b2.cr, b2.ll, b2.it, side.s2);
+        rc = fit_range(b2, rows + 1, side.s2);
         g_stats_second = false;
     }
     g_handoff = PixHandoff();
@@ -1063,14 +1254,15 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
     if (rc != PMI_OK) return rc;
     PMI_HIP(hipEventRecord(side.ev_b, side.s2));
     PMI_HIP(hipStreamWaitEvent(s, side.ev_b, 0));
+    join.done = true;
     // ---- the table, once both counts are known: A's rows, then B's
-    LocCols lc;
-    for (int c = 0; c < PMI_LOC_COLUMNS; c++) lc.c[c] = cols[c];
-    const unsigned blocks = (unsigned)((cap + 255) / 256);
-    hipLaunchKernelGGL(locs_from_fits_kernel, dim3(blocks), dim3(256), 0, s, a.f, a.y, a.x, a.ng, a.th, a.cr, a.ll, a.it, cap,
-                       (const int64_t *)(rows + 2), box, lc, (const int64_t *)nullptr);
-    hipLaunchKernelGGL(locs_from_fits_kernel, dim3(blocks), dim3(256), 0, s, b2.f, b2.y, b2.x, b2.ng, b2.th, b2.cr, b2.ll, b2.it, cap,
-                       (const int64_t *)(rows + 3), box, lc, (const int64_t *)(rows + 4));
+    if (defer)
+        hipLaunchKernelGGL(accepted_rows_kernel, dim3(1), dim3(1), 0, s, (const int64_t *)d_na, (const unsigned *)(a.blk + nblk_c),
+                           (const int64_t *)d_nb, (const unsigned *)(b2.blk + nblk_c), capc, cap, rows, d_out_n);
+    hipLaunchKernelGGL(locs_from_fits_kernel, dim3(tblocks), dim3(256), 0, s, a.f, a.y, a.x, a.ng, a.th, a.cr, a.ll, a.it, cap,
+                       (const int64_t *)(rows + 2), box, lc, (const int64_t *)nullptr, (const int32_t *)(defer ? a.tlist : nullptr));
+    hipLaunchKernelGGL(locs_from_fits_kernel, dim3(tblocks), dim3(256), 0, s, b2.f, b2.y, b2.x, b2.ng, b2.th, b2.cr, b2.ll, b2.it, cap,
+                       (const int64_t *)(rows + 3), box, lc, (const int64_t *)(rows + 4), (const int32_t *)(defer ? b2.tlist : nullptr));
     PMI_HIP(hipGetLastError());
     return PMI_OK;
 }

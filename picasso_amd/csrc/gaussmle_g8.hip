@@ -27,6 +27,7 @@
 #include <algorithm>
 
 #include "fit_common.h"
+#include "ng_common.h"
 
 namespace pmi {
 
@@ -150,6 +151,57 @@ __device__ __forceinline__ BTerms boundary_terms(float jf, float mu, float sigma
     return t;
 }
 
+// The same for BOTH axes of a lane at once: component .x = column j (mu = theta_0, sigma = theta_4), .y = row j (theta_1,
+// theta_5 or theta_4).  The two evaluations are independent and made of the same operations, so every multiply, add and
+// FMA of boundary_terms / erf_f32 becomes one packed instruction on a register pair (v_pk_mul_f32, v_pk_add_f32,
+// v_pk_fma_f32) — component by component the same operation order as the scalar form.  Only v_rcp_f32, v_exp_f32, the
+// DPP moves, the sign transfer and the final select stay per component.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+struct BTerms2 { f32x2 E, A, A2, S, S2; };
+__device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f32x2 erf_f32x2(f32x2 a)
+{
+    const f32x2 t = {fabsf(a.x), fabsf(a.y)}, s = a * a;
+    f32x2 r = fma2(splat2(-1.72853470e-5f), t, splat2(3.83197126e-4f));
+    const f32x2 u = fma2(splat2(-3.88396438e-3f), t, splat2(2.42546219e-2f));
+    r = fma2(r, s, u);
+    r = fma2(r, t, splat2(-1.06777877e-1f));
+    r = fma2(r, t, splat2(-6.34846687e-1f));
+    r = fma2(r, t, splat2(-1.28717512e-1f));
+    r = fma2(r, t, -t);
+    const f32x2 ex = {__expf(r.x), __expf(r.y)};
+    const f32x2 one_m = splat2(1.0f) - ex;
+    const f32x2 big = {copysignf(one_m.x, a.x), copysignf(one_m.y, a.y)};
+    f32x2 q = splat2(-5.96761703e-4f);
+    q = fma2(q, s, splat2(4.99119423e-3f));
+    q = fma2(q, s, splat2(-2.67681349e-2f));
+    q = fma2(q, s, splat2(1.12819925e-1f));
+    q = fma2(q, s, splat2(-3.76125336e-1f));
+    q = fma2(q, s, splat2(1.28379166e-1f));
+    const f32x2 small = fma2(q, a, a);
+    return (f32x2){t.x > 0.921875f ? big.x : small.x, t.y > 0.921875f ? big.y : small.y};
+}
+__device__ __forceinline__ BTerms2 boundary_terms2(float jf, f32x2 mu, f32x2 sigma)
+{
+    const f32x2 is = {rcp_f32(sigma.x), rcp_f32(sigma.y)};
+    const f32x2 sn = splat2(0.70710678118654757f) * is, c1 = splat2(0.3989422804014327f) * is, is2 = is * is;
+    const f32x2 u0 = splat2(jf - 0.5f) - mu;
+    const f32x2 e0 = erf_f32x2(u0 * sn);
+    const f32x2 ga = splat2(-0.5f) * u0 * u0 * is2;
+    const f32x2 g0 = {__expf(ga.x), __expf(ga.y)};
+    const f32x2 e1 = {from_next(e0.x), from_next(e0.y)}, g1 = {from_next(g0.x), from_next(g0.y)};
+    const f32x2 u1 = u0 + splat2(1.0f);
+    const f32x2 q1 = u0 * g0 - u1 * g1;
+    const f32x2 q3 = u0 * u0 * u0 * g0 - u1 * u1 * u1 * g1;
+    BTerms2 t;
+    t.E = splat2(0.5f) * (e1 - e0);
+    t.A = (g0 - g1) * c1;
+    t.A2 = q1 * c1 * is2;
+    t.S = q1 * c1 * is;
+    t.S2 = c1 * is2 * (q3 * is2 - splat2(2.0f) * q1);
+    return t;
+}
 
 // ---- pieces shared by the three kernels ------------------------------------
 template <int B, bool FROM_MOVIE>
@@ -207,7 +259,6 @@ __device__ __forceinline__ void load_row(const FitParams &p, int64_t sidx, int j
 // instruction); the group sum goes through LDS so that lane l ends up with num[l], den[l] only
 // and updates ITS parameter (sixteen instructions in parallel instead of six parameters in
 // sequence in every lane), then the six new values are broadcast back through LDS.
-typedef float f32x2 __attribute__((ext_vector_type(2)));
 #ifndef G8_REFILL_K
 #define G8_REFILL_K 2
 #endif
@@ -235,8 +286,12 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
     float *cols = lds, *red = lds + GS * 12, *bc = lds + 2 * GS * 12;
     const float jf = (float)j;
     const float sgy = NP == 6 ? th[5] : th[4];
-    const BTerms tx = boundary_terms(jf, th[0], th[4]);     // column j
-    const BTerms ty = boundary_terms(jf, th[1], sgy);       // row j
+    BTerms tx, ty;                                          // column j, row j
+    {
+        const BTerms2 b = boundary_terms2(jf, (f32x2){th[0], th[1]}, (f32x2){th[4], sgy});
+        tx.E = b.E.x; tx.A = b.A.x; tx.A2 = b.A2.x; tx.S = b.S.x; tx.S2 = b.S2.x;
+        ty.E = b.E.y; ty.A = b.A.y; ty.A2 = b.A2.y; ty.S = b.S.y; ty.S2 = b.S2.y;
+    }
     __builtin_amdgcn_wave_barrier();
     {
         float4 *c = reinterpret_cast<float4 *>(cols + j * 12);
@@ -416,6 +471,43 @@ __device__ __forceinline__ LaneRole make_role(const float (&th)[6], const float 
     return r;
 }
 
+// ---- identify's exact stage, taken over from the packed scan on the fused path (FitParams::ng_io) ----------------
+// unit vectors of picasso/localize.py:279-286 for a lane whose window row is only known at run time
+template <int H> struct UnitTable {
+    static constexpr int B = 2 * H + 1;
+    float ux[B * B], uy[B * B];
+    constexpr UnitTable() : ux(), uy()
+    {
+        for (int k = 0; k < B; k++)
+            for (int l = 0; l < B; l++) { ux[k * B + l] = unit_x<H>(k, l); uy[k * B + l] = unit_y<H>(k, l); }
+    }
+};
+template <int H> __device__ const UnitTable<H> g_unit_table = UnitTable<H>();
+
+// one row of a candidate's neighbourhood as float32 (np.float32(frame), localize.py:332): W - 1 consecutive pixels from
+// row[1] on, and row[c0] for the first column (c0 = 0, or the distance to the crop's last column when column -1 wraps).
+// One switch per row: the loads of a row issue back to back; uint16 rows as one 2-byte load + packed pairs.
+template <int W>
+__device__ __forceinline__ void load_nb_row(const void *movie, int dtype, int64_t o, int c0, float (&nb)[W])
+{
+    switch (dtype) {
+    case PMI_U16: {
+        constexpr int NP = (W - 1) / 2;
+        struct __attribute__((packed, aligned(2))) Pairs { uint32_t v[NP]; };
+        const uint16_t *q = (const uint16_t *)movie + o;
+        const Pairs t = *reinterpret_cast<const Pairs *>(q + 1);
+        nb[0] = (float)q[c0];
+#pragma unroll
+        for (int k = 0; k < NP; k++) { nb[1 + 2 * k] = (float)(t.v[k] & 0xffffu); nb[2 + 2 * k] = (float)(t.v[k] >> 16); }
+    } break;
+    case PMI_U8:  { const uint8_t *q = (const uint8_t *)movie + o;   nb[0] = (float)q[c0]; _Pragma("unroll") for (int c = 1; c < W; c++) nb[c] = (float)q[c]; } break;
+    case PMI_I16: { const int16_t *q = (const int16_t *)movie + o;   nb[0] = (float)q[c0]; _Pragma("unroll") for (int c = 1; c < W; c++) nb[c] = (float)q[c]; } break;
+    case PMI_U32: { const uint32_t *q = (const uint32_t *)movie + o; nb[0] = (float)q[c0]; _Pragma("unroll") for (int c = 1; c < W; c++) nb[c] = (float)q[c]; } break;
+    case PMI_I32: { const int32_t *q = (const int32_t *)movie + o;   nb[0] = (float)q[c0]; _Pragma("unroll") for (int c = 1; c < W; c++) nb[c] = (float)q[c]; } break;
+    default:      { const float *q = (const float *)movie + o;       nb[0] = q[c0]; _Pragma("unroll") for (int c = 1; c < W; c++) nb[c] = q[c]; } break;
+    }
+}
+
 // ---- kernel 1: initial parameters (gaussmle.py:28-168) ----------------------
 template <int NP, int B, bool FROM_MOVIE>
 __global__ __launch_bounds__(FIT_NT) void g8_init_kernel(FitParams p, float *__restrict__ state)
@@ -432,8 +524,91 @@ __global__ __launch_bounds__(FIT_NT) void g8_init_kernel(FitParams p, float *__r
     if (__builtin_amdgcn_readfirstlane((int)(p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW >= n))) return;
 
     float d[B];
-    load_row<B, FROM_MOVIE>(p, sidx, j, spot_ok && rowok, d);
-    if (FROM_MOVIE && p.spots_out && spot_ok && rowok) {
+    bool keep = true;          // (deferred exact stage: the candidate is an identification)
+    bool loaded = false;
+    if constexpr (FROM_MOVIE) {
+        if (p.ng_io) {
+            // The scan left the exact stage of identify to this kernel (pmi_common.h NG_DEFERRED_BITS): the (B+2)^2
+            // neighbourhood instead of the B^2 box — lane j < B reads neighbourhood row j + 1 (its box row with one more
+            // pixel on either side), lane GS - 1 the first row (index -1 of the crop wraps to its last row, as under numba)
+            // and the last row — then, per candidate: the float32 net gradient in the reference's (k, l) order
+            // (picasso/localize.py:233-243: every term by the lane of its row, the sum as ONE chain of float32 additions), the
+            // first-argmax rule of np.argmax (:128) and the threshold (:288).
+            constexpr int W = B + 2;
+            constexpr int TP = (B * B + 3) & ~3, GP = (TP + W * W + 3) & ~3;      // floats of a group: terms, then the neighbourhood
+            __shared__ __attribute__((aligned(16))) float s_nb[FIT_WAVES][NSPW][GP];
+            float *terms = &s_nb[wid][g][0], *nbt = terms + TP;
+            const bool need = spot_ok && __float_as_uint(p.ng_io[sidx]) == NG_DEFERRED_BITS;
+            const bool edge_lane = j == GS - 1;
+            int64_t fr = 0;
+            int yy = 0, xx = 0;
+            if (spot_ok) { fr = p.frame[sidx]; yy = p.y[sidx]; xx = p.x[sidx]; }
+            const int ci = yy - p.crop_y0, cj = xx - p.crop_x0;
+            const int xc0 = cj - H - 1 < 0 ? p.crop_x0 + (cj - H - 1 + p.crop_cx) : xx - H - 1;
+            const int r1 = edge_lane ? (ci - H - 1 < 0 ? p.crop_y0 + (ci - H - 1 + p.crop_cy) : yy - H - 1) : yy - H + j;
+            // this lane's unit vectors (its window row is j): fetched before the pixels, used after them
+            float ux[B], uy[B];
+#pragma unroll
+            for (int l = 0; l < B; l++) { ux[l] = g_unit_table<H>.ux[(rowok ? j : 0) * B + l]; uy[l] = g_unit_table<H>.uy[(rowok ? j : 0) * B + l]; }
+            float nb[W], nb2[W];
+#pragma unroll
+            for (int c = 0; c < W; c++) { nb[c] = 0.f; nb2[c] = 0.f; }
+            const int c0 = xc0 - (xx - H - 1);                     // 0 unless the first column wraps
+            if (spot_ok && (rowok || edge_lane)) load_nb_row<W>(p.movie, p.dtype, (fr * p.Y + r1) * p.X + (xx - H - 1), c0, nb);
+            if (spot_ok && edge_lane) load_nb_row<W>(p.movie, p.dtype, (fr * p.Y + (yy + H + 1)) * p.X + (xx - H - 1), c0, nb2);
+#pragma unroll
+            for (int i = 0; i < B; i++) d[i] = 0.f;
+            if (spot_ok && rowok) {
+#pragma unroll
+                for (int i = 0; i < B; i++) d[i] = (nb[i + 1] - p.baseline) * p.sensitivity;      // localize.py:1112, as load_row
+                div_const_row<B>(d, p.gdiv);
+            }
+            loaded = true;
+            if (__any(need)) {
+                if (rowok) {
+#pragma unroll
+                    for (int c = 0; c < W; c++) nbt[(j + 1) * W + c] = nb[c];
+                }
+                if (edge_lane) {
+#pragma unroll
+                    for (int c = 0; c < W; c++) { nbt[c] = nb[c]; nbt[(W - 1) * W + c] = nb2[c]; }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+                const float vc = nbt[(H + 1) * W + (H + 1)];
+                bool fm = true;
+                if (rowok) {
+#pragma unroll
+                    for (int l = 0; l < B; l++) {
+                        // window pixel (j, l) sits at neighbourhood (j + 1, l + 1)
+                        const float o = nb[l + 1];
+                        const bool before = j < H || (j == H && l < H);
+                        const bool centre = j == H && l == H;
+                        fm = fm && (centre || (before ? vc > o : vc >= o));
+                        const float gy = sub_rn(nbt[(j + 2) * W + l + 1], nbt[j * W + l + 1]);
+                        const float gx = sub_rn(nb[l + 2], nb[l]);
+                        terms[j * B + l] = add_rn(mul_rn(gy, uy[l]), mul_rn(gx, ux[l]));
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                __threadfence_block();
+                float ng = 0.0f;
+#pragma unroll
+                for (int q = 0; q < B * B; q++)
+                    if (q != H * B + H) ng = add_rn(ng, terms[q]);       // the centre is skipped (its unit vector is 0 / 0)
+                const unsigned long long gm = (GS == 64 ? ~0ull : ((1ull << GS) - 1ull)) << (lane & ~(GS - 1));
+                const bool first_max = (__ballot(fm) & gm) == gm;
+                if (need) {
+                    keep = first_max && (double)ng > p.min_ng;
+                    if (j == 0) p.ng_io[sidx] = ng;
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (spot_ok && j == 0) p.accept[sidx] = keep ? 1 : 0;
+        }
+    }
+    if (!loaded) load_row<B, FROM_MOVIE>(p, sidx, j, spot_ok && rowok, d);
+    if (FROM_MOVIE && p.spots_out && spot_ok && rowok && keep) {
         // the Newton loop and the Fisher pass read the spot from here: 2 cache lines per spot instead of B
         float *o = p.spots_out + (sidx - p.first) * (B * B) + j * B;
 #pragma unroll
@@ -533,14 +708,16 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
     const bool rowok = j < B;
     int64_t n = p.N;
     if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
-    // static partition: every wave owns a contiguous chunk of the batch (no queue atomics in the loop)
-    const int64_t count = n - p.first;
+    // static partition: every wave owns a contiguous chunk of the batch (no queue atomics in the loop) — of the list of
+    // accepted candidates when the start-value kernel took identify's exact stage over (FitParams::alist)
+    const int64_t count = p.alist ? (int64_t)*p.alist_n : n - p.first;
     if (count <= 0) return;
     const int64_t total_waves = (int64_t)gridDim.x * FIT_WAVES;
     const int64_t chunk = (count + total_waves - 1) / total_waves;
     const int64_t wv = (int64_t)blockIdx.x * FIT_WAVES + __builtin_amdgcn_readfirstlane(wid);
-    int64_t next = p.first + wv * chunk;
-    const int64_t end = next + chunk < n ? next + chunk : n;
+    const int64_t base = p.alist ? 0 : p.first, lim = base + count;
+    int64_t next = base + wv * chunk;
+    const int64_t end = next + chunk < lim ? next + chunk : lim;
     if (next >= end) return;
 
     float *xs = &s_x[wid][g][0];
@@ -584,7 +761,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
             if (!active) {
                 sidx = -1;
                 if (cand < end) {
-                    sidx = cand;
+                    sidx = p.alist ? (int64_t)p.alist[cand] : cand;
                     const float4 *si = reinterpret_cast<const float4 *>(state + (sidx - p.first) * 12);
                     const float4 s0 = si[0], s1 = si[1], s2 = si[2];
                     th[0] = s0.x; th[1] = s0.y; th[2] = s0.z; th[3] = s0.w; th[4] = s1.x; th[5] = s1.y;
@@ -642,6 +819,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_final_kernel(FitParams p)
         spot_ok = w0 + g < items;
         sidx = spot_ok ? (int64_t)p.final_list[w0 + g] : p.first;
     } else if (__builtin_amdgcn_readfirstlane((int)(p.first + ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW >= n))) return;
+    else if (p.accept) spot_ok = spot_ok && p.accept[sidx] != 0;        // a candidate identify's exact stage rejected (g8_init)
 
     float d[B], th[6];
     load_row<B, FROM_MOVIE>(p, sidx, j, spot_ok && rowok, d);

@@ -359,7 +359,8 @@ static int launch_scan(const void *d_movie, const IdParams &p, const float *d_ta
 int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
                          int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
                          long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled,
-                         const int *gate = nullptr, uint32_t *pix = nullptr, unsigned *pix_cnt = nullptr, unsigned pix_cap = 0);
+                         const int *gate = nullptr, uint32_t *pix = nullptr, unsigned *pix_cnt = nullptr, unsigned pix_cap = 0,
+                         bool defer = false);
 
 // float32 / int32 / uint32 movies that hold 16-bit counts (a camera's counts saved wide): the frames are narrowed to
 // uint16 — exactly, or not at all: any pixel that is not an integer in 0..65535 raises the chunk's flag — and take the
@@ -449,10 +450,11 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
         bool fast = false;
         rc = PMI_OK;
         // register-pipelined packed-u16 scan (identify_fast.hip: uint16, uint8, int16) when the layout allows
-        const bool hand = g_handoff.pix && dtype == PMI_U16;
+        // (a fused call may leave the exact stage to its fit's start-value kernel: g_defer_exact, pmi_common.h)
+        const bool hand = g_handoff.pix && dtype == PMI_U16 && !g_defer_exact;
         rc = launch_scan_u16_fast(d_movie, dtype, Y, X, p.y0, p.x0, p.cy, p.cx, f_lo, label_offset, p.nframes, box, min_ng,
                                       d_tab, recs, cap, d_total, count, s, &fast, nullptr, hand ? g_handoff.pix : nullptr,
-                                      hand ? pix_cnt : nullptr, hand ? g_handoff.cap_per_shard : 0u);
+                                      hand ? pix_cnt : nullptr, hand ? g_handoff.cap_per_shard : 0u, g_defer_exact);
         g_handoff.used = hand && fast;
         p.gate = nullptr;
         const bool wide = dtype == PMI_U32 || dtype == PMI_I32 || dtype == PMI_F32;

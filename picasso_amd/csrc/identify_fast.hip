@@ -28,49 +28,12 @@
 #include <cstdlib>
 #include <vector>
 
+#include "ng_common.h"
 #include "pmi_common.h"
 
 #pragma clang fp contract(off)
 
 namespace pmi {
-
-// float32 ops that must round exactly like the reference's unfused arithmetic.  They are
-// defined HERE, under the pragma above, so the instructions carry no `contract` flag
-// (the __f*_rn helpers of the HIP headers are compiled with contraction allowed).
-static __device__ __forceinline__ float mul_rn(float a, float b) { return a * b; }
-static __device__ __forceinline__ float add_rn(float a, float b) { return a + b; }
-static __device__ __forceinline__ float sub_rn(float a, float b) { return a - b; }
-
-// float32 sqrt of 0..128 (the squared lengths that occur for box <= 17), correctly rounded; the host
-// checks them against sqrtf before the first launch (unit_vectors_match).
-constexpr float SQRT_F32[129] = {
-    0x0.0p+0f, 0x1.0p+0f, 0x1.6a09e6p+0f, 0x1.bb67aep+0f, 0x1.0p+1f, 0x1.1e377ap+1f, 0x1.3988e2p+1f,
-    0x1.52a7fap+1f, 0x1.6a09e6p+1f, 0x1.8p+1f, 0x1.94c584p+1f, 0x1.a8872ap+1f, 0x1.bb67aep+1f, 0x1.cd82b4p+1f,
-    0x1.deeea2p+1f, 0x1.efbdecp+1f, 0x1.0p+2f, 0x1.07e0f6p+2f, 0x1.0f876cp+2f, 0x1.16f834p+2f, 0x1.1e377ap+2f,
-    0x1.2548ecp+2f, 0x1.2c2fc6p+2f, 0x1.32eee8p+2f, 0x1.3988e2p+2f, 0x1.4p+2f, 0x1.465656p+2f, 0x1.4c8dc2p+2f,
-    0x1.52a7fap+2f, 0x1.58a68ap+2f, 0x1.5e8adep+2f, 0x1.64564p+2f, 0x1.6a09e6p+2f, 0x1.6fa6eap+2f, 0x1.752e5p+2f,
-    0x1.7aa10ep+2f, 0x1.8p+2f, 0x1.854bfcp+2f, 0x1.8a85c2p+2f, 0x1.8fae0cp+2f, 0x1.94c584p+2f, 0x1.99cccap+2f,
-    0x1.9ec474p+2f, 0x1.a3ad12p+2f, 0x1.a8872ap+2f, 0x1.ad5336p+2f, 0x1.b211b2p+2f, 0x1.b6c30cp+2f, 0x1.bb67aep+2f,
-    0x1.cp+2f, 0x1.c48c6p+2f, 0x1.c90d2ap+2f, 0x1.cd82b4p+2f, 0x1.d1ed52p+2f, 0x1.d64d52p+2f, 0x1.daa2fep+2f,
-    0x1.deeea2p+2f, 0x1.e3307cp+2f, 0x1.e768d4p+2f, 0x1.eb97e4p+2f, 0x1.efbdecp+2f, 0x1.f3db22p+2f, 0x1.f7efbep+2f,
-    0x1.fbfbf8p+2f, 0x1.0p+3f, 0x1.01fe04p+3f, 0x1.03f82p+3f, 0x1.05ee68p+3f, 0x1.07e0f6p+3f, 0x1.09cfdcp+3f,
-    0x1.0bbb3p+3f, 0x1.0da304p+3f, 0x1.0f876cp+3f, 0x1.11687ap+3f, 0x1.13464p+3f, 0x1.1520cep+3f, 0x1.16f834p+3f,
-    0x1.18cc82p+3f, 0x1.1a9dc8p+3f, 0x1.1c6c16p+3f, 0x1.1e377ap+3f, 0x1.2p+3f, 0x1.21c5b8p+3f, 0x1.2388acp+3f,
-    0x1.2548ecp+3f, 0x1.270682p+3f, 0x1.28c17cp+3f, 0x1.2a79e4p+3f, 0x1.2c2fc6p+3f, 0x1.2de32cp+3f, 0x1.2f9422p+3f,
-    0x1.3142b4p+3f, 0x1.32eee8p+3f, 0x1.3498cap+3f, 0x1.364064p+3f, 0x1.37e5bep+3f, 0x1.3988e2p+3f, 0x1.3b29d8p+3f,
-    0x1.3cc8aap+3f, 0x1.3e655ep+3f, 0x1.4p+3f, 0x1.419894p+3f, 0x1.432f24p+3f, 0x1.44c3b8p+3f, 0x1.465656p+3f,
-    0x1.47e706p+3f, 0x1.4975cep+3f, 0x1.4b02b4p+3f, 0x1.4c8dc2p+3f, 0x1.4e16fep+3f, 0x1.4f9e6cp+3f, 0x1.512414p+3f,
-    0x1.52a7fap+3f, 0x1.542a28p+3f, 0x1.55aaap+3f, 0x1.57296ap+3f, 0x1.58a68ap+3f, 0x1.5a2208p+3f, 0x1.5b9be6p+3f,
-    0x1.5d142cp+3f, 0x1.5e8adep+3f, 0x1.6p+3f, 0x1.617398p+3f, 0x1.62e5acp+3f, 0x1.64564p+3f, 0x1.65c558p+3f,
-    0x1.6732f8p+3f, 0x1.689f26p+3f, 0x1.6a09e6p+3f};
-// unit vectors of picasso/localize.py:279-286 as compile-time float32 constants:
-// ux[k][l] = (H - l) / |(H - l, H - k)|, uy[k][l] = (H - k) / |...|  (float32 sqrt and divide)
-template <int H> constexpr float unit_x(int k, int l)
-{
-    const int vx = H - l, vy = H - k;
-    return (vx == 0 && vy == 0) ? 0.0f : (float)vx / SQRT_F32[vx * vx + vy * vy];
-}
-template <int H> constexpr float unit_y(int k, int l) { return unit_x<H>(l, k); }
 
 typedef unsigned short u16x2_t __attribute__((ext_vector_type(2)));
 typedef unsigned int u32;
@@ -141,6 +104,7 @@ struct FastParams {
     u32 *pix;
     unsigned *pix_cnt;
     unsigned pix_cap;
+    int defer;                 // 1: a wave whose exact rounds accept most of its candidates may emit the rest undecided (net gradient NG_DEFERRED_BITS, pmi_common.h)
     const int *gate;           // optional device flag: the launch does nothing unless it is 0 (32-bit movies narrowed to uint16, identify.hip)
     int dbg;                   // PMI_IDENTIFY_DBG: 1 = skip the exact net gradient, 2 = skip the record append, 4 = no floor filter (timing only)
 };
@@ -466,6 +430,14 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
     bool redo = false;
     constexpr int ROUND = fast_round(H);
     int trigger = filter ? 8 + (ROUND / 8) * (int)(blockIdx.x % 7u) : THRESH;
+    // Deferred exact stage (p.defer): the wave starts with exact rounds like any other and counts how many of its candidates
+    // they accept; once three in four of at least 32 were accepted it emits its candidates undecided (net gradient
+    // NG_DEFERRED_BITS: the fit's start-value kernel decides them from the rows it reads anyway) — a round then only copies
+    // ring entries to the records, nothing has to stay near, and the ring is drained when nearly full.  Where the floor
+    // lets many shot-noise maxima through (a low threshold for the box) the waves keep deciding them here, one lane per
+    // candidate, instead of sending the fit a group of lanes for every reject.
+    int ex_seen = 0, ex_kept = 0;
+    bool defer_now = false;
 
     // ---- results: buffered in registers, appended KBUF rounds at a time with ONE slot-allocating atomic per flush
     // per wave on the counter of this block's shard (a single hot counter costs ~11 ns per atomic)
@@ -567,6 +539,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
             if (lane == 0) pixbase = atomicAdd(&p.pix_cnt[shard], (unsigned)n);
             pixbase = (unsigned)__builtin_amdgcn_readfirstlane((int)pixbase);
         }
+        bool kept = false;
         if (lane < n) {
             const int q = (head + lane) & (LIST - 1);
             const unsigned e = s_pos[q];
@@ -579,12 +552,22 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                 slot = (int)((unsigned)shard * p.pix_cap + pixbase + (unsigned)lane);
                 pixdst = p.pix + (size_t)slot * (size_t)(BOX * (H + 1));
             }
-            if (p.dbg & 1) append(fi, i, j, (e & 7) == 0 ? 1e9f : 0.0f, -1);
+            if (defer_now) {
+#pragma unroll
+                for (int k = 0; k < KBUF; k++) if (k == nbuf) { buf_f[k] = fi; buf_i[k] = i; buf_j[k] = j; buf_ng[k] = __uint_as_float(NG_DEFERRED_BITS); buf_s[k] = -1; }
+                nbuf++;
+            } else if (p.dbg & 1) append(fi, i, j, (e & 7) == 0 ? 1e9f : 0.0f, -1);
             else {
                 bool first_max;
                 const float ng = exact_ng<H, PT>(src, p.X, p.cy, p.cx, i, j, first_max, pixdst);
                 if (first_max) append(fi, i, j, ng, slot);
+                kept = first_max && (double)ng > p.min_ng;
             }
+        }
+        if (p.defer && !defer_now) {
+            ex_seen += n;
+            ex_kept += (int)__popcll(__ballot(kept));
+            defer_now = ex_seen >= 32 && ex_kept * 4 >= ex_seen * 3;
         }
         head += n;
         if (++rounds == KBUF) flush();
@@ -999,7 +982,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                     // A threshold so low that most maxima pass the floor (two and more candidates per row): ending the
                     // chunk every ROUND candidates would replay the 2H + 2 halo rows every dozen rows — the ring
                     // is then drained only when nearly full, as without a floor.
-                    trigger = (dn > 0 && added >= 2 * dn) ? THRESH : ROUND;
+                    trigger = ((dn > 0 && added >= 2 * dn) || defer_now) ? THRESH : ROUND;
                 }
             }
             o += dn;
@@ -1061,7 +1044,7 @@ static int g_fast_cus = 0;
 int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
                          int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
                          long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled,
-                         const int *gate, uint32_t *pix, unsigned *pix_cnt, unsigned pix_cap)
+                         const int *gate, uint32_t *pix, unsigned *pix_cnt, unsigned pix_cap, bool defer)
 {
     *handled = false;
     static const bool force_generic = tuning_env("PMI_IDENTIFY_GENERIC") != nullptr;
@@ -1094,6 +1077,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     p.movie = d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;
     p.f_lo = f_lo; p.label_off = label_off; p.nframes = nframes; p.box = box; p.min_ng = min_ng; p.gate = gate;
     p.pix = pix; p.pix_cnt = pix_cnt; p.pix_cap = pix_cap;
+    p.defer = defer ? 1 : 0;
     p.segs = pack > 1 ? 1 : (nch + 63) / 64;
     // Rows per unit: long units amortise the 2H + 2 pipeline rows a unit spends on its halo, short ones balance the
     // persistent waves (every wave runs ceil(units / waves) units).  Pick the length with the least total work.

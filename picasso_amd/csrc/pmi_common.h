@@ -65,6 +65,13 @@ struct Record {   // one identification, 16 B
     float ng;
 };
 __host__ __device__ __forceinline__ uint32_t pack_yx(int y, int x) { return ((uint32_t)y << 16) | (uint32_t)(x & 0xffff); }
+// A fused pipeline may ask the packed scan to leave the exact stage (float32 net gradient in the reference's order,
+// first-argmax rule: picasso/localize.py:97-134, 202-244, 288) to the fit's start-value kernel, which reads the very
+// rows it needs: the scan then emits CANDIDATES whose net gradient is this NaN pattern (an accepted identification's
+// net gradient is never NaN: it passed `ng > min_ng`), and the start-value kernel decides them (gaussmle_g8.hip).
+constexpr uint32_t NG_DEFERRED_BITS = 0x7fc0d1feu;
+// set (per thread) by a fused call around identify_impl: the packed scan may defer its exact stage
+extern thread_local bool g_defer_exact;
 
 // pixel load as float32 (the reference's np.float32(frame), localize.py:332)
 template <typename T>

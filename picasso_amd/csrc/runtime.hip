@@ -11,6 +11,7 @@ static thread_local char g_err[512] = "";
 bool g_kernel_timing = false;
 KernelTimes g_last_times = {0.f, 0.f};
 thread_local PixHandoff g_handoff;
+thread_local bool g_defer_exact = false;
 
 void set_error(const char *fmt, ...)
 {
@@ -95,7 +96,7 @@ void release_fft_plans();   // xcorr.hip
 
 extern "C" {
 
-int pmi_version(void) { return 102; }   // 0.1.2: round 3 (flag reasons, gausslq re-fit counters, localize schedule knobs, pmi_comm_available, pmi_fft_prewarm)
+int pmi_version(void) { return 103; }   // 0.1.3: round 4 (pmi_gausslq_set_mode, pmi_localize_set_defer, pmi_get_device)
 
 const char *pmi_last_error(void) { return pmi::g_err; }
 
@@ -109,6 +110,14 @@ int pmi_device_count(void)
 int pmi_set_device(int device)
 {
     PMI_HIP(hipSetDevice(device));
+    return PMI_OK;
+}
+
+int pmi_get_device(int *device)
+{
+    int dev = 0;
+    PMI_HIP(hipGetDevice(&dev));
+    if (device) *device = dev;
     return PMI_OK;
 }
 

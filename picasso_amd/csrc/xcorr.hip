@@ -14,6 +14,7 @@
 #include <algorithm>
 #include <cmath>
 #include <map>
+#include <tuple>
 #include <mutex>
 #include <utility>
 #include <vector>
@@ -28,13 +29,15 @@ int rcc_fit_peaks(const double *d_rois, const int32_t *h_peaks3, int64_t n_pairs
 namespace xc {
 
 struct Plans { hipfftHandle fwd, inv; };
-static std::map<std::pair<int64_t, int64_t>, Plans> g_plans;
+static std::map<std::tuple<int, int64_t, int64_t>, Plans> g_plans;      // a plan belongs to the device it was made on
 static std::mutex g_plans_mu;        // pmi_fft_prewarm makes plans from a side thread of the host
 
 static int get_plans(int64_t Y, int64_t X, Plans *out)
 {
     std::lock_guard<std::mutex> lk(g_plans_mu);
-    auto key = std::make_pair(Y, X);
+    int dev = 0;
+    PMI_HIP(hipGetDevice(&dev));
+    auto key = std::make_tuple(dev, Y, X);
     auto it = g_plans.find(key);
     if (it == g_plans.end()) {
         Plans p;

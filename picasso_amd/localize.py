@@ -555,9 +555,6 @@ def localize_streamed(movie, camera_info: dict, parameters: dict, *, roi=None, f
     if hi >= lo:
         from concurrent.futures import ThreadPoolExecutor
         first = np.asarray(movie[lo])
-        # `picasso localize --drift` undrifts right after this: its FFT plans (seconds of kernel compilation inside
-        # rocFFT for large frames) are made on a side thread meanwhile
-        backend.prewarm_fft(first.shape[0], first.shape[1])
         per = max(1, int(chunk_bytes) // max(first.nbytes, 1))
         # Two staging allocations.  This thread uploads chunk i + 1 (a blocking default-stream copy; ctypes
         # releases the GIL) while a worker thread runs chunk i on a non-blocking stream of its own — kernels,
@@ -628,6 +625,10 @@ def localize_file(path: str, camera_info: dict, parameters: dict, *, fitting_met
 
     from . import io, postprocess
     movie, info = io.load_movie(path)
+    if drift and drift > 0 and len(movie):
+        # the undrift below needs FFT plans for this frame size — seconds of kernel compilation inside rocFFT for large
+        # frames: made on a side thread while the movie is localized (joined before the correlations, backend.py)
+        backend.prewarm_fft(int(movie.shape[1]), int(movie.shape[2]))
     # the metadata the CLI saves: movie info + identify info + fit info (picasso/__main__.py:1086-1100, localize.py:1810)
     locs, info = localize(movie, camera_info, parameters, roi=roi, frame_bounds=frame_bounds, movie_info=info,
                           fitting_method=fitting_method, eps=eps, max_it=max_it, mle_method=mle_method, return_info=True)

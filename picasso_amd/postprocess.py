@@ -10,7 +10,7 @@ import numpy as np
 import pandas as pd
 from scipy.interpolate import InterpolatedUnivariateSpline
 
-from . import imageprocess, lib, render
+from . import backend, imageprocess, lib, render
 
 _SEGMENT_RENDER = {"blur_method": "gaussian", "min_blur_width": 1}      # what undrift renders its segments with
 
@@ -91,6 +91,7 @@ def undrift(locs: pd.DataFrame, info, segmentation: int, display: bool = True, s
     with warnings.catch_warnings():
         warnings.simplefilter("ignore", DeprecationWarning)       # render()'s oversampling notice, as in the reference call
         bounds, stack = segment(locs, info, segmentation, dict(_SEGMENT_RENDER), segmentation_callback)
+    backend.join_fft_prewarm()            # plans started by localize_file on a side thread: ready (or made) before they are used
     shift_y, shift_x = imageprocess.rcc(stack, 32, rcc_callback)
     n_frames = info[0]["Frames"]
     drift = pd.DataFrame({"x": _spline_over_frames(bounds, shift_x, n_frames),

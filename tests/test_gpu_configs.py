@@ -295,9 +295,67 @@ def test_fused_call_keeps_two_frame_ranges_in_flight():
             assert npl == nh and torch.equal(plain[:, :npl], h[:, :nh])
         finally:
             _lib.check(L.pmi_localize_set_handoff(0), "pmi_localize_set_handoff")
-        # capacity between the first half's count and the total: nothing may be written
+        # capacity between the first half's count and the total: nothing may be written; the count reported is the rows
+        # needed — or, when even the candidates of the deferred exact stage overflow their scratch, their number (an upper bound)
+        small, n_small, _ = run(2, 0, F - 1, None, int(n_full * 0.75), fill=0x5A5A5A5A)
+        assert n_full <= n_small < 1.5 * n_full and bool((small == 0x5A5A5A5A).all())
+        _lib.check(L.pmi_localize_set_defer(0), "pmi_localize_set_defer")
         small, n_small, _ = run(2, 0, F - 1, None, int(n_full * 0.75), fill=0x5A5A5A5A)
         assert n_small == n_full and bool((small == 0x5A5A5A5A).all())
         assert L.pmi_localize_set_ranges(3) != 0
     finally:
         _lib.check(L.pmi_localize_set_ranges(2), "pmi_localize_set_ranges")
+        _lib.check(L.pmi_localize_set_defer(1), "pmi_localize_set_defer")
+
+
+@pytest.mark.parametrize("case", ["u16_box7", "u16_box5_roi", "u16_box9", "u16_box13", "u8_box7", "i16_box7_roi", "low_threshold", "tight_cap"])
+def test_fused_call_with_the_exact_stage_of_identify_in_the_fit(case):
+    """pmi_localize_set_defer: the packed scan emits candidates and the fit's start-value kernel evaluates the float32 net
+    gradient in the reference's order, the first-argmax rule and the threshold from the rows it reads anyway
+    (picasso/localize.py:97-134, 202-244, 288).  The table is the one of the scan's own exact stage, bit for bit: boxes
+    of both group sizes, an ROI that starts off an 8-pixel boundary (maxima in the crop's row / column H: their stencils wrap
+    to its last row / column), uint8 and int16 movies, a threshold so low that the waves keep deciding their candidates
+    themselves, and a capacity with no room for rejected candidates."""
+    import torch
+    from picasso_amd import _lib, backend, synth
+    L = _lib.load()
+    F = 1000                                    # 2.6e8 pixels: the two-range schedule applies
+    movie = synth.simulate_movie(F, 512, 512, emitters_per_frame=70, seed=31, device="cuda")
+    counts = movie.view(torch.int16).to(torch.int32) & 0xffff
+    box, roi, min_ng, baseline = 7, None, 5000.0, 100.0
+    if case == "u16_box5_roi": box, roi = 5, (10, 10, 499, 503)            # emitters from pixel 12 on: maxima in the crop's row / column 2
+    elif case == "u16_box9": box = 9
+    elif case == "u16_box13": box = 13                  # (a threshold that lets many shot-noise maxima through: most waves keep deciding)
+    elif case == "u8_box7": movie, min_ng, baseline = (counts // 8).clamp(max=255).to(torch.uint8), 600.0, 12.0
+    elif case == "i16_box7_roi": movie, roi, baseline = (counts - 700).to(torch.int16), (9, 9, 508, 470), -600.0
+    elif case == "low_threshold": min_ng = 300.0
+    del counts
+    torch.cuda.synchronize()
+    code = backend.dtype_code({torch.uint16: np.uint16, torch.uint8: np.uint8, torch.int16: np.int16}[movie.dtype])
+
+    def run(defer, ranges, cap_):
+        _lib.check(L.pmi_localize_set_defer(defer), "pmi_localize_set_defer")
+        _lib.check(L.pmi_localize_set_ranges(ranges), "pmi_localize_set_ranges")
+        table = torch.zeros((_lib.PMI_LOC_COLUMNS, cap_), dtype=torch.int32, device="cuda")
+        d_n = torch.zeros(1, dtype=torch.int64, device="cuda")
+        r = (ctypes.c_int64 * 4)(*roi) if roi else None
+        rc = L.pmi_localize_mle_dev(ctypes.c_void_p(movie.data_ptr()), code, F, 512, 512, box, min_ng, r, 0, F - 1, baseline, 1.0, 1.0,
+                                    1e-3, 100, _lib.MLE_METHODS["sigmaxy"], ctypes.c_void_p(table.data_ptr()), cap_,
+                                    ctypes.c_void_p(d_n.data_ptr()), None)
+        _lib.check(rc, "pmi_localize_mle_dev")
+        torch.cuda.synchronize()
+        return table, int(d_n.item())
+
+    try:
+        cap = 400 * F if case == "low_threshold" else 160 * F
+        ref, n_ref = run(0, 1, cap)
+        assert n_ref > 5000, n_ref
+        if case == "tight_cap":
+            cap = n_ref                      # exactly the rows: the candidates live in the library's scratch
+        for ranges in (1, 2):
+            got, n_got = run(1, ranges, cap)
+            assert n_got == n_ref, (case, ranges, n_got, n_ref)
+            assert torch.equal(got[:, :n_got], ref[:, :n_ref]), (case, ranges)
+    finally:
+        _lib.check(L.pmi_localize_set_ranges(2), "pmi_localize_set_ranges")
+        _lib.check(L.pmi_localize_set_defer(1), "pmi_localize_set_defer")

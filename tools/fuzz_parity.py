@@ -134,6 +134,13 @@ while time.time() < t_end:
             md = np.max(np.abs(th[fin][:, [0, 1, 4, 5]] - oth[fin][:, [0, 1, 4, 5]])) if fin.any() else 0
             counts["lq_spots"] = counts.get("lq_spots", 0) + n
             counts["lq_not_identical"] = counts.get("lq_not_identical", 0) + int((~exact).sum())
+            dd = np.where(fin, np.abs(th[:, [0, 1, 4, 5]] - oth[:, [0, 1, 4, 5]]).max(axis=1), 0)
+            counts["lq_beyond_1e-3"] = counts.get("lq_beyond_1e-3", 0) + int((dd > 1e-3).sum())
+            if (~exact).any():          # keep the inputs: regression cases (tests/golden/lq_fuzz_regressions)
+                rows = np.flatnonzero(~exact)
+                __import__("os").makedirs("gpurun_out/fuzz_fail", exist_ok=True)
+                np.savez_compressed(f"gpurun_out/fuzz_fail/lq_{seed}_{counts['lq']}.npz", spots=spots[rows], box=box, theta_gpu=th[rows],
+                                    theta_orc=oth[rows], info_gpu=info[rows], info_orc=oinfo[rows], worst_px=float(dd[rows].max()))
             # every spot inside the tolerance, MINPACK's verdict (info) on every spot; bit-identity is counted over the run
             if md > 1e-3 or (info != oinfo).any():
                 fails += 1

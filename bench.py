@@ -46,6 +46,8 @@ def parse():
     ap.add_argument("--method", default="sigmaxy")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra instrumented steps for per-kernel time")
+    ap.add_argument("--strict-steps", type=int, default=2,
+                    help="extra steps with every spot in the reference's arithmetic (value_strict; 0 = skip)")
     ap.add_argument("--ranges", type=int, default=2, choices=(1, 2),
                     help="frame ranges pmi_localize_mle_dev keeps in flight in the timed steps (2 = the library's default "
                          "schedule: the scan of the second half beside the fit of the first; 1 = one range, as the profiled passes)")
@@ -293,11 +295,32 @@ def main():
         _lib.check(L.pmi_localize_set_ranges(args.ranges), "pmi_localize_set_ranges")
         scan_ms, fit_ms = float(np.mean(s_acc)), float(np.mean(f_acc))
 
+    # the refit count of the timed configuration, then — beside `value` — the same step with EVERY spot fitted in the
+    # reference's arithmetic (float64 intermediates, float32 stores, its summation order: pmi_mle_set_mode strict)
+    mle_mode, mle_margin = backend.get_mle_mode()
+    refit = backend.last_refit_count(stream)
+    scan_kernel = last_scan_kernel(L)
+    strict_ms = None
+    if args.strict_steps > 0 and mle_mode != "strict":
+        backend.set_mle_mode("strict", mle_margin)
+        try:
+            run(table, d_n, cap)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.strict_steps):
+                run(table, d_n, cap)
+            torch.cuda.synchronize()
+            strict_ms = 1e3 * (time.perf_counter() - t1) / args.strict_steps
+        finally:
+            backend.set_mle_mode(mle_mode, mle_margin)
+        if grouped:
+            st = torch.tensor([strict_ms], dtype=torch.float64, device=dev)
+            dist.all_reduce(st, op=dist.ReduceOp.MAX)
+            strict_ms = float(st.item())
+
     result = None
     if rank == 0:
         n_rank0 = int(d_n.item())
-        mle_mode, mle_margin = backend.get_mle_mode()
-        refit = backend.last_refit_count(stream)
         kernels = {
             "identify_scan": {"ms": scan_ms, "algorithmic_bytes": movie_bytes,
                               "GB/s": movie_bytes / (scan_ms * 1e-3) / 1e9 if scan_ms == scan_ms else None},
@@ -309,13 +332,14 @@ def main():
         # 5.24 kB per localization; the fit moves 166 B and is FP32-ALU bound, listed beside it).
         dom = "identify_scan"
         ach = kernels[dom]["GB/s"]
-        traffic, traffic_source = pmc_traffic_bytes(F, H, W, box)
+        traffic, traffic_source = pmc_traffic_bytes(F, H, W, box, scan_kernel)
         roofline = {"bound": "hbm", "kernel": dom, "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                     "frac": (ach / HBM_PEAK_GBS) if ach else None,
                     "traffic": traffic, "traffic_source": traffic_source,
                     "measured_on": f"{args.profile_steps} single-range passes over the whole movie after the timed steps (HIP events "
                                    "around the kernels on their launch stream, inside the library); the same launches as "
-                                   "`bench.py --ranges 1`, profiles/r03_bench_ranges1_kernel_stats.txt",
+                                   "`bench.py --ranges 1`, profiles/r04_bench_ranges1_kernel_stats.txt",
+                    "scan_kernel": scan_kernel,
                     "kernels": kernels}
         kernels["mle_fit"]["bound"] = "fp32 valu (no MFMA shape); algorithmic bytes are 166 B/spot"
         cpu = None
@@ -326,6 +350,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None,
+            # every spot in the reference's arithmetic (pmi_mle_set_mode strict), the same step, after the timed ones (no all-gather)
+            "ms_per_step_strict": strict_ms,
+            "value_strict": (n_total / (strict_ms * 1e-3)) if strict_ms else None,
+            "refit_fraction": (refit / n_rank0) if n_rank0 else None,
             # float32 Newton loop; spots whose convergence test falls within rounding distance of eps are fitted again
             # with the reference's float64 intermediates INSIDE the timed step (csrc/gaussmle_strict.hip)
             "dtype": {"fast": "f32", "refit": "f32+f64", "strict": "f64"}[mle_mode], "data": "synthetic",
@@ -354,25 +382,36 @@ def main():
     return result
 
 
-PMC_TRAFFIC_FILE = "profiles/r03_identify_pmc.json"
+PMC_TRAFFIC_FILE = "profiles/r04_identify_pmc.json"
 
 
-def pmc_traffic_bytes(F, H, W, box):
+def last_scan_kernel(L):
+    buf = ctypes.create_string_buffer(128)
+    L.pmi_last_scan_kernel(buf, 128)
+    return buf.value.decode()
+
+
+def pmc_traffic_bytes(F, H, W, box, scan_kernel):
     """HBM-side bytes per launch of the scan kernel from the committed rocprofv3 PMC run of THIS kernel on THIS
     workload (TCC_EA0_RDREQ x 128 B = 2 x FETCH_SIZE x 1024, the gfx950 correction of MI355X_MICROARCH.md, plus
     WRITE_SIZE), and where the number comes from; (None, None) for any other workload.  Counters cannot be read
-    inside an un-profiled run: the figure is a measurement of the committed profile, labelled as such."""
+    inside an un-profiled run: the figure is a measurement of the committed profile, labelled as such — and the
+    committed profile must be of the kernel (template instance, deferred exact stage or not) this run launched:
+    anything else is a stale file and stops the benchmark."""
     path = os.path.join(ROOT, PMC_TRAFFIC_FILE)
     try:
         with open(path) as fh:
             rec = json.load(fh)
-        if [rec["frames"], rec["height"], rec["width"], rec["box"]] == [F, H, W, box]:
-            return (rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"],
-                    f"{PMC_TRAFFIC_FILE} (rocprofv3 --pmc TCC_EA0_RDREQ_sum / WRITE_SIZE passes of tools/pmc_scan.sh, "
-                    f"kernel {rec['kernel'].split('(')[0].replace('void ', '')})")
-    except (OSError, KeyError, ValueError):
-        pass
-    return None, None
+    except (OSError, ValueError):
+        return None, None
+    if [rec.get("frames"), rec.get("height"), rec.get("width"), rec.get("box")] != [F, H, W, box]:
+        return None, None
+    profiled = rec["kernel"].split("(")[0].replace("void ", "").replace("pmi::", "") + (" defer" if rec.get("defer") else "")
+    if profiled != scan_kernel:
+        raise SystemExit(f"bench.py: {PMC_TRAFFIC_FILE} holds the counters of `{profiled}` but this run launched `{scan_kernel}`: "
+                         "take the counters again (tools/pmc_scan.sh) before quoting roofline.traffic")
+    return (rec["hbm_read_bytes_per_launch"] + rec["hbm_write_bytes_per_launch"],
+            f"{PMC_TRAFFIC_FILE} (rocprofv3 --pmc TCC_EA0_RDREQ_sum / WRITE_SIZE passes of tools/pmc_scan.sh, kernel {profiled})")
 
 
 def cpu_baseline(movie, cam, box, min_ng, method, budget_s):

@@ -405,6 +405,9 @@ int pmi_event_elapsed_ms(void *start, void *stop, float *ms);   /* synchronises 
 int pmi_event_destroy(void *event);
 /* Milliseconds the last pmi_identify_dev / pmi_gaussmle*_dev spent in its
  * dominant kernel, measured with HIP events around that kernel when enabled. */
+/* name of the scan kernel the calling thread's last identify / localize call launched, as rocprofv3 prints it (e.g.
+ * "identify_scan_u16_fast_kernel<3, 3, 1, 0, false>", + " defer" when the exact stage may be left to the fit) */
+int pmi_last_scan_kernel(char *name, size_t name_len);
 int pmi_set_kernel_timing(int enabled);
 int pmi_last_kernel_ms(float *scan_ms, float *fit_ms);
 

@@ -245,6 +245,11 @@ def gausslq(spots, threads=1, full=False):
     return (th, info, nfev) if full else th
 
 
+def lq_set_exp(which: int):
+    """PROBE: 0 = libm's exp (default), 1 = exp correctly rounded to float64 (picasso_oracle.c orc_lq_set_exp)."""
+    lib().orc_lq_set_exp(int(which))
+
+
 def gausslq_initial(spots):
     spots = np.ascontiguousarray(spots, np.float32)
     N, box, _ = spots.shape

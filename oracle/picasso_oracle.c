@@ -858,6 +858,15 @@ static double enorm(int n, const double *x)
     return x3max * sqrt(s3);
 }
 
+/* PROBE (diagnostics only, default 0 = libm's exp, what the reference's np.exp resolves to here): 1 evaluates the two
+ * Gaussian profiles with exp correctly rounded to float64 (expl, 64-bit significand, then one rounding).  tools/probe_lq_exp.py
+ * uses it on the spots where the device's strict mode differs from this oracle: libm's exp is within an ulp but not always
+ * the correctly rounded value, the device's (ocml) is another such function, and where the two differ in the last bit of ONE
+ * profile value a float32 rounding of the stored model (gausslq.py:203) can flip. */
+static int g_lq_exp_variant = 0;
+void orc_lq_set_exp(int which) { g_lq_exp_variant = which; }
+static double lq_exp(double x) { return g_lq_exp_variant ? (double)expl((long double)x) : exp(x); }
+
 /* residuals of the point-sampled Gaussian model, float32 stores as in gausslq.py:151-203 */
 static void lq_residuals(const double *theta, const float *spot, int size, double *fvec)
 {
@@ -867,8 +876,8 @@ static void lq_residuals(const double *theta, const float *spot, int size, doubl
     for (int i = 0; i < size; i++) {
         double g = (double)(float)(i - h);                    /* grid is a float32 array */
         double tx = (g - theta[0]) / theta[4], ty = (g - theta[1]) / theta[5];
-        mx[i] = (float)(nx * exp(-0.5 * (tx * tx)));          /* f32 store */
-        my[i] = (float)(ny * exp(-0.5 * (ty * ty)));
+        mx[i] = (float)(nx * lq_exp(-0.5 * (tx * tx)));       /* f32 store */
+        my[i] = (float)(ny * lq_exp(-0.5 * (ty * ty)));
     }
     for (int i = 0; i < size; i++)
         for (int j = 0; j < size; j++) {

@@ -105,6 +105,7 @@ SYMBOLS = {
     "pmi_event_record": (_i32, [_p, _p]),
     "pmi_event_elapsed_ms": (_i32, [_p, _p, _p]),
     "pmi_event_destroy": (_i32, [_p]),
+    "pmi_last_scan_kernel": (_i32, [_p, ctypes.c_size_t]),
     "pmi_set_kernel_timing": (_i32, [_i32]),
     "pmi_last_kernel_ms": (_i32, [_p, _p]),
 }

@@ -152,7 +152,9 @@ def get_mle_mode():
 
 
 def last_refit_count(stream=None) -> int:
-    """Spots the last MLE call fitted a second time (synchronises `stream`)."""
+    """Spots the last MLE call OF THE CALLING THREAD fitted a second time (synchronises `stream`).  The library keeps these
+    statistics — like the scratch bank, `last_flag_reasons`, `last_lq_refit_count`, `last_lq_tie_reasons` — per thread: read
+    from another thread than the one that ran the fit they are 0, not an error."""
     n = ctypes.c_int64(0)
     _lib.check(_lib.load().pmi_mle_last_refit_count(ctypes.byref(n), stream), "pmi_mle_last_refit_count")
     return int(n.value)

@@ -156,6 +156,9 @@ __device__ __forceinline__ BTerms boundary_terms(float jf, float mu, float sigma
 // FMA of boundary_terms / erf_f32 becomes one packed instruction on a register pair (v_pk_mul_f32, v_pk_add_f32,
 // v_pk_fma_f32) — component by component the same operation order as the scalar form.  Only v_rcp_f32, v_exp_f32, the
 // DPP moves, the sign transfer and the final select stay per component.
+#ifndef G8_PACKED_BOUNDARY
+#define G8_PACKED_BOUNDARY 1      // A/B knob of the build: 0 = the scalar evaluation per axis
+#endif
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 struct BTerms2 { f32x2 E, A, A2, S, S2; };
 __device__ __forceinline__ f32x2 splat2(float v) { return (f32x2){v, v}; }
@@ -287,11 +290,16 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
     const float jf = (float)j;
     const float sgy = NP == 6 ? th[5] : th[4];
     BTerms tx, ty;                                          // column j, row j
+#if G8_PACKED_BOUNDARY
     {
         const BTerms2 b = boundary_terms2(jf, (f32x2){th[0], th[1]}, (f32x2){th[4], sgy});
         tx.E = b.E.x; tx.A = b.A.x; tx.A2 = b.A2.x; tx.S = b.S.x; tx.S2 = b.S2.x;
         ty.E = b.E.y; ty.A = b.A.y; ty.A2 = b.A2.y; ty.S = b.S.y; ty.S2 = b.S2.y;
     }
+#else
+    tx = boundary_terms(jf, th[0], th[4]);
+    ty = boundary_terms(jf, th[1], sgy);
+#endif
     __builtin_amdgcn_wave_barrier();
     {
         float4 *c = reinterpret_cast<float4 *>(cols + j * 12);

@@ -494,6 +494,7 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
             }
             fast = all_fast;
         }
+        if (rc == PMI_OK && !fast) snprintf(g_last_scan_kernel, sizeof(g_last_scan_kernel), "identify_scan_kernel (dtype %d)", dtype);
         if (rc == PMI_OK && !fast) switch (dtype) {
         case PMI_U16: rc = launch_scan<uint16_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;
         case PMI_U8:  rc = launch_scan<uint8_t>(d_movie, p, d_tab, recs, cap, d_total, count, s); break;

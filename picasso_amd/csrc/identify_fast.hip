@@ -1000,6 +1000,8 @@ static int launch_fast(const FastParams &p, int pt, const float *d_tab, Record *
     const long long blocks = (p.units + p.upw - 1) / p.upw;
     if (blocks > 0x7fffffffLL) { set_error("identify: too many blocks (%lld)", blocks); return PMI_ERR_ARG; }
     const dim3 g((unsigned)blocks), b(64);
+    snprintf(g_last_scan_kernel, sizeof(g_last_scan_kernel), "identify_scan_u16_fast_kernel<%d, %d, %d, %d, %s>%s", H, D, P, pt,
+             (P == 1 && p.segs > 1) ? "true" : "false", p.defer ? " defer" : "");
     if constexpr (P == 1) {
         if (p.segs > 1) {             // frames wider than a wave: the variant with the edge loads
             if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_U8, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);

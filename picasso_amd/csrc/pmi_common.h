@@ -72,6 +72,9 @@ __host__ __device__ __forceinline__ uint32_t pack_yx(int y, int x) { return ((ui
 constexpr uint32_t NG_DEFERRED_BITS = 0x7fc0d1feu;
 // set (per thread) by a fused call around identify_impl: the packed scan may defer its exact stage
 extern thread_local bool g_defer_exact;
+// the scan kernel the calling thread launched last, as rocprofv3 names it (+ " defer" when it may leave its exact stage to
+// the fit): pmi_last_scan_kernel, so that a benchmark can tell which kernel a committed counter file belongs to
+extern thread_local char g_last_scan_kernel[128];
 
 // pixel load as float32 (the reference's np.float32(frame), localize.py:332)
 template <typename T>

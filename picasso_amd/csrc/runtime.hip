@@ -12,6 +12,7 @@ bool g_kernel_timing = false;
 KernelTimes g_last_times = {0.f, 0.f};
 thread_local PixHandoff g_handoff;
 thread_local bool g_defer_exact = false;
+thread_local char g_last_scan_kernel[128] = "";
 
 void set_error(const char *fmt, ...)
 {
@@ -110,6 +111,12 @@ int pmi_device_count(void)
 int pmi_set_device(int device)
 {
     PMI_HIP(hipSetDevice(device));
+    return PMI_OK;
+}
+
+int pmi_last_scan_kernel(char *name, size_t name_len)
+{
+    if (name && name_len) { strncpy(name, pmi::g_last_scan_kernel, name_len - 1); name[name_len - 1] = 0; }
     return PMI_OK;
 }
 

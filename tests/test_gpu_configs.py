@@ -286,13 +286,18 @@ def test_fused_call_keeps_two_frame_ranges_in_flight():
         # the pixel hand-off from the scan's exact stage to the fit (off by default): the same table, bit for bit
         _lib.check(L.pmi_localize_set_handoff(1), "pmi_localize_set_handoff")
         try:
+            hand = {}
             for ranges in (1, 2):
-                h, nh, _ = run(ranges, 0, F - 1, None, cap)
-                full, nfu, _ = run(1, 0, F - 1, None, cap) if ranges == 1 else (h, nh, 0)
-                assert nh == n_full
+                hand[ranges] = run(ranges, 0, F - 1, None, cap)[:2]
+                assert hand[ranges][1] == n_full
+            hroi = run(1, 0, F - 1, (10, 21, 500, 490), cap)[:2]          # an ROI that starts off an 8-pixel boundary
             _lib.check(L.pmi_localize_set_handoff(0), "pmi_localize_set_handoff")
-            plain, npl, _ = run(2, 0, F - 1, None, cap)
-            assert npl == nh and torch.equal(plain[:, :npl], h[:, :nh])
+            for ranges in (1, 2):
+                plain, npl, _ = run(ranges, 0, F - 1, None, cap)
+                h, nh = hand[ranges]
+                assert npl == nh and torch.equal(plain[:, :npl], h[:, :nh]), ranges
+            plain, npl, _ = run(1, 0, F - 1, (10, 21, 500, 490), cap)
+            assert npl == hroi[1] and torch.equal(plain[:, :npl], hroi[0][:, :npl])
         finally:
             _lib.check(L.pmi_localize_set_handoff(0), "pmi_localize_set_handoff")
         # capacity between the first half's count and the total: nothing may be written; the count reported is the rows

@@ -36,13 +36,16 @@ def test_rccl_probe_one_rank():
 
 
 def test_bench_one_gpu_line_and_world_checks():
-    small = ["--steps", "2", "--warmup", "1", "--frames", "400", "--cpu-seconds", "0", "--profile-steps", "1"]
+    small = ["--steps", "2", "--warmup", "1", "--frames", "400", "--cpu-seconds", "0", "--profile-steps", "1", "--strict-steps", "1"]
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small, cwd=ROOT, env=_env(),
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads(out.stdout.strip().splitlines()[-1])
     assert line["n_gpus"] == 1 and line["steps"] == 2 and line["value"] > 1e6
     assert line["roofline"]["bound"] == "hbm" and 0 < line["roofline"]["frac"] < 1
+    assert line["roofline"]["scan_kernel"].startswith("identify_scan_u16_fast_kernel<3, 3, 1, 0, false>")
+    # every spot in the reference's arithmetic beside the timed configuration, and how many of its spots were fitted twice
+    assert line["value_strict"] and 0 < line["value_strict"] < line["value"] and 0 < line["refit_fraction"] < 0.05
     # a world the command line did not ask for is refused
     env = _env()
     env.update({"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
@@ -66,16 +69,26 @@ def test_bench_starts_its_own_ranks():
         assert "only 1 GPU(s) visible" in out.stderr and "2-rank launch failed" in out.stderr
 
 
-def test_bench_under_the_launcher_uses_the_native_all_gather():
-    """One rank under torch.distributed.run: the step ends with pmi_allgather_locs (RCCL called from the library) and
-    the gathered table is checked against the local one inside bench.py."""
-    small = ["--steps", "2", "--warmup", "1", "--frames", "400", "--cpu-seconds", "0", "--profile-steps", "0"]
+@pytest.mark.parametrize("serial", [False, True])
+def test_bench_under_the_launcher_uses_the_native_all_gather(serial):
+    """The N > 1 path of bench.py on the one GPU there is: one rank under torch.distributed.run, 50 timed steps that each
+    end with pmi_allgather_locs — RCCL called from the library (its own communicator, its own librccl handle) beside
+    torch.distributed's RCCL in the same process — double-buffered on a side stream, and unoverlapped (--serial-gather).
+    bench.py checks the gathered table against the local one; the line carries the per-rank compute / gather split."""
+    small = ["--steps", "50", "--warmup", "2", "--frames", "400", "--cpu-seconds", "0", "--profile-steps", "0", "--strict-steps", "0"]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
            "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small
+    if serial:
+        cmd.append("--serial-gather")
     out = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["steps"] == 50 and line["n_gpus"] == 1
     assert line["config"]["all_gather"].startswith("pmi_allgather_locs"), line["config"]["all_gather"]
+    per = line["config"]["per_rank"]
+    assert per and len(per["compute_ms"]) == 1 and per["compute_ms"][0] > 0
+    assert per["gather_ms"][0] is not None and per["gather_ms"][0] >= 0 and per["gather_bytes_received_per_step"] > 0
+    assert ("double-buffered" in line["config"]["workload"]) == (not serial)
 
 
 def test_native_communicator_one_rank():

@@ -77,6 +77,17 @@ def test_gaussmle_every_row_at_max_it_1000(be, orc, box, n, method, eps):
     check_case(be, orc, spots, eps, 1000, method, f"box {box} {method} eps {eps} max_it 1000")
 
 
+@pytest.mark.parametrize("box", [7, 13])
+@pytest.mark.parametrize("max_it", [40, 64])
+@pytest.mark.parametrize("method", ["sigmaxy", "sigma"])
+def test_gaussmle_every_row_with_max_it_between_32_and_64(be, orc, box, max_it, method):
+    """max_it in (32, 64] at eps 1e-4: fits that run into max_it, or take more than 32 iterations, carry no flag of their own
+    since round 3 (the slow-fit threshold went from 32 to 64, the 'ran into max_it' flag was dropped) — the margin, swing and
+    contraction flags have to cover them here too."""
+    spots = knob_spots(box, 20000, 4000 + 100 * box + max_it)
+    check_case(be, orc, spots, 1e-4, max_it, method, f"box {box} {method} eps 1e-4 max_it {max_it}")
+
+
 def test_regression_swinging_fit_wide_sigma(be, orc):
     """fuzz_long.log (round 2): box 21 `sigma`, eps 1e-3: equal iteration counts (14 / 14) but 1.07e-3 px apart — photons,
     background and width trade against each other and step back and forth for a dozen iterations; the positions pass

@@ -26,12 +26,14 @@ def main():
     ap.add_argument("--only", type=int, default=0, help="3 or 5: just that config")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--defer", type=int, default=1, choices=(0, 1), help="A/B: 0 keeps identify's exact stage in the scan (pmi_localize_set_defer)")
     args = ap.parse_args()
     import torch
     from oracle import oracle as orc
     from picasso_amd import _lib, backend, synth
     L = _lib.load()
     _lib.require_gpu()
+    _lib.check(L.pmi_localize_set_defer(args.defer), "pmi_localize_set_defer")
     F, H, W = args.frames, 512, 512
     cam = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
     threads = min(16, len(os.sched_getaffinity(0)))
@@ -184,7 +186,7 @@ def config5(args, torch, orc, L, _lib, synth, cam, threads, timed, kernel_ms, ro
                       "config": {"workload": f"{F}-frame 512x512 uint16 astigmatic movie, {n} spots, identify(box 13) + fused cut + "
                                              "MLE sigmaxy + 17-column table, then bounded-Brent zfit", "frames": F, "box": 13},
                       "stages_ms": {"identify+gaussmle+table": 1e3 * t_m, "zfit": 1e3 * t_z},
-                      "mle": {"mode": backend.get_mle_mode()[0], "refit_spots": refit},
+                      "mle": {"mode": backend.get_mle_mode()[0], "refit_spots": refit, "exact_stage_deferred_to_fit": bool(args.defer)},
                       "roofline": roofline(movie.numel() * 2, scan_ms, fit_ms, n, "mle_fit_13x13 (g8 init/iterate/final + strict refit + crlb)",
                                            "fp32 valu issue; 406 B/spot algorithmic", 406.0),
                       "cpu_baseline": cpu}), flush=True)

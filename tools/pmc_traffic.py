@@ -2,7 +2,7 @@
 """Turn the counter_collection.csv files of tools/pmc_quick.sh passes into profiles/<name>.json
 (HBM-side bytes per launch of the identify scan kernel, gfx950 corrections of MI355X_MICROARCH.md).
 usage: tools/pmc_traffic.py <out.json> <frames> <height> <width> <box> <pass dir> [<pass dir> ...]"""
-import collections, csv, glob, json, re, sys
+import collections, csv, glob, json, os, re, sys
 
 out, F, H, W, box = sys.argv[1], *map(int, sys.argv[2:6])
 rx = re.compile("identify_scan")
@@ -29,9 +29,11 @@ elif fetch_kb is not None:
     read_bytes = 2 * fetch_kb * 1024                     # FETCH_SIZE counts 64 B per 128-B request on gfx950
 write_bytes = ctr.get("WRITE_SIZE", 0.0) * 1024
 alg = F * H * W * 2
+prog = os.environ.get("PMC_COMMAND", "python3 tools/time_identify.py %d %d 1" % (F, box))
 rec = {"kernel": kname, "frames": F, "height": H, "width": W, "box": box,
-       "command": "rocprofv3 --kernel-trace --pmc <set> --kernel-include-regex identify_scan -- python3 "
-                  "tools/time_identify.py %d %d 1   (one --pmc pass per counter set, tools/pmc_quick.sh)" % (F, box),
+       "defer": int(os.environ.get("PMC_DEFER", "0")),      # 1: the launches of the fused path, exact stage left to the fit's start-value kernel
+       "command": "rocprofv3 --kernel-trace --pmc <set> --kernel-include-regex identify_scan -- %s   "
+                  "(one --pmc pass per counter set, tools/pmc_quick.sh)" % prog,
        "counters_per_launch": ctr,
        "hbm_read_bytes_per_launch": int(read_bytes) if read_bytes is not None else None,
        "hbm_write_bytes_per_launch": int(write_bytes),

@@ -1,0 +1,23 @@
+#!/bin/bash
+# The measurement artefacts of a round on ONE box: bench line, rocprofv3 kernel stats of the same command (default and
+# --ranges 1), PMC of the scan as the benchmark launches it (fused path, exact stage deferred) and alone, instruction-mix
+# PMC of the Newton loop and of the least-squares kernels, the config-3 / config-5 lines.
+# usage (on the GPU box, from the repo root): bash tools/round_profiles.sh <outdir> [round tag]
+OUT=${1:-gpurun_out/prof}; TAG=${2:-r04}
+mkdir -p $OUT; export TMPDIR=/tmp
+bash tools/pmc_scan.sh /tmp/pmc_scan_fused 10000 7 fused > $OUT/${TAG}_scan_pmc.txt 2>&1; cp /tmp/pmc_scan_fused/traffic.json $OUT/${TAG}_identify_pmc.json
+cp /tmp/pmc_scan_fused/traffic.json profiles/${TAG}_identify_pmc.json      # bench.py quotes roofline.traffic from this file and checks the kernel
+python3 bench.py > $OUT/${TAG}_bench.json 2> $OUT/bench.err || tail -5 $OUT/bench.err
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_bench -- python3 $OLDPWD/bench.py --cpu-seconds 0 > /tmp/prof_bench.log 2>&1)
+python3 tools/rocprof_summary.py /tmp/prof_bench > $OUT/${TAG}_bench_kernel_stats.txt
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_bench1 -- python3 $OLDPWD/bench.py --cpu-seconds 0 --ranges 1 > /tmp/prof_bench1.log 2>&1)
+python3 tools/rocprof_summary.py /tmp/prof_bench1 > $OUT/${TAG}_bench_ranges1_kernel_stats.txt
+bash tools/pmc_scan.sh /tmp/pmc_scan_alone 10000 7 identify > $OUT/${TAG}_scan_alone_pmc.txt 2>&1; cp /tmp/pmc_scan_alone/traffic.json $OUT/${TAG}_identify_alone_pmc.json
+bash tools/pmc_fit.sh /tmp/pmc_g8 "g8_iterate" python3 tools/ab_defer.py 10000 7 1 1 > $OUT/${TAG}_g8_iterate_pmc.txt 2>&1
+bash tools/pmc_fit.sh /tmp/pmc_g8i "g8_init" python3 tools/ab_defer.py 10000 7 1 1 > $OUT/${TAG}_g8_init_pmc.txt 2>&1
+bash tools/pmc_fit.sh /tmp/pmc_lqj "lq_jacobian" python3 tools/time_gausslq.py 1048576 7 > $OUT/${TAG}_lq_jacobian_pmc.txt 2>&1
+bash tools/pmc_fit.sh /tmp/pmc_lqs "lq_step" python3 tools/time_gausslq.py 1048576 7 > $OUT/${TAG}_lq_step_pmc.txt 2>&1
+python3 tools/bench_configs.py --only 3 > $OUT/${TAG}_config3.jsonl 2> $OUT/config3.err || tail -3 $OUT/config3.err
+python3 tools/bench_configs.py --only 5 > $OUT/${TAG}_config5.jsonl 2> $OUT/config5.err || tail -3 $OUT/config5.err
+python3 tools/bench_configs.py --only 5 --defer 0 --cpu-seconds 0 > $OUT/${TAG}_config5_nodefer.jsonl 2>> $OUT/config5.err
+ls -la $OUT

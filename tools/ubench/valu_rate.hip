@@ -29,6 +29,32 @@ OPS(k_add_f32, "v_add_f32 %0, %0, %1")
 OPS(k_fma, "v_fma_f32 %0, %0, %1, %1")
 OPS(k_exp, "v_exp_f32 %0, %0")
 OPS(k_rcp, "v_rcp_f32 %0, %0")
+OPS(k_mul_f32, "v_mul_f32 %0, %0, %1")
+#define OPS2(NAME, ASMSTR)                                                                       \
+    __global__ void NAME(unsigned *out, int iters)                                               \
+    {                                                                                            \
+        typedef float f2 __attribute__((ext_vector_type(2)));                                    \
+        f2 a0 = {(float)threadIdx.x, 1.f}, a1 = a0 * 3.f, a2 = a0 * 5.f, a3 = a0 * 7.f, a4 = a0 * 11.f, a5 = a0 * 13.f, a6 = a0 * 17.f, a7 = a0 * 19.f; \
+        f2 b = {1.0001f, 0.9999f};                                                               \
+        for (int i = 0; i < iters; i++) {                                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a0) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a1) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a2) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a3) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a4) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a5) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a6) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a7) : "v"(b));                                        \
+        }                                                                                        \
+        f2 r = a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7;                                            \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = __float_as_uint(r.x + r.y);                  \
+    }
+OPS2(k_pk_fma_f32, "v_pk_fma_f32 %0, %0, %1, %1")
+OPS2(k_pk_mul_f32, "v_pk_mul_f32 %0, %0, %1")
+OPS2(k_pk_add_f32, "v_pk_add_f32 %0, %0, %1")
+OPS2(k_fma_f64, "v_fma_f64 %0, %0, %1, %1")
+OPS2(k_mul_f64, "v_mul_f64 %0, %0, %1")
+OPS2(k_addd_f64, "v_add_f64 %0, %0, %1")
 OPS(k_lshl_or, "v_lshl_or_b32 %0, %0, 1, %1")
 OPS(k_mov_dpp, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
 OPS(k_add_dpp, "v_add_f32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
@@ -57,7 +83,11 @@ int main()
     for (int w : {1, 2, 4, 8}) {
         run("v_pk_max_u16", k_pk_max, w); run("v_max_u32", k_max_u32, w); 
         
-        run("v_exp_f32", k_exp, w); 
+        run("v_exp_f32", k_exp, w);
+        run("v_fma_f32", k_fma, w); run("v_mul_f32", k_mul_f32, w);
+        run("v_pk_fma_f32", k_pk_fma_f32, w); run("v_pk_mul_f32", k_pk_mul_f32, w); run("v_pk_add_f32", k_pk_add_f32, w);
+        run("v_fma_f64", k_fma_f64, w); run("v_mul_f64", k_mul_f64, w); run("v_add_f64", k_addd_f64, w);
+        run("v_rcp_f32", k_rcp, w);
          run("v_add_f32_dpp", k_add_dpp, w);
     }
     return 0;

@@ -207,7 +207,7 @@ int pmi_localize_set_ranges(int ranges);
  * +0.14 ms (7 more scattered 16-byte stores per candidate on a kernel bound by its memory-side requests) - the same
  * table, no gain, hence off. */
 int pmi_localize_set_handoff(int on);
-/* Deferred exact stage (default on): on uint16 / uint8 / int16 movies, boxes up to 15 and a positive threshold the packed
+/* Deferred exact stage (default on): on uint16 / uint8 / int16 movies, boxes up to 7 and a positive threshold the packed
  * scan of pmi_localize_mle_dev only emits CANDIDATES (window maximum, floor, neighbour rule) and the start-value kernel
  * of the fit — which reads a candidate's rows anyway — evaluates the float32 net gradient in the reference's (k, l)
  * order, the first-argmax rule and the threshold (picasso/localize.py:97-134, 202-244, 288): the scan no longer re-reads

@@ -23,6 +23,7 @@
 #include <cstring>
 
 #include "fit_common.h"
+#include "exp_cr.h"
 
 #pragma clang fp contract(off)
 
@@ -336,8 +337,25 @@ __device__ __forceinline__ double enorm_rows(const double (&v)[E], int lane, int
 // is, one in the photons or the background leaves both — the values are the same function of the same arguments, so
 // what is reused is bit for bit what would have been recomputed (6 instead of 14 float64 exp per lane and Jacobian in
 // the 8-lane groups, 5 instead of 7 in the others).
-template <int GS>
-__device__ __forceinline__ void profiles(const double (&th)[6], int size, int lane, int which, float (&prof)[GS == 8 ? 2 : 1])
+// A profile value is stored in float32 (gausslq.py:203): nrm * exp(..) is rounded to float64, then to float32.  The
+// device's exp and a CPU libm's are different functions within an ulp of the true one; where the float64 product sits
+// within a few of its ulps of a float32 rounding boundary, the last bit of exp decides the stored value.  `fragile`
+// reports that (strict mode: such a spot is fitted again with exp rounded correctly, exp_cr.h — 2 of 29 million fuzz
+// spots ended 8e-5 px from the oracle before this); in the float32 subnormal range fewer bits are kept.
+__device__ __forceinline__ unsigned fragile_f32_rounding(double p)
+{
+    // Does the float32 value change when p moves by 8 of its ulps either way?  In the normal float32 range 29 bits are
+    // dropped: fragile within 8 of their midpoint 2^28 — three 32-bit instructions on the low word (this sits in the hot
+    // profile loops of kernels that have no register to spare; asking the conversion itself, (float)(p (1 +- 2^-50)) != (float)p,
+    // costs three quarter-rate conversions per value: 7x7 +5 %, 13x13 +19 %).  Among the float32 subnormals fewer bits are
+    // kept and the test is not the right one — but a profile value below 1e-38 enters the model as photons x value + background,
+    // rounded to float32 again: whichever way it rounds, nothing a float64 sum of the fit can see.
+    return (unsigned)((((unsigned)__double2loint(p) & 0x1fffffffu) - 0x0ffffff8u) <= 16u);
+}
+template <bool CR> __device__ __forceinline__ double lq_exp(double x) { if constexpr (CR) return exp_cr(x); else return exp(x); }
+
+template <int GS, bool CR = false>
+__device__ __forceinline__ void profiles(const double (&th)[6], int size, int lane, int which, float (&prof)[GS == 8 ? 2 : 1], unsigned &fragile)
 {
     constexpr int NPROF = GS == 8 ? 2 : 1;
     const int hsz = size / 2;
@@ -351,7 +369,9 @@ __device__ __forceinline__ void profiles(const double (&th)[6], int size, int la
         const double g = (double)(float)(idx - hsz);
         const double t = (g - mu) / sg;
         const double nrm = 0.3989422804014327 / sg;
-        prof[k] = (float)(nrm * exp(-0.5 * (t * t)));
+        const double pv = nrm * lq_exp<CR>(-0.5 * (t * t));
+        fragile |= fragile_f32_rounding(pv);
+        prof[k] = (float)pv;
     }
 }
 
@@ -812,9 +832,11 @@ struct LqState {                                 // structure of arrays, stride 
 // (a): residuals at x, Jacobian, QR.  list == nullptr: spots [first, min(first + count, n)).
 // Waves per SIMD the Jacobian kernel leaves room for: three where a lane holds at most four rows of a small box (boxes
 // 3 and 5: 4 / 35 spilled values, 5x5 5.67 -> 5.42 ms per 1e6 spots), two elsewhere (7x7 at three: 230 spills, 7.6 -> 11.6 ms).
-constexpr int lq_jacobian_min_waves(int GS, int E) { return GS * E <= 32 ? 3 : LQ_MIN_WAVES; }
-template <int GS, int E, bool FROM_MOVIE, bool STRICT>
-__global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E)) void lq_jacobian_kernel(Params p, LqState st, const int32_t *__restrict__ list,
+// (strict mode, 5x5: the chains' buffers come on top — 84 spilled values at three waves, so two there)
+constexpr int lq_jacobian_min_waves(int GS, int E, bool STRICT) { return GS * E <= (STRICT ? 16 : 32) ? 3 : LQ_MIN_WAVES; }
+// CR (strict mode's second pass): the exp of the profiles rounded correctly (exp_cr.h)
+template <int GS, int E, bool FROM_MOVIE, bool STRICT, bool CR = false>
+__global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E, STRICT)) void lq_jacobian_kernel(Params p, LqState st, const int32_t *__restrict__ list,
                                                                       const unsigned *__restrict__ list_n, int64_t count)
 {
     constexpr int NGRP = 64 / GS;                              // spots per wavefront
@@ -873,7 +895,8 @@ __global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E)) void l
         double wa1[6], wa2[6], wa3[6];
         int ipvt[6];
         float prof0[GS == 8 ? 2 : 1], profj[GS == 8 ? 2 : 1];
-        profiles<GS>(x, size, lane, 3, prof0);
+        unsigned fragile = 0u;
+        profiles<GS, CR>(x, size, lane, 3, prof0, fragile);
         residuals<GS, E>(x, prof0, sp, ri, rj, act, size, lane, fv);
         // fdjac2
 #pragma unroll
@@ -885,8 +908,8 @@ __global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E)) void l
 #pragma unroll
             for (int k = 0; k < (GS == 8 ? 2 : 1); k++) profj[k] = prof0[k];
             // x0, sx move the x profile, y0, sy the y profile, photons and background neither
-            if (j == 0 || j == 4) profiles<GS>(x, size, lane, GS == 8 ? 1 : 3, profj);
-            if (j == 1 || j == 5) profiles<GS>(x, size, lane, GS == 8 ? 2 : 3, profj);
+            if (j == 0 || j == 4) profiles<GS, CR>(x, size, lane, GS == 8 ? 1 : 3, profj, fragile);
+            if (j == 1 || j == 5) profiles<GS, CR>(x, size, lane, GS == 8 ? 2 : 3, profj, fragile);
             residuals<GS, E>(x, profj, sp, ri, rj, act, size, lane, fp);
             x[j] = temp;
 #pragma unroll
@@ -971,6 +994,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E)) void l
             if (lane == j) a[j][0] = wa1[j];
         }
         }
+        const bool frag_any = STRICT && !CR && Grp<GS>::any(fragile != 0u);       // (every lane of the group takes part in the vote)
         if (store && lane < 6) {
 #pragma unroll
             for (int j = 0; j < 6; j++) LQD(st, 16 + lane * 6 + j, ls) = lane <= j ? a[j][0] : 0.0;
@@ -978,6 +1002,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E)) void l
             LQD(st, 58 + lane, ls) = get6(wa2, lane);
             LQI(st, lane, ls) = lane == 0 ? ipvt[0] : (lane == 1 ? ipvt[1] : (lane == 2 ? ipvt[2] : (lane == 3 ? ipvt[3] : (lane == 4 ? ipvt[4] : ipvt[5]))));
             if (!STRICT && tie && lane == 0) LQI(st, 9, ls) = LQI(st, 9, ls) | 1;
+            if (frag_any && lane == 0) LQI(st, 9, ls) = LQI(st, 9, ls) | 128;
         }
     }
 }
@@ -1102,7 +1127,9 @@ constexpr int LQ_STEP_NT = 64;        // one wave per workgroup: 7.58 -> 7.46 ms
 // (b): one spot per lane — the Levenberg-Marquardt step(s) on the factor lq_jacobian_kernel left, until the fit ends
 // or needs a new Jacobian.  Spots that go on are appended to next_list.
 // FLAG: every decision is also tested against a band around its threshold (the spots of the first pass of the refit mode)
-template <bool FROM_MOVIE, bool FLAG>
+// FRAG: a profile value whose float32 rounding hangs on the last bits of exp sends the spot to the tie list (first pass of the
+//       strict mode);  CR: exp rounded correctly (its second pass)
+template <bool FROM_MOVIE, bool FLAG, bool FRAG = false, bool CR = false>
 __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(Params p, LqState st, const int32_t *__restrict__ list,
                                                              const unsigned *__restrict__ list_n, int64_t count,
                                                              int32_t *__restrict__ next_list, unsigned *__restrict__ next_n,
@@ -1135,16 +1162,21 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
     if (FROM_MOVIE) { fr = p.frame[s]; y0 = p.y[s] - hsz; x0 = p.x[s] - hsz; }
 
     // norm of the residuals of the float32-stored model (gausslq.py:151-203) at th
+    unsigned fragile = 0u;
     auto fnorm_at = [&](const double (&th)[6]) -> double {
         const double nx = 0.3989422804014327 / th[4], ny = 0.3989422804014327 / th[5];
         for (int j = 0; j < size; j++) {
             const double t = ((double)(float)(j - hsz) - th[0]) / th[4];
-            s_px[j][tid] = (float)(nx * exp(-0.5 * (t * t)));
+            const double pv = nx * lq_exp<CR>(-0.5 * (t * t));
+            if constexpr (FRAG) fragile |= fragile_f32_rounding(pv);
+            s_px[j][tid] = (float)pv;
         }
         EnormAcc acc(m);
         for (int i = 0; i < size; i++) {
             const double t = ((double)(float)(i - hsz) - th[1]) / th[5];
-            const float myv = (float)(ny * exp(-0.5 * (t * t)));
+            const double pvy = ny * lq_exp<CR>(-0.5 * (t * t));
+            if constexpr (FRAG) fragile |= fragile_f32_rounding(pvy);
+            const float myv = (float)pvy;
             for (int j = 0; j < size; j++) {
                 float spv;
                 if (staged) {
@@ -1189,7 +1221,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
     // tie: a decision of this fit fell within LQ_TIE of its threshold — here, in lmpar or in the pivoting of the Jacobian
     // kernel (slot 9).  The group kernel's tree sums differ from MINPACK's sequential ones in the last bits of float64,
     // so such a decision may be MINPACK's other branch: the spot is fitted again with sequential sums (tie_list).
-    unsigned tie = FLAG && tie_list ? (unsigned)LQI(st, 9, ls) : 0u;       // bit 0: the pivot choice of the Jacobian kernel; 1: lmpar; 2..6 below
+    unsigned tie = (FLAG || FRAG) && tie_list ? (unsigned)LQI(st, 9, ls) : 0u;       // bit 0: the pivot choice of the Jacobian kernel; 1: lmpar; 2..6 below
     double gnorm = 0, fnorm1, actred, prered, dirder, ratio, pnorm;
     if (iter == 1) {
 #pragma unroll
@@ -1283,13 +1315,14 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
             if (ratio >= 1e-4) break;
         }
     }
+    if (FRAG && fragile) tie |= 128u;                       // bit 7: a float32 rounding of the model hangs on the last bit of an exp
     if (info != 0) {
 #pragma unroll
         for (int j = 0; j < 6; j++) p.thetas[s * 6 + j] = (float)x[j];
         if (p.info) p.info[s] = info;
         if (p.nfev) p.nfev[s] = nfev;
         LQI(st, 8, ls) = info;
-        if (FLAG && tie && tie_list) {
+        if ((FLAG || FRAG) && tie && tie_list) {
             tie_list[atomicAdd(tie_n, 1u)] = (int32_t)s;
             for (int b = 0; b < 7; b++)
                 if (tie & (1u << b)) atomicAdd(tie_n + 1 + b, 1u);      // why (diagnostics: pmi_gausslq_last_tie_reasons)
@@ -1299,12 +1332,12 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
         for (int j = 0; j < 6; j++) { LQD(st, j, ls) = x[j]; LQD(st, 6 + j, ls) = diag[j]; }
         LQD(st, 12, ls) = fnorm; LQD(st, 13, ls) = delta; LQD(st, 14, ls) = par; LQD(st, 15, ls) = xnorm;
         LQI(st, 6, ls) = iter; LQI(st, 7, ls) = nfev; LQI(st, 8, ls) = 0;
-        if (FLAG && tie && tie_list) LQI(st, 9, ls) = (int32_t)tie;
+        if ((FLAG || FRAG) && tie && tie_list) LQI(st, 9, ls) = (int32_t)tie;
         next_list[atomicAdd(next_n, 1u)] = (int32_t)s;
     }
 }
 
-template <bool FROM_MOVIE, bool STRICT>
+template <bool FROM_MOVIE, bool STRICT, bool CR = false>
 static void launch_jacobian(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count,
                             int cus, hipStream_t s)
 {
@@ -1321,9 +1354,9 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
 #define LQ_JAC(GS, E, SPW) do { \
         if (lds_for(SPW) > 65536) { \
             static bool asked = false; \
-            if (!asked) { (void)hipFuncSetAttribute((const void *)lq_jacobian_kernel<GS, E, FROM_MOVIE, STRICT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); asked = true; } \
+            if (!asked) { (void)hipFuncSetAttribute((const void *)lq_jacobian_kernel<GS, E, FROM_MOVIE, STRICT, CR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); asked = true; } \
         } \
-        hipLaunchKernelGGL((lq_jacobian_kernel<GS, E, FROM_MOVIE, STRICT>), grid_for(SPW), block, lds_for(SPW), s, p, st, list, list_n, count); \
+        hipLaunchKernelGGL((lq_jacobian_kernel<GS, E, FROM_MOVIE, STRICT, CR>), grid_for(SPW), block, lds_for(SPW), s, p, st, list, list_n, count); \
     } while (0)
     if (p.box <= 7 && !g16) {
         // eight spots per wavefront: the scalar chains of the factorisation (norm updates, Householder scalings:
@@ -1430,13 +1463,14 @@ static int launch(Params p, hipStream_t s)
         // pass 0: every spot of the batch, tree sums, decisions near a threshold collected in tie_list;
         // pass 1: the spots of tie_list again from their start values, sequential sums, no flagging
         unsigned hw[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // tie count and its reasons, read with the first pass's last look at the stream
-        // strict mode: one pass over every spot with the sequential sums, nothing to flag
-        for (int pass = all_strict ? 1 : 0; pass < 2; pass++) {
-            const int32_t *cur = pass == 0 || all_strict ? nullptr : tie_list;
-            const unsigned *cur_n = pass == 0 || all_strict ? nullptr : tie_n;
+        // strict mode: pass 0 = every spot with the sequential sums, flagging the spots on which a float32 rounding of the
+        // model hangs on the last bit of an exp (a handful per ten million); pass 1 = those again with exp rounded correctly
+        for (int pass = 0; pass < 2; pass++) {
+            const int32_t *cur = pass == 0 ? nullptr : tie_list;
+            const unsigned *cur_n = pass == 0 ? nullptr : tie_n;
             int64_t bound = count;                                   // spots the next round may hold
             unsigned h[3] = {0, 0, 0};                               // spots left, spots tied, (first batch) device row count
-            if (pass == 1 && !all_strict) {
+            if (pass == 1) {
                 h[1] = hw[0];
                 for (int b = 0; b < 7; b++) g_last_lq_why[b] += hw[1 + b];
                 if (h[1] == 0 || no_strict) break;
@@ -1456,15 +1490,18 @@ static int launch(Params p, hipStream_t s)
                     int32_t *nxt = lists[round & 1];
                     unsigned *nxt_n = counters + (round % NCTR);
                     if (round >= NCTR) PMI_HIP(hipMemsetAsync(nxt_n, 0, sizeof(unsigned), s));
-                    if (pass == 0) launch_jacobian<FROM_MOVIE, false>(p, st, cur, cur_n, bound, cus, s);
-                    else launch_jacobian<FROM_MOVIE, true>(p, st, cur, cur_n, bound, cus, s);
+                    if (pass == 0 && !all_strict) launch_jacobian<FROM_MOVIE, false>(p, st, cur, cur_n, bound, cus, s);
+                    else if (pass == 0) launch_jacobian<FROM_MOVIE, true>(p, st, cur, cur_n, bound, cus, s);
+                    else if (!all_strict) launch_jacobian<FROM_MOVIE, true>(p, st, cur, cur_n, bound, cus, s);
+                    else launch_jacobian<FROM_MOVIE, true, true>(p, st, cur, cur_n, bound, cus, s);
                     const unsigned sb = (unsigned)((bound + LQ_STEP_NT - 1) / LQ_STEP_NT);
-                    if (pass == 0)
-                        hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE, true>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, cur, cur_n, bound, nxt, nxt_n,
-                                           tie_list, tie_n);
-                    else
-                        hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE, false>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, cur, cur_n, bound, nxt, nxt_n,
-                                           (int32_t *)nullptr, (unsigned *)nullptr);
+#define LQ_STEP(FLAG, FRAG, CR, TL, TN) hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE, FLAG, FRAG, CR>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, \
+                                                           cur, cur_n, bound, nxt, nxt_n, TL, TN)
+                    if (pass == 0 && !all_strict) LQ_STEP(true, false, false, tie_list, tie_n);
+                    else if (pass == 0) LQ_STEP(false, true, false, tie_list, tie_n);
+                    else if (!all_strict) LQ_STEP(false, false, false, (int32_t *)nullptr, (unsigned *)nullptr);
+                    else LQ_STEP(false, false, true, (int32_t *)nullptr, (unsigned *)nullptr);
+#undef LQ_STEP
                     PMI_HIP(hipGetLastError());
                     cur = nxt; cur_n = nxt_n;
                     round++;
@@ -1473,7 +1510,7 @@ static int launch(Params p, hipStream_t s)
                 PMI_HIP(hipMemcpyAsync(&h[0], cur_n, sizeof(unsigned), hipMemcpyDeviceToHost, s));
                 if (pass == 0) PMI_HIP(hipMemcpyAsync(hw, tie_n, sizeof(hw), hipMemcpyDeviceToHost, s));
                 int64_t dn = -1;
-                if ((pass == 0 || all_strict) && first == 0 && p.d_n) PMI_HIP(hipMemcpyAsync(&dn, p.d_n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
+                if (pass == 0 && first == 0 && p.d_n) PMI_HIP(hipMemcpyAsync(&dn, p.d_n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
                 PMI_HIP(hipStreamSynchronize(s));
                 // the caller's N is a capacity when the row count lives on the device: no batch is queued past the rows that exist
                 if (dn >= 0 && dn < Ntotal) Ntotal = dn;

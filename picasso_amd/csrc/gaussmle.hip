@@ -1028,7 +1028,7 @@ int pmi_locs_from_fits_dev(const int32_t *d_frame, const int32_t *d_y, const int
 // fit B, with scratch from the inner bank; the table rows are written once both counts are known (A's rows, then
 // B's), so the capacity contract holds for the sum.
 //
-// Deferred exact stage (default, pmi_localize_set_defer): on uint16 / uint8 / int16 movies and boxes of the row-per-lane fit
+// Deferred exact stage (default, pmi_localize_set_defer): on uint16 / uint8 / int16 movies and boxes up to 7x7
 // the packed scan only emits CANDIDATES (window maximum, floor, neighbour rule) and the fit's start-value kernel, which
 // reads a candidate's rows anyway, computes the float32 net gradient in the reference's order, applies the first-argmax
 // rule and the threshold (gaussmle_g8.hip) — the scan no longer re-reads nine lines per candidate and never ends a chunk
@@ -1114,7 +1114,10 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
     // the table's rows (candidates that fail the threshold take a slot too), spread over the eight record shards
     const bool hand = g_localize_handoff && dtype == PMI_U16 && box <= 15 && mle_mode_now() != PMI_MLE_STRICT;
     // the exact stage of identify in the fit's start-value kernel instead of the scan (see above)
-    const bool defer = g_localize_defer && !hand && box <= 15 && mle_mode_now() != PMI_MLE_STRICT &&
+    // (boxes up to 7: eight lanes per candidate in the start-value kernel.  With the 16-lane groups of boxes 9 ... 15 the stage
+    // costs the fit more than it saves the scan — config 5, box 13: scan 7.0 -> 6.0 ms, fit 19.9 -> 22.0 ms — so those boxes
+    // keep it in the scan, which is bound by instruction issue there, not by its memory requests)
+    const bool defer = g_localize_defer && !hand && box <= 7 && mle_mode_now() != PMI_MLE_STRICT &&
                        (dtype == PMI_U16 || dtype == PMI_U8 || dtype == PMI_I16) && min_ng > 0.0 && std::isfinite(min_ng);
     const int64_t capc = defer ? cap + cap / 2 + 4096 : cap;         // rows of the identification / fit arrays
     int64_t cy0 = 0, cx0 = 0, cy1 = Y, cx1 = X;

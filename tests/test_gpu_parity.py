@@ -487,7 +487,9 @@ def test_gausslq_strict_mode_is_minpack_bit_for_bit(be, orc, box):
     n = 20000 if box <= 13 else 6000
     spots = _lq_adversarial_spots(box, n, 1900 + box)
     th, info, nfev = be.gausslq_arrays(spots, full_output=True)
-    assert be.last_lq_refit_count() == 0                # nothing is fitted twice in this mode
+    # (fitted twice in this mode: only a spot with a float32 rounding of its model within a few float64 ulps of a tie, which
+    # the last bit of one exp would decide — those run again with exp rounded correctly; a handful per ten million)
+    assert be.last_lq_refit_count() <= max(2, n // 1000)
     oth, oinfo, onfev = orc.gausslq(spots, full=True, threads=orc.max_threads())
     _lq_assert_identical(th, info, nfev, oth, oinfo, onfev)
 
@@ -510,13 +512,14 @@ def test_gausslq_strict_mode_on_the_fuzz_residuals_of_the_refit_mode(be, orc):
     assert total == 284
 
 
-def test_gausslq_strict_mode_floor_one_exp_in_its_last_bit(be, orc):
-    """What is left in strict mode: 2 spots of 29.2 million (tools/fuzz_parity.py 800 91 lq, 13 minutes) whose theta differs
-    from the oracle's — by 7e-5 and 8e-5 px, `info` and `nfev` equal.  Every sum is MINPACK's there; what differs is one
-    float64 exp of the Gaussian profiles in its last bit (the device's exp and glibc's are both within an ulp, neither is
-    the correctly rounded function), which flips ONE float32 rounding of the stored model (gausslq.py:203).
-    tools/probe_lq_exp.py: the oracle gives the same theta with libm's exp and with a correctly rounded one on both spots,
-    i.e. the odd bit is on the device's side.  Inside the north-star tolerance by a factor of 12; kept as inputs."""
+def test_gausslq_strict_mode_where_one_exp_decides_a_float32_rounding(be, orc):
+    """With every sum in MINPACK's order, 2 spots of 29.2 million still differed from the oracle (tools/fuzz_parity.py 800 91
+    lq, 13 minutes; 7e-5 and 8e-5 px, `info` and `nfev` equal): one float64 exp of the Gaussian profiles differs in its last
+    bit between the device's libm and glibc — both within an ulp, neither the correctly rounded function — and flips ONE
+    float32 rounding of the stored model (gausslq.py:203).  tools/probe_lq_exp.py: the oracle gives the same theta with
+    libm's exp and with a correctly rounded one on both spots, i.e. the odd bit was the device's.  The strict mode now flags
+    a profile value within 8 float64 ulps of a float32 rounding boundary and fits such a spot again with exp rounded
+    correctly (csrc/exp_cr.h): both spots are lmdif's bit for bit."""
     import glob
     import os
     files = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "lq_fuzz_regressions", "strict_exp_residual_box*.npz")))
@@ -525,8 +528,8 @@ def test_gausslq_strict_mode_floor_one_exp_in_its_last_bit(be, orc):
         spots = np.load(f)["spots"]
         th, info, nfev = be.gausslq_arrays(spots, full_output=True)
         oth, oinfo, onfev = orc.gausslq(spots, full=True)
-        assert np.array_equal(info, oinfo) and np.array_equal(nfev, onfev)
-        assert np.abs(th[:, [0, 1, 4, 5]] - oth[:, [0, 1, 4, 5]]).max() < 1e-4 and (np.abs(th[:, 2] - oth[:, 2]) / oth[:, 2]).max() < 1e-4
+        assert be.last_lq_refit_count() == len(spots)
+        _lq_assert_identical(th, info, nfev, oth, oinfo, onfev)
 
 
 @pytest.mark.parametrize("box", [3, 7, 13])

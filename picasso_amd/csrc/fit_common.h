@@ -112,6 +112,10 @@ struct FitParams {
     double min_ng;
     const int32_t *alist;        // accepted spots of the batch (absolute indices), ascending; nullptr: all spots of the batch
     const unsigned *alist_n;
+    // where the caller wants that list (N entries + the block counters of build_accept_list): a call of ONE batch builds it
+    // there, and the caller's table needs no second pass over the flags (host-side fields: the kernels do not read them)
+    int32_t *alist_out;
+    unsigned *alist_blk_out;
 };
 // why a spot goes to the re-fit (a spot can carry several)
 enum : unsigned { FLAG_MARGIN = 1u, FLAG_CURVATURE = 2u, FLAG_NARROW = 4u, FLAG_SWING = 8u, FLAG_WILD = 16u, FLAG_SLOW = 32u, FLAG_UNSTABLE = 64u };

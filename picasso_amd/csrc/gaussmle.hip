@@ -482,6 +482,7 @@ bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count
 void launch_fit_strict(const FitParams &p, int method, bool from_movie, const int32_t *list, const unsigned *list_n,
                        int64_t max_items, int cu_count, hipStream_t s);                                                    // gaussmle_strict.hip
 
+constexpr int64_t FIT_BATCH = 1 << 22;      // spots per batch of fit_impl
 // ---- the accepted candidates of a range of spots as an ascending list (deferred exact stage, fit_common.h) --------
 // three small launches: counts per block of ACC_BLOCK spots, one workgroup turns them into offsets (and the total), the
 // blocks write their spots' indices behind their offset
@@ -583,6 +584,12 @@ static thread_local const unsigned *g_last_stats[2] = {nullptr, nullptr};      /
 static thread_local unsigned g_last_stats_generation = 0;
 static thread_local bool g_stats_second = false;                                  // the fit being queued is that second range
 
+__global__ void zero_words_kernel(unsigned *__restrict__ a, int na, unsigned *__restrict__ b, int nb)
+{
+    for (int i = threadIdx.x; i < na; i += blockDim.x) a[i] = 0u;
+    for (int i = threadIdx.x; i < nb; i += blockDim.x) b[i] = 0u;
+}
+
 __global__ void flag_stats_kernel(const unsigned *__restrict__ flag_counts, int64_t nb, unsigned *__restrict__ stats)
 {
     unsigned total = 0;
@@ -617,7 +624,7 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     // Spots are processed in batches so that the Fisher scratch (168 B per spot) stays bounded;
     // every batch has its own queue words and flag counter.  With a device-side row count (d_n) the
     // batches past the count exit immediately.
-    const int64_t BATCH = 1 << 22;
+    const int64_t BATCH = FIT_BATCH;
     const int64_t nb = (p.N + BATCH - 1) / BATCH;
     void *ptr = nullptr, *fptr = nullptr;
     int rc;
@@ -635,13 +642,13 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     int32_t *acc_list = unstable_list + per_batch;
     unsigned *acc_blk = reinterpret_cast<unsigned *>(acc_list + per_batch);
     unsigned char *refit_mark = reinterpret_cast<unsigned char *>(acc_blk + acc_blocks);
-    PMI_HIP(hipMemsetAsync(ptr, 0, (size_t)nb * 32, s));
     unsigned long long *queues = (unsigned long long *)ptr;
     unsigned *flag_counts = (unsigned *)(queues + 3 * nb);           // [0, nb): flagged, [nb, 2 nb): unstable
     void *sptr = nullptr;
     if ((rc = scratch(SCR_STATS, 64, &sptr)) != PMI_OK) return rc;
     unsigned *stats = (unsigned *)sptr;
-    PMI_HIP(hipMemsetAsync(stats, 0, 64, s));
+    // (one launch for the two small blocks; the marks of the re-fit are cleared by the start-value kernel where there is one)
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, (unsigned *)ptr, (int)(nb * 8), stats, 16);
     p.flag_reasons = stats + 1;
     p.fisher = (double *)fptr;
     static const char *menv = tuning_env("PMI_MLE_MARGIN");       // overrides the margin of pmi_mle_set_mode (tuning runs)
@@ -674,7 +681,7 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         p.flag_list = mode == PMI_MLE_REFIT ? flag_list : nullptr;
         p.flag_count = flag_counts + bi;
         p.refit_mark = mode == PMI_MLE_REFIT ? refit_mark : nullptr;
-        if (p.refit_mark) PMI_HIP(hipMemsetAsync(refit_mark, 0, (size_t)(p.N - p.first), s));
+        if (p.refit_mark && !g8) PMI_HIP(hipMemsetAsync(refit_mark, 0, (size_t)(p.N - p.first), s));
         const int64_t count = p.N - p.first;
         const int64_t blocks = std::min<int64_t>((count + FIT_WAVES - 1) / FIT_WAVES, (int64_t)g_cu_count * 8);
         const dim3 grid((unsigned)std::max<int64_t>(blocks, 1));
@@ -701,9 +708,11 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
             q.spots = cut - p.first * (int64_t)(p.box * p.box);      // indexed by the absolute spot number
             if (p.ng_io) {
                 // g8_init decided the candidates: the Newton loop takes the accepted ones as a list
-                if ((rc = build_accept_list(p.accept, p.first, p.N, p.d_n, acc_blk, acc_list, s)) != PMI_OK) return rc;
-                q.alist = acc_list;
-                q.alist_n = acc_blk + (count + ACC_BLOCK - 1) / ACC_BLOCK;
+                int32_t *al = nb == 1 && p.alist_out ? p.alist_out : acc_list;
+                unsigned *ab = nb == 1 && p.alist_out ? p.alist_blk_out : acc_blk;
+                if ((rc = build_accept_list(p.accept, p.first, p.N, p.d_n, ab, al, s)) != PMI_OK) return rc;
+                q.alist = al;
+                q.alist_n = ab + (count + ACC_BLOCK - 1) / ACC_BLOCK;
             }
             launch_fit_g8(q, method, false, g_cu_count, state, FIT_STAGE_ITERATE_ONLY, s);
             PMI_HIP(hipGetLastError());
@@ -1166,10 +1175,13 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
         if (defer) {
             p.ng_io = d.ng; p.accept = d.acc; p.min_ng = min_ng;
             p.crop_y0 = (int)cy0; p.crop_x0 = (int)cx0; p.crop_cy = (int)(cy1 - cy0); p.crop_cx = (int)(cx1 - cx0);
+            p.alist_out = d.tlist; p.alist_blk_out = d.blk;
         }
         int r = fit_impl(p, method, true, st);
         if (r != PMI_OK || !defer) return r;
-        return build_accept_list(d.acc, 0, capc, d_rows, d.blk, d.tlist, st);       // the table's source rows; total at blk[nblk]
+        // the table's source rows (total at blk[nblk]): the list the fit made for its only batch, or one pass over all flags
+        if (capc <= FIT_BATCH) return PMI_OK;
+        return build_accept_list(d.acc, 0, capc, d_rows, d.blk, d.tlist, st);
     };
     const unsigned *const no_acc = nullptr;
     const int nblk_c = (int)((capc + ACC_BLOCK - 1) / ACC_BLOCK);

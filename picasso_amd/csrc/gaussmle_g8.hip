@@ -697,6 +697,7 @@ __global__ __launch_bounds__(FIT_NT) void g8_init_kernel(FitParams p, float *__r
     ms[2] = (float)(0.1 * (double)th[2]); ms[3] = (float)(0.1 * (double)th[3]);
     ms[4] = (float)(0.2 * (double)th[4]); ms[5] = (float)(0.2 * (double)th[5]);
     if (spot_ok && j == 0) {
+        if (p.refit_mark) p.refit_mark[sidx - p.first] = 0;          // set by the strict re-fit of a flagged spot (gaussmle_strict.hip)
         float4 *so = reinterpret_cast<float4 *>(state + (sidx - p.first) * 12);
         so[0] = make_float4(th[0], th[1], th[2], th[3]);
         so[1] = make_float4(th[4], th[5], ms[0], ms[1]);

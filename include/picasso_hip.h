@@ -237,8 +237,10 @@ int pmi_net_gradient(const float *image, int64_t Y, int64_t X, const int32_t *y,
  * squares model is point-sampled on the grid -r..r, gausslq.py:228).  info /
  * nfev (N, int32, may be NULL) are MINPACK's termination code and the number of
  * residual evaluations, what leastsq(full_output=1) would report.
- * The _dev forms queue five rounds of (Jacobian, step) and then WAIT for the stream once per batch of 2 Mi spots to
- * read how many fits need more (on photon data: none); they are asynchronous up to that point only.
+ * The _dev forms never wait for their stream (round 4): per batch of 2 Mi spots they queue the start values, five rounds
+ * of (Jacobian + QR, step) — more for boxes above 7x7 —, one kernel that finishes on the device whatever fit is still
+ * running, and the second pass of the mode over a device-side list; every count stays on the device.
+ * pmi_localize_lq_dev keeps two frame ranges in flight like pmi_localize_mle_dev (pmi_localize_set_ranges).
  * Arithmetic (modes below): MINPACK adds the box^2 residual rows of a column norm, a Householder product or Q^T f one
  * after the other; tree reductions over the lanes of a spot's group differ from that in the last bits of float64, which
  * matters where one of lmdif's tests (the gain ratio against 1e-4 / 0.25 / 0.75, the termination tests, lmpar's 10 %

@@ -869,141 +869,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E, STRICT)
         const int64_t w = store ? w0 + grp : items - 1;
         const int64_t s = list ? (int64_t)list[w] : st.first + w;
         const int64_t ls = s - st.first;
-        // ---- the spot: rows of this lane ----
-        float sp[E];
-        if (FROM_MOVIE) {
-            const int64_t fr = p.frame[s], y0 = p.y[s] - hsz, x0 = p.x[s] - hsz;
-#pragma unroll
-            for (int e = 0; e < E; e++) {
-                sp[e] = 0.f;
-                if (act[e]) {
-                    const float raw = load_movie_px(p.movie, p.dtype, (fr * p.Y + (y0 + ri[e])) * p.X + (x0 + rj[e]));
-                    sp[e] = div_const((raw - p.baseline) * p.sensitivity, p.gdiv);
-                }
-            }
-        } else {
-#pragma unroll
-            for (int e = 0; e < E; e++) sp[e] = act[e] ? p.spots[s * m + lane + GS * e] : 0.f;
-        }
-
-        double x[6];
-#pragma unroll
-        for (int j = 0; j < 6; j++) x[j] = LQD(st, j, ls);
-
-        double a[STRICT ? 7 : 6][E], w4[E];
-        float fv[E], fp[E];                   // residuals at x and at the perturbed x (float32 values, gausslq.py:203)
-        double wa1[6], wa2[6], wa3[6];
-        int ipvt[6];
-        float prof0[GS == 8 ? 2 : 1], profj[GS == 8 ? 2 : 1];
-        unsigned fragile = 0u;
-        profiles<GS, CR>(x, size, lane, 3, prof0, fragile);
-        residuals<GS, E>(x, prof0, sp, ri, rj, act, size, lane, fv);
-        // fdjac2
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const double temp = x[j];
-            double hstep = eps * fabs(temp);
-            if (hstep == 0) hstep = eps;
-            x[j] = temp + hstep;
-#pragma unroll
-            for (int k = 0; k < (GS == 8 ? 2 : 1); k++) profj[k] = prof0[k];
-            // x0, sx move the x profile, y0, sy the y profile, photons and background neither
-            if (j == 0 || j == 4) profiles<GS, CR>(x, size, lane, GS == 8 ? 1 : 3, profj, fragile);
-            if (j == 1 || j == 5) profiles<GS, CR>(x, size, lane, GS == 8 ? 2 : 3, profj, fragile);
-            residuals<GS, E>(x, profj, sp, ri, rj, act, size, lane, fp);
-            x[j] = temp;
-#pragma unroll
-            for (int e = 0; e < E; e++) a[j][e] = ((double)fp[e] - (double)fv[e]) / hstep;
-        }
-        // qrfac with column pivoting: rdiag = wa1, acnorm = wa2, wa = wa3
-        bool tie = false;
-        if constexpr (STRICT) {
-            // every sum over the rows in MINPACK's order; the six column norms as six chains side by side
-            const int MP = (m + 1) & ~1;
-            unsigned oddmask = 0;
-#pragma unroll
-            for (int c = 0; c < 6; c++) {
-                col_to_lds<GS, E>(a[c], lane, 0, m, sbuf + (size_t)c * MP);
-                oddmask |= Grp<GS>::any(col_is_odd<GS, E>(a[c], lane, 0, m)) ? 1u << c : 0u;
-            }
-            grp_sync();
-            const int myc = lane < 6 ? lane : 5;
-            const double mynorm = chain_enorm(sbuf + (size_t)myc * MP, MP, m, (oddmask >> myc) & 1u);
-            grp_sync();
-#pragma unroll
-            for (int j = 0; j < 6; j++) {
-                wa2[j] = Grp<GS>::bcast_d(mynorm, j);
-                wa1[j] = wa2[j];
-                wa3[j] = wa1[j];
-                ipvt[j] = j;
-            }
-            double (&a7)[7][E] = a;
-#pragma unroll
-            for (int e = 0; e < E; e++) a7[6][e] = (double)fv[e];
-            qrfac_strict_step<GS, E, 0>(a7, wa1, wa3, ipvt, lane, m, sbuf);
-            qrfac_strict_step<GS, E, 1>(a7, wa1, wa3, ipvt, lane, m, sbuf);
-            qrfac_strict_step<GS, E, 2>(a7, wa1, wa3, ipvt, lane, m, sbuf);
-            qrfac_strict_step<GS, E, 3>(a7, wa1, wa3, ipvt, lane, m, sbuf);
-            qrfac_strict_step<GS, E, 4>(a7, wa1, wa3, ipvt, lane, m, sbuf);
-            qrfac_strict_step<GS, E, 5>(a7, wa1, wa3, ipvt, lane, m, sbuf);
-            // R: row i in lane i; (Q^T fvec)[j] in lane j of the residual column
-#pragma unroll
-            for (int j = 0; j < 6; j++)
-                if (lane == j) a[j][0] = wa1[j];
-#pragma unroll
-            for (int e = 0; e < E; e++) w4[e] = a7[6][e];
-        } else {
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            wa2[j] = enorm_rows<GS, E>(a[j], lane, 0, m);
-            wa1[j] = wa2[j];
-            wa3[j] = wa1[j];
-            ipvt[j] = j;
-        }
-        qrfac_step<GS, E, 0, false>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
-        qrfac_step<GS, E, 1, false>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
-        qrfac_step<GS, E, 2, false>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
-        qrfac_step<GS, E, 3, false>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
-        qrfac_step<GS, E, 4, false>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
-        qrfac_step<GS, E, 5, false>(a, wa1, wa3, ipvt, lane, m, sbuf, tie);
-        {
-            // a column of which less than LQ_RANK survives the projection on the columns before it: the Jacobian is
-            // close to rank deficient, the Gauss-Newton step amplifies the last bits of R and Q^T f by 1 / that ratio, and
-            // every later decision inherits the difference (a width that collapses or turns negative, nine residuals
-            // for six parameters): the sums' order decides the fit although no single test is close to its threshold
-#pragma unroll
-            for (int j = 0; j < 6; j++) tie = tie || !(fabs(wa1[j]) > LQ_RANK * get6(wa2, ipvt[j]));
-        }
-        // (Q^T fvec)[0..6): row j of the transformed vector ends in lane j; R: row i in lane i
-#pragma unroll
-        for (int e = 0; e < E; e++) w4[e] = (double)fv[e];
-#pragma unroll
-        for (int j = 0; j < 6; j++) {
-            const double ajj = Grp<GS>::bcast_d(a[j][0], j);
-            if (ajj != 0) {
-                double sum = 0;
-#pragma unroll
-                for (int e = 0; e < E; e++)
-                    if (e > 0 || lane >= j) sum += a[j][e] * w4[e];
-                sum = Grp<GS>::sum_d(sum);
-                const double temp = -sum / ajj;
-#pragma unroll
-                for (int e = 0; e < E; e++)
-                    if (e > 0 || lane >= j) w4[e] += a[j][e] * temp;
-            }
-            if (lane == j) a[j][0] = wa1[j];
-        }
-        }
-        const bool frag_any = STRICT && !CR && Grp<GS>::any(fragile != 0u);       // (every lane of the group takes part in the vote)
-        if (store && lane < 6) {
-#pragma unroll
-            for (int j = 0; j < 6; j++) LQD(st, 16 + lane * 6 + j, ls) = lane <= j ? a[j][0] : 0.0;
-            LQD(st, 52 + lane, ls) = w4[0];
-            LQD(st, 58 + lane, ls) = get6(wa2, lane);
-            LQI(st, lane, ls) = lane == 0 ? ipvt[0] : (lane == 1 ? ipvt[1] : (lane == 2 ? ipvt[2] : (lane == 3 ? ipvt[3] : (lane == 4 ? ipvt[4] : ipvt[5]))));
-            if (!STRICT && tie && lane == 0) LQI(st, 9, ls) = LQI(st, 9, ls) | 1;
-            if (frag_any && lane == 0) LQI(st, 9, ls) = LQI(st, 9, ls) | 128;
-        }
+#include "lq_jacobian_body.inc"
     }
 }
 
@@ -1061,6 +927,7 @@ __global__ __launch_bounds__(256) void lq_init_kernel(Params p, LqState st, int6
     int64_t n = p.N;
     if (p.d_n) { const int64_t dn = *p.d_n; n = dn < n ? dn : n; }
     if (list) { const int64_t ln = (int64_t)*list_n; count = ln < count ? ln : count; }
+    if ((int64_t)blockIdx.x * blockDim.x >= count) return;             // (the grid is sized for the worst case of a device-side list)
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];      // [256] spot indices, then the tile of 256 x m floats
     int64_t (&s_idx)[256] = *reinterpret_cast<int64_t (*)[256]>(s_dyn);
     float *s_tile = reinterpret_cast<float *>(s_dyn + 256 * sizeof(int64_t));
@@ -1126,36 +993,17 @@ constexpr int LQ_STEP_NT = 64;        // one wave per workgroup: 7.58 -> 7.46 ms
 
 // (b): one spot per lane — the Levenberg-Marquardt step(s) on the factor lq_jacobian_kernel left, until the fit ends
 // or needs a new Jacobian.  Spots that go on are appended to next_list.
+// (b) for ONE spot per lane: the Levenberg-Marquardt step(s) on the factor lq_jacobian_spot left, until the fit ends (theta,
+// info, nfev written; returns info > 0) or needs a new Jacobian (state written; returns 0).  `tie`: the decision flags.
 // FLAG: every decision is also tested against a band around its threshold (the spots of the first pass of the refit mode)
-// FRAG: a profile value whose float32 rounding hangs on the last bits of exp sends the spot to the tie list (first pass of the
-//       strict mode);  CR: exp rounded correctly (its second pass)
-template <bool FROM_MOVIE, bool FLAG, bool FRAG = false, bool CR = false>
-__global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(Params p, LqState st, const int32_t *__restrict__ list,
-                                                             const unsigned *__restrict__ list_n, int64_t count,
-                                                             int32_t *__restrict__ next_list, unsigned *__restrict__ next_n,
-                                                             int32_t *__restrict__ tie_list, unsigned *__restrict__ tie_n)
+// FRAG: a profile value whose float32 rounding hangs on the last bits of exp sets bit 7 (first pass of the strict mode);
+// CR: exp rounded correctly (its second pass)
+template <bool FROM_MOVIE, bool FLAG, bool FRAG, bool CR>
+__device__ __forceinline__ int lq_step_spot(const Params &p, const LqState &st, int64_t s, int info, bool flagging, const float *mytile,
+                                            float (*s_px)[LQ_STEP_NT], int tid, bool staged, unsigned &tie)
 {
-    // dynamic LDS: [NT] spot indices, the x profile of the current evaluation (box x NT floats), the tile of NT x m floats
-    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
-    int64_t (&s_idx)[LQ_STEP_NT] = *reinterpret_cast<int64_t (*)[LQ_STEP_NT]>(s_dyn);
-    float (*s_px)[LQ_STEP_NT] = reinterpret_cast<float (*)[LQ_STEP_NT]>(s_dyn + LQ_STEP_NT * sizeof(int64_t));
-    float *s_tile = reinterpret_cast<float *>(s_dyn + LQ_STEP_NT * sizeof(int64_t) + (size_t)p.box * LQ_STEP_NT * sizeof(float));
-    int64_t n = p.N;
-    if (p.d_n) { const int64_t dn = *p.d_n; n = dn < n ? dn : n; }
-    const int64_t items = list ? (int64_t)*list_n : (st.first + count < n ? count : n - st.first);
-    const int64_t w = (int64_t)blockIdx.x * LQ_STEP_NT + threadIdx.x;
-    if ((int64_t)blockIdx.x * LQ_STEP_NT >= items) return;   // the whole workgroup is past the list
     const int size = p.box, m = size * size, hsz = size / 2;
-    const int tid = threadIdx.x;
-    const bool staged = m <= LQ_TILE_MAXPIX;
-    const int64_t s = w < items ? (list ? (int64_t)list[w] : st.first + w) : -1;
     const int64_t ls = s - st.first;
-    int info = s >= 0 ? LQI(st, 8, ls) : 1;
-    s_idx[tid] = info > 0 ? -1 : s;
-    __syncthreads();
-    if (staged) { stage_spots<FROM_MOVIE, LQ_STEP_NT>(p, s_idx, s_tile, m, size); __syncthreads(); }
-    if (info > 0) return;
-    const float *mytile = s_tile + (size_t)tid * m;
     const double ftol = 1e-2, xtol = 1e-2, gtol = 0.0, factor = 100.0;
     const int maxfev = 200 * (6 + 1);
     int64_t fr = 0, y0 = 0, x0 = 0;
@@ -1221,7 +1069,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
     // tie: a decision of this fit fell within LQ_TIE of its threshold — here, in lmpar or in the pivoting of the Jacobian
     // kernel (slot 9).  The group kernel's tree sums differ from MINPACK's sequential ones in the last bits of float64,
     // so such a decision may be MINPACK's other branch: the spot is fitted again with sequential sums (tie_list).
-    unsigned tie = (FLAG || FRAG) && tie_list ? (unsigned)LQI(st, 9, ls) : 0u;       // bit 0: the pivot choice of the Jacobian kernel; 1: lmpar; 2..6 below
+    tie = (FLAG || FRAG) && flagging ? (unsigned)LQI(st, 9, ls) : 0u;       // bit 0: the pivot choice of the Jacobian kernel; 1: lmpar; 2..6 below
     double gnorm = 0, fnorm1, actred, prered, dirder, ratio, pnorm;
     if (iter == 1) {
 #pragma unroll
@@ -1322,18 +1170,136 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
         if (p.info) p.info[s] = info;
         if (p.nfev) p.nfev[s] = nfev;
         LQI(st, 8, ls) = info;
+    } else {
+#pragma unroll
+        for (int j = 0; j < 6; j++) { LQD(st, j, ls) = x[j]; LQD(st, 6 + j, ls) = diag[j]; }
+        LQD(st, 12, ls) = fnorm; LQD(st, 13, ls) = delta; LQD(st, 14, ls) = par; LQD(st, 15, ls) = xnorm;
+        LQI(st, 6, ls) = iter; LQI(st, 7, ls) = nfev; LQI(st, 8, ls) = 0;
+        if ((FLAG || FRAG) && tie && flagging) LQI(st, 9, ls) = (int32_t)tie;
+    }
+    return info;
+}
+
+template <bool FROM_MOVIE, bool FLAG, bool FRAG = false, bool CR = false>
+__global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(Params p, LqState st, const int32_t *__restrict__ list,
+                                                             const unsigned *__restrict__ list_n, int64_t count,
+                                                             int32_t *__restrict__ next_list, unsigned *__restrict__ next_n,
+                                                             int32_t *__restrict__ tie_list, unsigned *__restrict__ tie_n)
+{
+    // dynamic LDS: [NT] spot indices, the x profile of the current evaluation (box x NT floats), the tile of NT x m floats
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+    int64_t (&s_idx)[LQ_STEP_NT] = *reinterpret_cast<int64_t (*)[LQ_STEP_NT]>(s_dyn);
+    float (*s_px)[LQ_STEP_NT] = reinterpret_cast<float (*)[LQ_STEP_NT]>(s_dyn + LQ_STEP_NT * sizeof(int64_t));
+    float *s_tile = reinterpret_cast<float *>(s_dyn + LQ_STEP_NT * sizeof(int64_t) + (size_t)p.box * LQ_STEP_NT * sizeof(float));
+    int64_t n = p.N;
+    if (p.d_n) { const int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+    const int64_t items = list ? (int64_t)*list_n : (st.first + count < n ? count : n - st.first);
+    const int64_t w = (int64_t)blockIdx.x * LQ_STEP_NT + threadIdx.x;
+    if ((int64_t)blockIdx.x * LQ_STEP_NT >= items) return;   // the whole workgroup is past the list
+    const int size = p.box, m = size * size;
+    const int tid = threadIdx.x;
+    const bool staged = m <= LQ_TILE_MAXPIX;
+    const int64_t s = w < items ? (list ? (int64_t)list[w] : st.first + w) : -1;
+    const int64_t ls = s - st.first;
+    int info = s >= 0 ? LQI(st, 8, ls) : 1;
+    s_idx[tid] = info > 0 ? -1 : s;
+    __syncthreads();
+    if (staged) { stage_spots<FROM_MOVIE, LQ_STEP_NT>(p, s_idx, s_tile, m, size); __syncthreads(); }
+    if (info > 0) return;
+    const float *mytile = s_tile + (size_t)tid * m;
+    unsigned tie = 0u;
+    info = lq_step_spot<FROM_MOVIE, FLAG, FRAG, CR>(p, st, s, info, tie_list != nullptr, mytile, s_px, tid, staged, tie);
+    if (info != 0) {
         if ((FLAG || FRAG) && tie && tie_list) {
             tie_list[atomicAdd(tie_n, 1u)] = (int32_t)s;
             for (int b = 0; b < 7; b++)
                 if (tie & (1u << b)) atomicAdd(tie_n + 1 + b, 1u);      // why (diagnostics: pmi_gausslq_last_tie_reasons)
         }
     } else {
-#pragma unroll
-        for (int j = 0; j < 6; j++) { LQD(st, j, ls) = x[j]; LQD(st, 6 + j, ls) = diag[j]; }
-        LQD(st, 12, ls) = fnorm; LQD(st, 13, ls) = delta; LQD(st, 14, ls) = par; LQD(st, 15, ls) = xnorm;
-        LQI(st, 6, ls) = iter; LQI(st, 7, ls) = nfev; LQI(st, 8, ls) = 0;
-        if ((FLAG || FRAG) && tie && tie_list) LQI(st, 9, ls) = (int32_t)tie;
         next_list[atomicAdd(next_n, 1u)] = (int32_t)s;
+    }
+}
+
+// ---- the fits the rounds have left, finished on the device ------------------------------------------------------
+// MINPACK's loop has no bound a host could queue ahead of (maxfev = 1400: up to 200 rounds), and asking the device how many
+// spots are left costs a synchronisation per look.  After the rounds that finish every fit of photon data, ONE launch of
+// this kernel takes whatever is still running — and the whole second pass of the refit / strict modes, whose list lives on
+// the device: every wavefront owns chunks of 64 spots of the list and alternates (a) and (b) for them, eight... one spot per
+// Jacobian (the widest lane group serves every box; the sums in MINPACK's order whatever the mode: those bits do not
+// depend on the lane layout), one spot per lane in the step, until none of its spots is running.  Nothing in here waits for
+// another wavefront.
+constexpr int LQ_FIN_GS = 64, LQ_FIN_E = 7;
+template <bool CR, bool FLAG, bool FRAG, bool STRICT = true>       // (STRICT a parameter so that the tree-sum branch of the body is discarded)
+__global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_finish_kernel(Params p, LqState st, const int32_t *__restrict__ list,
+                                                                                  const unsigned *__restrict__ list_n,
+                                                                                  int32_t *__restrict__ tie_list, unsigned *__restrict__ tie_n)
+{
+    constexpr int GS = LQ_FIN_GS, E = LQ_FIN_E;
+    constexpr bool FROM_MOVIE = false;
+    static_assert(STRICT, "the finishing kernel adds in MINPACK's order");
+    // dynamic LDS: [64] spot indices, the x profile of the current evaluation (box x 64 floats), the tile of 64 x m floats
+    // (boxes up to 9), the chains' 6 columns of box^2 (+ 1) doubles
+    extern __shared__ __attribute__((aligned(16))) char s_dyn[];
+    const int size = p.box, m = size * size, hsz = size / 2;
+    const bool staged = m <= LQ_TILE_MAXPIX;
+    int64_t (&s_idx)[LQ_STEP_NT] = *reinterpret_cast<int64_t (*)[LQ_STEP_NT]>(s_dyn);
+    float (*s_px)[LQ_STEP_NT] = reinterpret_cast<float (*)[LQ_STEP_NT]>(s_dyn + LQ_STEP_NT * sizeof(int64_t));
+    float *s_tile = reinterpret_cast<float *>(s_dyn + LQ_STEP_NT * sizeof(int64_t) + (size_t)size * LQ_STEP_NT * sizeof(float));
+    double *sbuf = reinterpret_cast<double *>(s_dyn + ((LQ_STEP_NT * sizeof(int64_t) + (size_t)size * LQ_STEP_NT * sizeof(float) +
+                                                         (staged ? (size_t)LQ_STEP_NT * m * sizeof(float) : 0) + 15) & ~(size_t)15));
+    const int tid = threadIdx.x, lane = tid;                   // one group = the wavefront
+    const int64_t items = (int64_t)*list_n;
+    int ri[E], rj[E];
+    bool act[E];
+#pragma unroll
+    for (int e = 0; e < E; e++) {
+        const int r = lane + GS * e;
+        act[e] = r < m;
+        const int rr = act[e] ? r : 0;
+        ri[e] = rr / size;
+        rj[e] = rr - ri[e] * size;
+    }
+    const double eps = sqrt(1.1920928955078125e-07);
+    // a wavefront works its spots' Jacobians off one after the other: a short list is spread over all the wavefronts (K spots
+    // each, the other lanes idle in the step) rather than packed 64 to a wavefront
+    const int K = (int)std::min<int64_t>(LQ_STEP_NT, std::max<int64_t>(1, (items + gridDim.x - 1) / gridDim.x));
+    for (int64_t base = (int64_t)blockIdx.x * K; base < items; base += (int64_t)gridDim.x * K) {
+        const int64_t w = base + tid;
+        const int64_t s_mine = (tid < K && w < items) ? (int64_t)list[w] : -1;
+        int info = s_mine >= 0 ? LQI(st, 8, s_mine - st.first) : 1;            // -1 fresh, 0 running, > 0 done
+        __syncthreads();
+        s_idx[tid] = info > 0 ? -1 : s_mine;
+        __syncthreads();
+        if (staged) { stage_spots<FROM_MOVIE, LQ_STEP_NT>(p, s_idx, s_tile, m, size); __syncthreads(); }
+        const float *mytile = s_tile + (size_t)tid * m;
+        bool running = info <= 0;
+        for (;;) {
+            const unsigned long long run = __ballot(running);
+            if (run == 0ull) break;
+            // (a) a Jacobian for every running spot, one after the other
+            for (unsigned long long rest = run; rest != 0ull; rest &= rest - 1ull) {
+                const int src = (int)__builtin_ctzll(rest);
+                const int64_t s = (int64_t)__builtin_amdgcn_readlane((int)s_mine, src);      // spot indices are below 2^31
+                const int64_t ls = s - st.first;
+                const bool store = true;
+#include "lq_jacobian_body.inc"
+            }
+            __threadfence();                                   // the factors the lanes above wrote, read by the lane of each spot below
+            // (b) the step of every running spot
+            if (running) {
+                unsigned tie = 0u;
+                info = lq_step_spot<FROM_MOVIE, FLAG, FRAG, CR>(p, st, s_mine, info, tie_list != nullptr, mytile, s_px, tid, staged, tie);
+                if (info != 0) {
+                    running = false;
+                    if ((FLAG || FRAG) && tie && tie_list) {
+                        tie_list[atomicAdd(tie_n, 1u)] = (int32_t)s_mine;
+                        for (int b = 0; b < 7; b++)
+                            if (tie & (1u << b)) atomicAdd(tie_n + 1 + b, 1u);
+                    }
+                }
+            }
+            __threadfence();                                   // ... and the state a step left, read by the next Jacobian
+        }
     }
 }
 
@@ -1381,16 +1347,10 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
 #undef LQ_JAC
 }
 
-// Rounds of (Jacobian + QR, step) over the spots still running.  The first LQ_ROUNDS rounds are queued without
-// looking at the device; then the stream is synchronised once to read how many spots go on (on photon data: none —
-// a fit takes 2-4 outer iterations) and the stragglers get rounds of their own size until none is left.  The same
-// synchronisation returns the number of spots with a decision inside rounding distance of its threshold (tie list):
-// those are started again and fitted with MINPACK's summation order (strict Jacobian kernel), rounds sized to the list.
+// Rounds of (Jacobian + QR, step) over the spots still running that are queued before the finishing kernel takes over (boxes
+// up to 7x7; more for larger boxes, see launch)
 #ifndef LQ_ROUNDS
 #define LQ_ROUNDS 5
-#endif
-#ifndef LQ_STRAGGLER_BURST
-#define LQ_STRAGGLER_BURST 24
 #endif
 #ifndef LQ_BATCH_LOG2
 #define LQ_BATCH_LOG2 21      // spots per batch (state: 552 B per spot); every batch ends with one host synchronisation
@@ -1409,9 +1369,24 @@ static int lq_mode_now()
     }
     return g_lq_mode;
 }
-static thread_local int64_t g_last_lq_strict = 0;       // spots of the calling thread's last fit that were fitted again
-static thread_local int64_t g_last_lq_why[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};      // [7], [8]: rounds queued in the first / second pass
+// statistics of the calling thread's last fit: a device buffer of its own ([0] spots fitted again, [1..7] why), read when asked for
+static thread_local const unsigned *g_lq_stats[2] = {nullptr, nullptr};          // [1]: the second frame range of a fused call
+static thread_local unsigned g_lq_stats_generation = 0;
+static thread_local hipStream_t g_lq_stats_stream[2] = {nullptr, nullptr};
+static thread_local bool g_lq_stats_second = false;                               // the fit being queued is that second range
+static thread_local int g_lq_rounds[2] = {0, 0};
 
+__global__ void lq_stats_add_kernel(const unsigned *__restrict__ tie_n, unsigned *__restrict__ stats, int refitted)
+{
+    if (threadIdx.x == 0 && refitted) stats[0] += tie_n[0];
+    if (threadIdx.x >= 1 && threadIdx.x < 8) stats[threadIdx.x] += tie_n[threadIdx.x];
+}
+
+// One call = batches of 2 Mi spots; a batch = start values, LQ_ROUNDS rounds of (Jacobian + QR, step) over the spots
+// still running — on photon data every fit is done by then —, one launch of lq_finish_kernel for whatever is left, then
+// the second pass of the mode (refit: the spots with a decision near its threshold; strict: those with a float32
+// rounding that hangs on the last bit of an exp) as start values + one lq_finish_kernel over the tie list.  Every
+// count lives on the device: nothing here waits for the stream.
 template <bool FROM_MOVIE_IN>
 static int launch(Params p, hipStream_t s)
 {
@@ -1420,12 +1395,15 @@ static int launch(Params p, hipStream_t s)
     (void)hipGetDevice(&dev);
     (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
     const int64_t BATCH = (int64_t)1 << LQ_BATCH_LOG2;
-    int64_t Ntotal = p.N;
+    const int64_t Ntotal = p.N;                    // a capacity when the row count lives on the device: batches past the rows exit at once
     const int64_t cap = std::min<int64_t>(Ntotal, BATCH);
-    void *ptr = nullptr;
+    void *ptr = nullptr, *sptr = nullptr;
     int rc;
     const size_t bytes = (size_t)cap * (LQ_NSD * sizeof(double) + LQ_NSI * sizeof(int32_t) + 3 * sizeof(int32_t)) + 2048;
     if ((rc = scratch(SCR_STAGE_D, bytes, &ptr)) != PMI_OK) return rc;
+    if ((rc = scratch(SCR_LQ_STATS, 64, &sptr)) != PMI_OK) return rc;
+    unsigned *stats = (unsigned *)sptr;
+    PMI_HIP(hipMemsetAsync(stats, 0, 64, s));
     LqState st;
     st.d = (double *)ptr;
     st.i = (int32_t *)(st.d + (size_t)cap * LQ_NSD);
@@ -1434,6 +1412,7 @@ static int launch(Params p, hipStream_t s)
     int32_t *tie_list = st.i + (size_t)cap * (LQ_NSI + 2);
     unsigned *counters = (unsigned *)(tie_list + cap);           // one per round + the tie counter, zeroed per batch
     constexpr int NCTR = 64;
+    static_assert(LQ_ROUNDS >= 1 && LQ_ROUNDS + 7 <= NCTR, "one counter per round");
     unsigned *tie_n = counters + NCTR;
     const int mode = lq_mode_now();
     const bool no_strict = mode == PMI_LQ_FAST, all_strict = mode == PMI_LQ_STRICT;
@@ -1444,11 +1423,15 @@ static int launch(Params p, hipStream_t s)
         if ((rc = scratch(SCR_STAGE_C, (size_t)cap * mpix * sizeof(float), &cptr)) != PMI_OK) return rc;
         cut = (float *)cptr;
     }
-    const size_t init_lds = 256 * sizeof(int64_t) + (mpix <= LQ_TILE_MAXPIX ? (size_t)256 * mpix * sizeof(float) : 0);
+    const bool staged = mpix <= LQ_TILE_MAXPIX;
+    const size_t init_lds = 256 * sizeof(int64_t) + (staged ? (size_t)256 * mpix * sizeof(float) : 0);
     const size_t step_lds = LQ_STEP_NT * sizeof(int64_t) + (size_t)p.box * LQ_STEP_NT * sizeof(float) +
-                            (mpix <= LQ_TILE_MAXPIX ? (size_t)LQ_STEP_NT * mpix * sizeof(float) : 0);
-    g_last_lq_strict = 0;
-    for (int64_t &v : g_last_lq_why) v = 0;
+                            (staged ? (size_t)LQ_STEP_NT * mpix * sizeof(float) : 0);
+    const size_t fin_lds = ((step_lds + 15) & ~(size_t)15) + (size_t)6 * ((mpix + 1) & ~1) * sizeof(double);
+    const dim3 fin_grid((unsigned)std::min<int64_t>((int64_t)cus * 8, std::max<int64_t>(1, cap)));
+    // rounds queued before the finishing kernel: a fit of an n x n box takes (nfev - 1) / 7 of them — 2 to 4 at 7x7 (none left
+    // after five), up to ten at 13x13, where the finishing kernel's one spot per Jacobian would be the slower way for many
+    const int rounds = p.box <= 7 ? LQ_ROUNDS : (p.box <= 9 ? LQ_ROUNDS + 1 : (p.box <= 13 ? LQ_ROUNDS + 4 : LQ_ROUNDS + 7));
     for (int64_t first = 0; first < Ntotal; first += BATCH) {
         const int64_t count = std::min<int64_t>(BATCH, Ntotal - first);
         st.first = first;
@@ -1460,65 +1443,57 @@ static int launch(Params p, hipStream_t s)
         PMI_HIP(hipMemsetAsync(counters, 0, (NCTR + 8) * sizeof(unsigned), s));
         hipLaunchKernelGGL((lq_init_kernel<FROM_MOVIE>), dim3((unsigned)((count + 255) / 256)), dim3(256), init_lds, s, p, st, count,
                            (const int32_t *)nullptr, (const unsigned *)nullptr);
-        // pass 0: every spot of the batch, tree sums, decisions near a threshold collected in tie_list;
-        // pass 1: the spots of tie_list again from their start values, sequential sums, no flagging
-        unsigned hw[8] = {0, 0, 0, 0, 0, 0, 0, 0};                   // tie count and its reasons, read with the first pass's last look at the stream
-        // strict mode: pass 0 = every spot with the sequential sums, flagging the spots on which a float32 rounding of the
-        // model hangs on the last bit of an exp (a handful per ten million); pass 1 = those again with exp rounded correctly
-        for (int pass = 0; pass < 2; pass++) {
-            const int32_t *cur = pass == 0 ? nullptr : tie_list;
-            const unsigned *cur_n = pass == 0 ? nullptr : tie_n;
-            int64_t bound = count;                                   // spots the next round may hold
-            unsigned h[3] = {0, 0, 0};                               // spots left, spots tied, (first batch) device row count
-            if (pass == 1) {
-                h[1] = hw[0];
-                for (int b = 0; b < 7; b++) g_last_lq_why[b] += hw[1 + b];
-                if (h[1] == 0 || no_strict) break;
-                bound = h[1];
-                g_last_lq_strict += bound;
-                hipLaunchKernelGGL((lq_init_kernel<FROM_MOVIE>), dim3((unsigned)((bound + 255) / 256)), dim3(256), init_lds, s, p, st, bound,
-                                   (const int32_t *)tie_list, (const unsigned *)tie_n);
-                PMI_HIP(hipMemsetAsync(counters, 0, NCTR * sizeof(unsigned), s));
-            }
-            // rounds are queued in bursts and the stream is read only after a burst: LQ_ROUNDS rounds at first (on photon
-            // data every fit is done by then), afterwards LQ_STRAGGLER_BURST rounds sized to the spots that are left —
-            // a round over an empty list costs two launches that exit at once, a synchronisation per round cost more
-            // than the rounds themselves (degenerate fits take up to 200 of them: maxfev = 1400)
-            int round = 0, burst = LQ_ROUNDS;
-            for (;;) {
-                for (int q = 0; q < burst; q++) {
-                    int32_t *nxt = lists[round & 1];
-                    unsigned *nxt_n = counters + (round % NCTR);
-                    if (round >= NCTR) PMI_HIP(hipMemsetAsync(nxt_n, 0, sizeof(unsigned), s));
-                    if (pass == 0 && !all_strict) launch_jacobian<FROM_MOVIE, false>(p, st, cur, cur_n, bound, cus, s);
-                    else if (pass == 0) launch_jacobian<FROM_MOVIE, true>(p, st, cur, cur_n, bound, cus, s);
-                    else if (!all_strict) launch_jacobian<FROM_MOVIE, true>(p, st, cur, cur_n, bound, cus, s);
-                    else launch_jacobian<FROM_MOVIE, true, true>(p, st, cur, cur_n, bound, cus, s);
-                    const unsigned sb = (unsigned)((bound + LQ_STEP_NT - 1) / LQ_STEP_NT);
-#define LQ_STEP(FLAG, FRAG, CR, TL, TN) hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE, FLAG, FRAG, CR>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, \
-                                                           cur, cur_n, bound, nxt, nxt_n, TL, TN)
-                    if (pass == 0 && !all_strict) LQ_STEP(true, false, false, tie_list, tie_n);
-                    else if (pass == 0) LQ_STEP(false, true, false, tie_list, tie_n);
-                    else if (!all_strict) LQ_STEP(false, false, false, (int32_t *)nullptr, (unsigned *)nullptr);
-                    else LQ_STEP(false, false, true, (int32_t *)nullptr, (unsigned *)nullptr);
-#undef LQ_STEP
-                    PMI_HIP(hipGetLastError());
-                    cur = nxt; cur_n = nxt_n;
-                    round++;
-                    g_last_lq_why[7 + pass]++;
-                }
-                PMI_HIP(hipMemcpyAsync(&h[0], cur_n, sizeof(unsigned), hipMemcpyDeviceToHost, s));
-                if (pass == 0) PMI_HIP(hipMemcpyAsync(hw, tie_n, sizeof(hw), hipMemcpyDeviceToHost, s));
-                int64_t dn = -1;
-                if (pass == 0 && first == 0 && p.d_n) PMI_HIP(hipMemcpyAsync(&dn, p.d_n, sizeof(int64_t), hipMemcpyDeviceToHost, s));
-                PMI_HIP(hipStreamSynchronize(s));
-                // the caller's N is a capacity when the row count lives on the device: no batch is queued past the rows that exist
-                if (dn >= 0 && dn < Ntotal) Ntotal = dn;
-                if (h[0] == 0) break;
-                bound = h[0];
-                burst = LQ_STRAGGLER_BURST;
-            }
+        // ---- pass 0: every spot of the batch (refit / fast: tree sums, decisions near a threshold collected in tie_list;
+        // strict: MINPACK's order, fragile float32 roundings collected there)
+        const int32_t *cur = nullptr;
+        const unsigned *cur_n = nullptr;
+        for (int round = 0; round < rounds; round++) {
+            int32_t *nxt = lists[round & 1];
+            unsigned *nxt_n = counters + round;
+            if (all_strict) launch_jacobian<FROM_MOVIE, true>(p, st, cur, cur_n, count, cus, s);
+            else launch_jacobian<FROM_MOVIE, false>(p, st, cur, cur_n, count, cus, s);
+            const unsigned sb = (unsigned)((count + LQ_STEP_NT - 1) / LQ_STEP_NT);
+            if (all_strict)
+                hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE, false, true, false>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, cur, cur_n, count,
+                                   nxt, nxt_n, tie_list, tie_n);
+            else
+                hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE, true, false, false>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, cur, cur_n, count,
+                                   nxt, nxt_n, tie_list, tie_n);
+            PMI_HIP(hipGetLastError());
+            cur = nxt; cur_n = nxt_n;
         }
+        if (all_strict) hipLaunchKernelGGL((lq_finish_kernel<false, false, true>), fin_grid, dim3(LQ_STEP_NT), fin_lds, s, p, st, cur, cur_n, tie_list, tie_n);
+        else hipLaunchKernelGGL((lq_finish_kernel<false, true, false>), fin_grid, dim3(LQ_STEP_NT), fin_lds, s, p, st, cur, cur_n, tie_list, tie_n);
+        hipLaunchKernelGGL(lq_stats_add_kernel, dim3(1), dim3(64), 0, s, (const unsigned *)tie_n, stats, no_strict ? 0 : 1);
+        // ---- pass 1: the spots of tie_list again from their start values (refit: sequential sums; strict: exp rounded correctly)
+        if (!no_strict) {
+            hipLaunchKernelGGL((lq_init_kernel<FROM_MOVIE>), dim3((unsigned)((count + 255) / 256)), dim3(256), init_lds, s, p, st, count,
+                               (const int32_t *)tie_list, (const unsigned *)tie_n);
+            if (all_strict) hipLaunchKernelGGL((lq_finish_kernel<true, false, false>), fin_grid, dim3(LQ_STEP_NT), fin_lds, s, p, st, (const int32_t *)tie_list,
+                                               (const unsigned *)tie_n, (int32_t *)nullptr, (unsigned *)nullptr);
+            else hipLaunchKernelGGL((lq_finish_kernel<false, false, false>), fin_grid, dim3(LQ_STEP_NT), fin_lds, s, p, st, (const int32_t *)tie_list,
+                                    (const unsigned *)tie_n, (int32_t *)nullptr, (unsigned *)nullptr);
+        }
+        PMI_HIP(hipGetLastError());
+    }
+    g_lq_stats[g_lq_stats_second ? 1 : 0] = stats;
+    g_lq_stats_stream[g_lq_stats_second ? 1 : 0] = s;
+    if (!g_lq_stats_second) g_lq_stats[1] = nullptr;
+    g_lq_stats_generation = scratch_generation();
+    g_lq_rounds[0] = rounds; g_lq_rounds[1] = no_strict ? 0 : 1;
+    return PMI_OK;
+}
+
+static int read_lq_stats(unsigned (&h)[16])
+{
+    for (unsigned &v : h) v = 0;
+    if (!g_lq_stats[0] || g_lq_stats_generation != scratch_generation()) return PMI_OK;      // no fit yet, or its buffers are gone
+    for (int k = 0; k < 2; k++) {
+        if (!g_lq_stats[k]) continue;
+        unsigned part[16];
+        PMI_HIP(hipStreamSynchronize(g_lq_stats_stream[k]));
+        PMI_HIP(hipMemcpy(part, g_lq_stats[k], 64, hipMemcpyDeviceToHost));
+        for (int i = 0; i < 16; i++) h[i] += part[i];
     }
     return PMI_OK;
 }
@@ -1554,16 +1529,17 @@ struct LqCols { void *c[PMI_LQ_COLUMNS]; };
 __global__ void locs_from_fits_lq_kernel(const int32_t *__restrict__ frame, const int32_t *__restrict__ y,
                                          const int32_t *__restrict__ x, const float *__restrict__ ng,
                                          const float *__restrict__ th, int64_t N, const int64_t *__restrict__ d_n,
-                                         int em, LqCols cols)
+                                         int em, LqCols cols, const int64_t *__restrict__ d_row0)
 {
     int64_t n = N;
     if (d_n) { const int64_t dn = *d_n; n = dn < n ? dn : n; }
-    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const float *t = th + i * 6;
-    ((uint32_t *)cols.c[0])[i] = (uint32_t)frame[i];
-    ((float *)cols.c[1])[i] = (float)((double)t[0] + (double)x[i]);
-    ((float *)cols.c[2])[i] = (float)((double)t[1] + (double)y[i]);
+    const int64_t src = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;      // row of the fit arrays
+    if (src >= n) return;
+    const int64_t i = src + (d_row0 ? *d_row0 : 0);                           // row of the table: a second frame range follows the first
+    const float *t = th + src * 6;
+    ((uint32_t *)cols.c[0])[i] = (uint32_t)frame[src];
+    ((float *)cols.c[1])[i] = (float)((double)t[0] + (double)x[src]);
+    ((float *)cols.c[2])[i] = (float)((double)t[1] + (double)y[src]);
     ((float *)cols.c[3])[i] = t[2];
     ((float *)cols.c[4])[i] = t[4];
     ((float *)cols.c[5])[i] = t[5];
@@ -1572,7 +1548,7 @@ __global__ void locs_from_fits_lq_kernel(const int32_t *__restrict__ frame, cons
     ((float *)cols.c[8])[i] = lq_precision(t[2], t[5], t[4], t[3], em);
     const float a = np_maxf(t[4], t[5]), b = np_minf(t[4], t[5]);
     ((float *)cols.c[9])[i] = (a - b) / a;
-    ((float *)cols.c[10])[i] = ng[i];
+    ((float *)cols.c[10])[i] = ng[src];
 }
 
 }  // namespace lq
@@ -1602,13 +1578,19 @@ int pmi_gausslq_get_mode(int *mode)
 
 int pmi_gausslq_last_refit_count(int64_t *n_refit)
 {
-    if (n_refit) *n_refit = pmi::lq::g_last_lq_strict;
+    unsigned h[16];
+    const int rc = pmi::lq::read_lq_stats(h);
+    if (rc != PMI_OK) return rc;
+    if (n_refit) *n_refit = h[0];
     return PMI_OK;
 }
 
 int pmi_gausslq_last_tie_reasons(int64_t *counts, int n)
 {
-    for (int i = 0; counts && i < n; i++) counts[i] = i < 9 ? pmi::lq::g_last_lq_why[i] : 0;
+    unsigned h[16];
+    const int rc = pmi::lq::read_lq_stats(h);
+    if (rc != PMI_OK) return rc;
+    for (int i = 0; counts && i < n; i++) counts[i] = i < 7 ? h[1 + i] : (i < 9 ? pmi::lq::g_lq_rounds[i - 7] : 0);
     return PMI_OK;
 }
 
@@ -1681,11 +1663,35 @@ int pmi_locs_from_fits_lq_dev(const int32_t *d_frame, const int32_t *d_y, const 
     for (int c = 0; c < PMI_LQ_COLUMNS; c++) cols.c[c] = d_cols[c];
     const unsigned blocks = (unsigned)((N + 255) / 256);
     hipLaunchKernelGGL(lq::locs_from_fits_lq_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d_frame, d_y,
-                       d_x, d_ng, d_thetas, N, d_n, em, cols);
+                       d_x, d_ng, d_thetas, N, d_n, em, cols, (const int64_t *)nullptr);
     PMI_HIP(hipGetLastError());
     return PMI_OK;
 }
 
+namespace pmi {
+namespace lq {
+struct SideLane { hipStream_t s2 = nullptr; hipEvent_t ev_start = nullptr, ev_scan_a = nullptr, ev_b = nullptr; };
+static thread_local SideLane g_lq_side;
+// rows: [0] rows of A to fit, [1] rows of B to fit, [2] rows of A for the table, [3] rows of B for the table, [4] row offset of B
+__global__ void lq_rows_a_kernel(const int64_t *__restrict__ n_a, int64_t cap, int64_t *__restrict__ rows) { rows[0] = *n_a > cap ? 0 : *n_a; }
+__global__ void lq_rows_b_kernel(const int64_t *__restrict__ n_a, const int64_t *__restrict__ n_b, int64_t cap, int64_t *__restrict__ rows,
+                                 int64_t *__restrict__ d_out_n)
+{
+    const int64_t a = *n_a, b = *n_b, total = a + b;
+    const bool fits = total <= cap;
+    rows[1] = fits ? b : 0;
+    rows[2] = fits ? a : 0;
+    rows[3] = fits ? b : 0;
+    rows[4] = a;
+    *d_out_n = total;
+}
+}  // namespace lq
+}  // namespace pmi
+
+// identify -> fused cut + least-squares fit -> table.  Nothing in here waits for the stream (the fit's loops live on the
+// device, lq::launch), so a large frame range is cut in two like pmi_localize_mle_dev's: the scan of the second half — bound
+// by the memory side — runs on a side stream of the library beside the fit of the first, which is bound by instruction issue;
+// the table is written once both counts are known, A's rows, then B's.
 int pmi_localize_lq_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t X, int box, double min_ng,
                         const int64_t *roi4, int64_t f_lo, int64_t f_hi, double baseline, double sensitivity,
                         double gain, int em, void *d_table, int64_t cap, int64_t *d_out_n, void *stream)
@@ -1695,21 +1701,88 @@ int pmi_localize_lq_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, in
     int rc = lq::check_box(box);
     if (rc != PMI_OK) return rc;
     hipStream_t s = (hipStream_t)stream;
-    void *ptr = nullptr;
-    if ((rc = scratch(SCR_IDS, (size_t)cap * (16 + 6 * 4), &ptr)) != PMI_OK) return rc;
-    int32_t *d_f = (int32_t *)ptr, *d_y = d_f + cap, *d_x = d_y + cap;
-    float *d_ng = (float *)(d_x + cap);
-    float *d_th = d_ng + cap;
-    rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, f_lo, f_hi, 0, d_f, d_y, d_x, d_ng, cap, d_out_n, s);
+    struct Ids { int32_t *f, *y, *x; float *ng, *th; };
+    auto carve = [&](void *ptr) {
+        Ids d;
+        d.f = (int32_t *)ptr; d.y = d.f + cap; d.x = d.y + cap;
+        d.ng = (float *)(d.x + cap);
+        d.th = d.ng + cap;
+        return d;
+    };
+    const size_t ids_bytes = (size_t)cap * (16 + 6 * 4);
+    lq::LqCols cols;
+    for (int c = 0; c < PMI_LQ_COLUMNS; c++) cols.c[c] = (char *)d_table + (size_t)c * cap * 4;
+    const unsigned tblocks = (unsigned)((cap + 255) / 256);
+    void *ptr = nullptr, *cptr = nullptr;
+    if ((rc = scratch(SCR_ROWS, 8 * sizeof(int64_t), &cptr)) != PMI_OK) return rc;
+    int64_t *d_na = (int64_t *)cptr, *d_nb = d_na + 1, *rows = d_na + 2;
+    const int64_t lo = f_lo < 0 ? 0 : f_lo, hi = f_hi > F - 1 ? F - 1 : f_hi, nf = hi - lo + 1;
+    const bool two = g_localize_ranges == 2 && !g_kernel_timing && nf >= 16 && (double)nf * (double)Y * (double)X >= 2.5e8;
+    if (!two) {
+        if ((rc = scratch(SCR_IDS, ids_bytes, &ptr)) != PMI_OK) return rc;
+        const Ids d = carve(ptr);
+        rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, f_lo, f_hi, 0, d.f, d.y, d.x, d.ng, cap, d_out_n, s);
+        if (rc != PMI_OK) return rc;
+        hipLaunchKernelGGL(lq::lq_rows_a_kernel, dim3(1), dim3(1), 0, s, (const int64_t *)d_out_n, cap, rows);
+        rc = pmi_gausslq_movie_dev(d_movie, dtype, F, Y, X, d.f, d.y, d.x, cap, rows + 0, box, baseline, sensitivity,
+                                   gain, d.th, nullptr, nullptr, stream);
+        if (rc != PMI_OK) return rc;
+        hipLaunchKernelGGL(lq::locs_from_fits_lq_kernel, dim3(tblocks), dim3(256), 0, s, d.f, d.y, d.x, d.ng, d.th, cap,
+                           (const int64_t *)(rows + 0), em, cols, (const int64_t *)nullptr);
+        PMI_HIP(hipGetLastError());
+        return PMI_OK;
+    }
+    lq::SideLane &side = lq::g_lq_side;
+    if (!side.s2) {
+        PMI_HIP(hipStreamCreateWithFlags(&side.s2, hipStreamNonBlocking));
+        PMI_HIP(hipEventCreateWithFlags(&side.ev_start, hipEventDisableTiming));
+        PMI_HIP(hipEventCreateWithFlags(&side.ev_scan_a, hipEventDisableTiming));
+        PMI_HIP(hipEventCreateWithFlags(&side.ev_b, hipEventDisableTiming));
+    }
+    const int64_t mid = lo + nf / 2 - 1;                      // A = [lo, mid], B = [mid + 1, hi]
+    if ((rc = scratch(SCR_IDS, ids_bytes, &ptr)) != PMI_OK) return rc;
+    const Ids a = carve(ptr);
+    PMI_HIP(hipEventRecord(side.ev_start, s));
+    PMI_HIP(hipStreamWaitEvent(side.s2, side.ev_start, 0));
+    struct Join {       // whatever happens, the caller's stream is ordered after the side stream before this call returns
+        lq::SideLane &sd; hipStream_t st; bool done = false;
+        ~Join() { if (!done) { (void)hipEventRecord(sd.ev_b, sd.s2); (void)hipStreamWaitEvent(st, sd.ev_b, 0); } }
+    } join{side, s};
+    // ---- range A on the caller's stream
+    rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, lo, mid, 0, a.f, a.y, a.x, a.ng, cap, d_na, s);
     if (rc != PMI_OK) return rc;
-    const int64_t *d_rows = nullptr;
-    if ((rc = rows_to_fit(d_out_n, cap, &d_rows, s)) != PMI_OK) return rc;
-    rc = pmi_gausslq_movie_dev(d_movie, dtype, F, Y, X, d_f, d_y, d_x, cap, d_rows, box, baseline, sensitivity,
-                               gain, d_th, nullptr, nullptr, stream);
+    hipLaunchKernelGGL(lq::lq_rows_a_kernel, dim3(1), dim3(1), 0, s, (const int64_t *)d_na, cap, rows);
+    PMI_HIP(hipEventRecord(side.ev_scan_a, s));
+    rc = pmi_gausslq_movie_dev(d_movie, dtype, F, Y, X, a.f, a.y, a.x, cap, rows + 0, box, baseline, sensitivity, gain, a.th, nullptr,
+                               nullptr, s);
     if (rc != PMI_OK) return rc;
-    void *cols[PMI_LQ_COLUMNS];
-    for (int c = 0; c < PMI_LQ_COLUMNS; c++) cols[c] = (char *)d_table + (size_t)c * cap * 4;
-    return pmi_locs_from_fits_lq_dev(d_f, d_y, d_x, d_ng, d_th, cap, d_rows, em, cols, stream);
+    // ---- range B on the side stream, scratch from the inner bank; its scan starts when scan A is done
+    PMI_HIP(hipStreamWaitEvent(side.s2, side.ev_scan_a, 0));
+    const int outer = scratch_enter_inner();
+    Ids b2 = {};
+    rc = scratch(SCR_IDS, ids_bytes, &ptr);
+    if (rc == PMI_OK) {
+        b2 = carve(ptr);
+        rc = identify_impl(d_movie, dtype, F, Y, X, box, min_ng, roi4, mid + 1, hi, 0, b2.f, b2.y, b2.x, b2.ng, cap, d_nb, side.s2);
+    }
+    if (rc == PMI_OK) {
+        hipLaunchKernelGGL(lq::lq_rows_b_kernel, dim3(1), dim3(1), 0, side.s2, (const int64_t *)d_na, (const int64_t *)d_nb, cap, rows, d_out_n);
+        lq::g_lq_stats_second = true;
+        rc = pmi_gausslq_movie_dev(d_movie, dtype, F, Y, X, b2.f, b2.y, b2.x, cap, rows + 1, box, baseline, sensitivity, gain, b2.th,
+                                   nullptr, nullptr, side.s2);
+        lq::g_lq_stats_second = false;
+    }
+    scratch_leave_inner(outer);
+    if (rc != PMI_OK) return rc;
+    PMI_HIP(hipEventRecord(side.ev_b, side.s2));
+    PMI_HIP(hipStreamWaitEvent(s, side.ev_b, 0));
+    join.done = true;
+    hipLaunchKernelGGL(lq::locs_from_fits_lq_kernel, dim3(tblocks), dim3(256), 0, s, a.f, a.y, a.x, a.ng, a.th, cap,
+                       (const int64_t *)(rows + 2), em, cols, (const int64_t *)nullptr);
+    hipLaunchKernelGGL(lq::locs_from_fits_lq_kernel, dim3(tblocks), dim3(256), 0, s, b2.f, b2.y, b2.x, b2.ng, b2.th, cap,
+                       (const int64_t *)(rows + 3), em, cols, (const int64_t *)(rows + 4));
+    PMI_HIP(hipGetLastError());
+    return PMI_OK;
 }
 
 }  // extern "C"

@@ -1046,7 +1046,6 @@ int pmi_locs_from_fits_dev(const int32_t *d_frame, const int32_t *d_y, const int
 // that: *d_out_n reports their number (an upper bound of the rows), nothing is fitted, the table is untouched — the same
 // contract as a table that is too small.
 namespace pmi {
-static int g_localize_ranges = 2;
 static bool g_localize_handoff = false;
 static bool g_localize_defer = true;
 struct SideLane { hipStream_t s2 = nullptr; hipEvent_t ev_start = nullptr, ev_scan_a = nullptr, ev_b = nullptr; };

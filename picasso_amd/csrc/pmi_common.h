@@ -47,6 +47,7 @@ enum ScratchSlot {
     SCR_GATES,            // per-chunk flags of that copy
     SCR_PIX,              // box pixels of the candidates, left by the scan's exact stage for the fit (identify_fast.hip)
     SCR_STATS,            // flag statistics of the last MLE fit (re-fit count, count per criterion)
+    SCR_LQ_STATS,         // the same of the last least-squares fit (spots fitted again, count per reason)
     SCR_NUM
 };
 int scratch(int slot, size_t bytes, void **ptr);
@@ -75,6 +76,7 @@ extern thread_local bool g_defer_exact;
 // the scan kernel the calling thread launched last, as rocprofv3 names it (+ " defer" when it may leave its exact stage to
 // the fit): pmi_last_scan_kernel, so that a benchmark can tell which kernel a committed counter file belongs to
 extern thread_local char g_last_scan_kernel[128];
+extern int g_localize_ranges;        // frame ranges a fused call keeps in flight (pmi_localize_set_ranges)
 
 // pixel load as float32 (the reference's np.float32(frame), localize.py:332)
 template <typename T>

@@ -12,6 +12,7 @@ bool g_kernel_timing = false;
 KernelTimes g_last_times = {0.f, 0.f};
 thread_local PixHandoff g_handoff;
 thread_local bool g_defer_exact = false;
+int g_localize_ranges = 2;          // pmi_localize_set_ranges (gaussmle.hip); read by both fused calls
 thread_local char g_last_scan_kernel[128] = "";
 
 void set_error(const char *fmt, ...)

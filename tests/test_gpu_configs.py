@@ -313,6 +313,43 @@ def test_fused_call_keeps_two_frame_ranges_in_flight():
         _lib.check(L.pmi_localize_set_defer(1), "pmi_localize_set_defer")
 
 
+def test_fused_least_squares_call_keeps_two_frame_ranges_in_flight():
+    """pmi_localize_lq_dev (round 4: nothing in it waits for the stream any more) cuts a large frame range in two like the
+    MLE call: the same 11-column table, bit for bit, with one range and with two; a capacity below the sum reports the sum
+    and leaves the table untouched."""
+    import torch
+    from picasso_amd import _lib, synth
+    L = _lib.load()
+    F = 1100
+    movie = synth.simulate_movie(F, 512, 512, emitters_per_frame=60, seed=29, device="cuda")
+    torch.cuda.synchronize()
+
+    def run(ranges, f_lo, f_hi, roi, cap_, fill=0):
+        _lib.check(L.pmi_localize_set_ranges(ranges), "pmi_localize_set_ranges")
+        table = torch.full((_lib.PMI_LQ_COLUMNS, cap_), fill, dtype=torch.int32, device="cuda")
+        d_n = torch.zeros(1, dtype=torch.int64, device="cuda")
+        r = (ctypes.c_int64 * 4)(*roi) if roi else None
+        rc = L.pmi_localize_lq_dev(ctypes.c_void_p(movie.data_ptr()), 0, F, 512, 512, 7, 5000.0, r, f_lo, f_hi, 100.0, 1.0, 1.0, 0,
+                                   ctypes.c_void_p(table.data_ptr()), cap_, ctypes.c_void_p(d_n.data_ptr()), None)
+        _lib.check(rc, "pmi_localize_lq_dev")
+        torch.cuda.synchronize()
+        return table, int(d_n.item())
+
+    try:
+        cap = 150 * F
+        for f_lo, f_hi, roi in ((0, F - 1, None), (3, F - 5, (10, 20, 500, 490))):
+            one, n1 = run(1, f_lo, f_hi, roi, cap)
+            for rep in range(2):
+                two, n2 = run(2, f_lo, f_hi, roi, cap)
+                assert n1 == n2 and n1 > 20000, (n1, n2)
+                assert torch.equal(one[:, :n1], two[:, :n2]), (f_lo, f_hi, roi, rep)
+        full, n_full = run(1, 0, F - 1, None, cap)
+        small, n_small = run(2, 0, F - 1, None, int(n_full * 0.75), fill=0x5A5A5A5A)
+        assert n_small == n_full and bool((small == 0x5A5A5A5A).all())
+    finally:
+        _lib.check(L.pmi_localize_set_ranges(2), "pmi_localize_set_ranges")
+
+
 @pytest.mark.parametrize("case", ["u16_box7", "u16_box5_roi", "u16_box9", "u16_box13", "u8_box7", "i16_box7_roi", "low_threshold", "tight_cap"])
 def test_fused_call_with_the_exact_stage_of_identify_in_the_fit(case):
     """pmi_localize_set_defer: the packed scan emits candidates and the fit's start-value kernel evaluates the float32 net

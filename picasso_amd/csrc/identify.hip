@@ -360,7 +360,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
                          int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
                          long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled,
                          const int *gate = nullptr, uint32_t *pix = nullptr, unsigned *pix_cnt = nullptr, unsigned pix_cap = 0,
-                         bool defer = false);
+                         bool defer = false, const float *fmovie = nullptr, int gate_want = 0);
 
 // float32 / int32 / uint32 movies that hold 16-bit counts (a camera's counts saved wide): the frames are narrowed to
 // uint16 — exactly, or not at all: any pixel that is not an integer in 0..65535 raises the chunk's flag — and take the
@@ -371,6 +371,9 @@ __global__ __launch_bounds__(256) void narrow_to_u16_kernel(const T *__restrict_
 {
     bool bad = false;
     for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+        // another block has seen a pixel that is not a count: the copy is void already (an atomic load: `flag` is restrict-qualified
+        // and a plain one is hoisted out of the loop)
+        if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) return;
         T v[4];
         const bool full = i + 4 <= n;
         if (full) { const uint4 q = *reinterpret_cast<const uint4 *>(src + i); __builtin_memcpy(v, &q, 16); }
@@ -394,6 +397,26 @@ __global__ __launch_bounds__(256) void narrow_to_u16_kernel(const T *__restrict_
         else for (int k = 0; k < 4 && i + k < n; k++) dst[i + k] = o[k];
     }
     if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+// float32 movies with any other content (fractions, negatives, NaN, infinities): the scan runs on 16-bit keys — the upper
+// half of the order-preserving integer image of a float32 (identify_fast.hip, PT_KEY) — and decides everything exact on the
+// float32 pixels.  Runs only for a chunk the count narrowing above has flagged.
+__global__ __launch_bounds__(256) void narrow_to_key_kernel(const float *__restrict__ src, long long n, uint16_t *__restrict__ dst,
+                                                            const int *__restrict__ flag)
+{
+    if (*flag == 0) return;
+    auto key = [](float f) -> unsigned { const unsigned b = __float_as_uint(f); return ((b & 0x80000000u) ? ~b : (b | 0x80000000u)) >> 16; };
+    for (long long i = ((long long)blockIdx.x * blockDim.x + threadIdx.x) * 4; i < n; i += (long long)gridDim.x * blockDim.x * 4) {
+        if (i + 4 <= n) {
+            const float4 q = *reinterpret_cast<const float4 *>(src + i);
+            uint2 w;
+            w.x = key(q.x) | (key(q.y) << 16); w.y = key(q.z) | (key(q.w) << 16);
+            *reinterpret_cast<uint2 *>(dst + i) = w;
+        } else {
+            for (int k = 0; k < 4 && i + k < n; k++) dst[i + k] = (uint16_t)key(src[i + k]);
+        }
+    }
 }
 
 // d_movie points at frame 0 of a stack holding at least frames [f_lo, f_hi].
@@ -484,6 +507,17 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
                                           d_tab, recs, cap, d_total, count + c0, s, &f2, gates + ci);
                 if (rc != PMI_OK) return rc;
                 if (!f2) { all_fast = false; break; }          // the geometry rules the packed scan out: nothing was queued by it
+                if (dtype == PMI_F32) {
+                    // a flagged chunk of a float32 movie: keys + the packed scan again, exact decisions on the float32 pixels
+                    hipLaunchKernelGGL(narrow_to_key_kernel, dim3(nb), dim3(256), 0, s, (const float *)srcp, npx, (uint16_t *)tmp, (const int *)(gates + ci));
+                    PMI_HIP(hipGetLastError());
+                    bool f3 = false;
+                    rc = launch_scan_u16_fast(tmp, PMI_U16, Y, X, p.y0, p.x0, p.cy, p.cx, 0, f_lo + label_offset + c0, (int)n, box, min_ng,
+                                              d_tab, recs, cap, d_total, count + c0, s, &f3, gates + ci, nullptr, nullptr, 0u, false,
+                                              (const float *)srcp, 1);
+                    if (rc != PMI_OK) return rc;
+                    if (f3) continue;
+                }
                 IdParams pc = p;
                 pc.f_lo = f_lo + c0; pc.nframes = (int)n; pc.gate = gates + ci;
                 switch (dtype) {

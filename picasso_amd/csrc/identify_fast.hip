@@ -70,7 +70,23 @@ __device__ __forceinline__ u32 pk_sub_sat(u32 a, u32 b)
 //           a sum of DIFFERENCES of pixels (picasso/localize.py:233-243), which a common offset does not change —
 //           float32(a + 32768) - float32(b + 32768) = float32(a) - float32(b) exactly for 16-bit values.
 // (float32 / 32-bit integer movies compare as float32 in the reference, picasso/localize.py:332: generic kernel.)
-enum { PT_U16 = 0, PT_U8 = 1, PT_I16 = 2 };
+//   PT_KEY  float32 movies with any content: the scan works on 16-bit KEYS — the upper half of the order-preserving integer
+//           image of a float32 (key_of_float below: monotone, so every first maximum of the pixels is a maximum of the keys) —
+//           made by narrow_to_key_kernel (identify.hip); everything that is decided exactly — the first-argmax rule, the
+//           net gradient, the threshold — reads the float32 pixels.  Equal keys do not mean equal pixels, so the neighbour
+//           rule that drops the right-hand / lower one of two equal candidates does not apply; the floor is computed from
+//           the lower edges of the keys' buckets and turned back into a key (conservative on both sides).
+enum { PT_U16 = 0, PT_U8 = 1, PT_I16 = 2, PT_KEY = 3 };
+__host__ __device__ __forceinline__ uint32_t key_image(uint32_t bits) { return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u); }
+__device__ __forceinline__ unsigned key_of_float(float f) { return key_image(__float_as_uint(f)) >> 16; }
+// a lower bound of every float32 whose key is k: the smallest of them — or, where that pattern is a NaN (the buckets that hold
+// -inf / +inf also hold NaNs), -inf on the negative side and +inf on the positive one (only NaNs lie above +inf)
+__device__ __forceinline__ float key_lower_edge(unsigned k)
+{
+    const unsigned u = k << 16;
+    const float f = __uint_as_float((u & 0x80000000u) ? (u & 0x7fffffffu) : ~u);
+    return f == f ? f : ((u & 0x80000000u) ? INFINITY : -INFINITY);
+}
 template <int PT> struct Px { typedef uint16_t T; };
 template <> struct Px<PT_U8> { typedef uint8_t T; };
 template <int PT> __device__ __forceinline__ float px_float(typename Px<PT>::T raw)
@@ -105,6 +121,8 @@ struct FastParams {
     unsigned *pix_cnt;
     unsigned pix_cap;
     int defer;                 // 1: a wave whose exact rounds accept most of its candidates may emit the rest undecided (net gradient NG_DEFERRED_BITS, pmi_common.h)
+    const float *fmovie;       // PT_KEY: the float32 frames the keys in `movie` were made from (same frame indexing)
+    int gate_want;             // the launch runs only while *gate equals this
     const int *gate;           // optional device flag: the launch does nothing unless it is 0 (32-bit movies narrowed to uint16, identify.hip)
     int dbg;                   // PMI_IDENTIFY_DBG: 1 = skip the exact net gradient, 2 = skip the record append, 4 = no floor filter (timing only)
 };
@@ -333,6 +351,49 @@ __device__ __forceinline__ float exact_ng(const typename Px<PT>::T *__restrict__
     return exact_ng_rows<H, KM, BOX, PT>(base, row0w, X, c0w, ng, vc, first_max, pixdst);
 }
 
+// The same on float32 pixels (PT_KEY): three rows of the neighbourhood in registers, the next one fetched while a window
+// row is summed; the reference's expression as it stands (a non-finite pixel makes the sum NaN there too), and the
+// first-argmax rule on the float32 values.
+template <int H>
+__device__ __forceinline__ float exact_ng_f32(const float *__restrict__ src, int64_t X, int cy, int cx, int i, int j, bool &first_max)
+{
+    constexpr int BOX = 2 * H + 1, W = 2 * H + 3;
+    const float *base = src + (int64_t)(i - H - 1) * X + (j - H);           // neighbourhood row t, column 1
+    const int r0 = i - H - 1 < 0 ? i - H - 1 + cy : i - H - 1;                // numba negative-index wrap
+    const float *row0w = src + (int64_t)r0 * X + (j - H);
+    const int c0w = j - H - 1 < 0 ? cx - 1 - (j - H) : -1;
+    struct __attribute__((packed, aligned(4))) Row { float v[W - 1]; };
+    auto load_row = [&](int t, float (&r)[W]) {
+        const float *row = t == 0 ? row0w : base + (int64_t)t * X;
+        const Row q = *reinterpret_cast<const Row *>(row);
+        r[0] = row[c0w];
+#pragma unroll
+        for (int c = 1; c < W; c++) r[c] = q.v[c - 1];
+    };
+    float ra[W], rb[W], rc[W];
+    load_row(0, ra);
+    load_row(1, rb);
+    const float vc = base[(int64_t)(H + 1) * X + H];
+    float ng = 0.0f;
+    first_max = true;
+#pragma unroll
+    for (int k = 0; k < BOX; k++) {
+        load_row(k + 2, rc);
+#pragma unroll
+        for (int l = 0; l < BOX; l++) {
+            if (k == H && l == H) continue;
+            const float o = rb[l + 1];
+            first_max = first_max && ((k < H || (k == H && l < H)) ? vc > o : vc >= o);
+            const float gy = sub_rn(rc[l + 1], ra[l + 1]);
+            const float gx = sub_rn(rb[l + 2], rb[l]);
+            ng = add_rn(ng, add_rn(mul_rn(gy, unit_y<H>(k, l)), mul_rn(gx, unit_x<H>(k, l))));
+        }
+#pragma unroll
+        for (int c = 0; c < W; c++) { ra[c] = rb[c]; rb[c] = rc[c]; }
+    }
+    return ng;
+}
+
 // One wavefront per workgroup, persistent: it owns p.upw consecutive UNITS.  A unit is rbu rows x 512 columns of one
 // frame (P > 1, frames at most 512 / P pixels wide: P consecutive row ranges of rbu rows side by side, NL = 64 / P
 // lanes each, in lock step).  Consecutive units of a wave are consecutive row ranges of the same frame, so the 2H + 2
@@ -397,7 +458,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
         unit1 = unit0 + p.lin_rows < p.lin_total ? unit0 + p.lin_rows : p.lin_total;
     }
     if (unit0 >= unit1) return;
-    if (p.gate && *p.gate != 0) return;
+    if (p.gate && *p.gate != p.gate_want) return;
     const int sub = P > 1 ? lane / NL : 0;                            // this lane's sub-band and its rows' offset
     const int sub_rows = sub * p.rbu;
 
@@ -427,6 +488,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
     // whole margin).  The assumption is CHECKED when the chunk is done — the minimum of every row it streamed, per
     // lane window — and a chunk that saw a lower pixel is run again: with four times the slack first, then without.
     u32 cfloor = 0u;
+    float cf = -INFINITY;                                  // PT_KEY: the same bound as a float32 (nothing is assumed before the first chunk)
     bool redo = false;
     constexpr int ROUND = fast_round(H);
     int trigger = filter ? 8 + (ROUND / 8) * (int)(blockIdx.x % 7u) : THRESH;
@@ -498,15 +560,23 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
     auto frame_src = [&](int fi) -> const PX * {
         return (const PX *)p.movie + ((int64_t)(p.f_lo + fi) * p.Y + p.y0) * p.X + p.x0;
     };
+    auto frame_fsrc = [&](int fi) -> const float * {
+        return p.fmovie + ((int64_t)(p.f_lo + fi) * p.Y + p.y0) * p.X + p.x0;
+    };
     // slow exact path: overflow rescans (a plateau of equal pixels flooded the ring)
-    auto process_slow = [&](const PX *src, int fi, int i, int j, bool recheck) {
-        const float v = px_float<PT>(src[(int64_t)i * p.X + j]);
+    auto process_slow = [&](const PX *ksrc, int fi, int i, int j, bool recheck) {
+        // (PT_KEY: the pixels are the float32 ones; `pxs` indexes whichever frame holds them)
+        const float *fsrc = PT == PT_KEY ? frame_fsrc(fi) : nullptr;
+        struct { const PX *k; const float *f; __device__ float operator[](int64_t idx) const {
+            if constexpr (PT == PT_KEY) return f[idx]; else return px_float<PT>(k[idx]); } } pxs{ksrc, fsrc};
+        const int64_t src = 0;
+        const float v = pxs[(int64_t)i * p.X + j];
         if (recheck) {
 #pragma unroll 1
             for (int k = -H; k <= H; k++)
 #pragma unroll 1
                 for (int l = -H; l <= H; l++) {
-                    float o = px_float<PT>(src[(int64_t)(i + k) * p.X + (j + l)]);
+                    float o = pxs[(int64_t)(i + k) * p.X + (j + l)];
                     if ((k < 0 || (k == 0 && l < 0)) ? !(v > o) : !(v >= o)) return;
                 }
         }
@@ -515,16 +585,14 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
         for (int k = 0; k < BOX; k++) {
             const int rk = i - H + k;
             const int rm = rk - 1 < 0 ? rk - 1 + p.cy : rk - 1;          // numba negative-index wrap
-            const PX *rowm = src + (int64_t)rm * p.X;
-            const PX *row0 = src + (int64_t)rk * p.X;
-            const PX *rowp = src + (int64_t)(rk + 1) * p.X;
+            const int64_t rowm = src + (int64_t)rm * p.X, row0 = src + (int64_t)rk * p.X, rowp = src + (int64_t)(rk + 1) * p.X;
 #pragma unroll 1
             for (int l = 0; l < BOX; l++) {
                 if (k == H && l == H) continue;
                 const int cl = j - H + l;
                 const int clm = cl - 1 < 0 ? cl - 1 + p.cx : cl - 1;
-                float gy = sub_rn(px_float<PT>(rowp[cl]), px_float<PT>(rowm[cl]));
-                float gx = sub_rn(px_float<PT>(row0[cl + 1]), px_float<PT>(row0[clm]));
+                float gy = sub_rn(pxs[rowp + cl], pxs[rowm + cl]);
+                float gx = sub_rn(pxs[row0 + cl + 1], pxs[row0 + clm]);
                 float sacc = add_rn(mul_rn(gy, suy[k * BOX + l]), mul_rn(gx, sux[k * BOX + l]));
                 ng = add_rn(ng, sacc);
             }
@@ -559,7 +627,9 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
             } else if (p.dbg & 1) append(fi, i, j, (e & 7) == 0 ? 1e9f : 0.0f, -1);
             else {
                 bool first_max;
-                const float ng = exact_ng<H, PT>(src, p.X, p.cy, p.cx, i, j, first_max, pixdst);
+                float ng;
+                if constexpr (PT == PT_KEY) ng = exact_ng_f32<H>(frame_fsrc(fi), p.X, p.cy, p.cx, i, j, first_max);
+                else ng = exact_ng<H, PT>(src, p.X, p.cy, p.cx, i, j, first_max, pixdst);
                 if (first_max) append(fi, i, j, ng, slot);
                 kept = first_max && (double)ng > p.min_ng;
             }
@@ -717,7 +787,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
             int added = 0;                                    // candidates of this chunk, counted even when the ring is full
             int tail_lf = tail, rd_lf = clo;                  // ring state before, and first row of, the latest flush group
             u32 cmin = 0xffffffffu;                           // minimum of every pixel this lane streamed in the chunk (both halves)
-            const float beta = fmaf(1.0f - p.filt_alpha, (float)cfloor, p.filt_t);
+            const float beta = fmaf(1.0f - p.filt_alpha, PT == PT_KEY ? cf : (float)cfloor, p.filt_t);
             // A maximum in row H (column H) has the first row (column) of its neighbourhood at index -1, i.e. in the LAST
             // row (column) of the frame (numba wraps; localize.py:233-243).  Those pixels are not among the ones the
             // running minimum or the cfloor check see — but they carry negative weights only (N_wrap in total) and are
@@ -870,7 +940,8 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                             // / lower one cannot be it.  Dropped here — within the lane's 8 pixels and the group's rows —
                             // a plateau of equal pixels (a saturated fiducial) sends its upper-left rim to the ring
                             // instead of every pixel.
-                            const u32 c = pass;
+                            // (keys: equal keys are not equal pixels — the right-hand one may be the larger)
+                            const u32 c = PT == PT_KEY ? 0u : pass;
                             pass &= ~((c & 0x0000ffffu) << 16);                    // odd pixel, left neighbour = the even pixel of its pair
                             pass &= ~(((c >> 16) << 1) & 0x0000eeeeu);             // even pixel 2q (q > 0), left neighbour = odd pixel of pair q - 1
                             pass &= ~((c & 0x0fff0fffu) << 4);                     // same pixel, one row up (previous row slot)
@@ -920,8 +991,17 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                             const int rnext = rs0 + st + 1 - H + sub_rows;
                             const bool wraprow = rnext <= H && rnext + 3 >= H;
                             const float flw = wrapcol ? (wraprow ? beta_rc : beta_c) : beta_r;
-                            const float fl = (wrapcol || wraprow) ? flw : fmaf(p.filt_alpha, (float)(wmin & 0xffffu), beta);
-                            u32 fi_ = (u32)fminf(fl, 65535.0f);                                    // fl >= 0
+                            u32 fi_;
+                            if constexpr (PT == PT_KEY) {
+                                // the bound from the lower edge of the minimum's bucket, back to the key of the bucket it falls into:
+                                // v > fl implies key(v) >= key(fl).  Wrapped stencils reach pixels the minimum has not seen and
+                                // that may be negative here: no floor for them; none either when the bound is not a number.
+                                const float fl = fmaf(p.filt_alpha, key_lower_edge(wmin & 0xffffu), beta);
+                                fi_ = (wrapcol || wraprow || !(fl == fl)) ? 0u : key_of_float(fl);
+                            } else {
+                                const float fl = (wrapcol || wraprow) ? flw : fmaf(p.filt_alpha, (float)(wmin & 0xffffu), beta);
+                                fi_ = (u32)fminf(fl, 65535.0f);                                // fl >= 0
+                            }
                             fi_ = no_floor ? 0u : fi_;
                             F = fi_ | (fi_ << 16);
                         }
@@ -932,9 +1012,12 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
             // Rows decided: every row whose decision step lies before sb.  A chunk that ends early (sb < nr) keeps
             // only the rows before its latest flush group: the neighbourhoods of those have streamed in completely,
             // so the check of the floor's assumption below covers them.
-            const bool flooded = added > LIST - (tail0 - head);
+            bool flooded = added > LIST - (tail0 - head);
             int dn = min(len, sb - 2 * H - 1);
             if (sb < nr && !flooded) { tail = tail_lf; dn = rd_lf - clo; }
+            // a chunk that ended before it decided a single row (the ring filled within its first rows: whole rows of equal
+            // keys, where the neighbour rule does not apply) makes no progress: one row the slow way
+            if (dn < 1) { flooded = true; dn = 1; }
             __builtin_amdgcn_wave_barrier();
             __threadfence_block();
             if (filter && !flooded) {
@@ -945,7 +1028,19 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                     cw = pk_min(cw, pk_min(wl, wr));
                 }
                 cw &= 0xffffu;
-                const bool broken = cw < cfloor;               // a pixel below the assumed floor: the decisions of this chunk are void
+                bool broken;
+                if constexpr (PT == PT_KEY) {
+                    const float cwf = key_lower_edge(cw), slackf = (float)p.filt_slack;
+                    broken = cwf < cf;                         // (a NaN lower edge compares false, and makes the next floor NaN = none)
+                    cf = cwf - slackf;
+                    if (__any(broken)) {
+                        tail = tail0;
+                        cf = redo ? -INFINITY : cwf - 4.0f * slackf;
+                        redo = true;
+                        continue;
+                    }
+                } else {
+                broken = cw < cfloor;                          // a pixel below the assumed floor: the decisions of this chunk are void
                 const u32 slack = (u32)p.filt_slack;
                 cfloor = cw > slack ? cw - slack : 0u;
                 if (__any(broken)) {                           // run the chunk again; a second failure in a row drops the assumption
@@ -953,6 +1048,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                     cfloor = (redo || cw <= 4u * slack) ? 0u : cw - 4u * slack;
                     redo = true;
                     continue;
+                }
                 }
                 redo = false;
             }
@@ -1004,14 +1100,16 @@ static int launch_fast(const FastParams &p, int pt, const float *d_tab, Record *
              (P == 1 && p.segs > 1) ? "true" : "false", p.defer ? " defer" : "");
     if constexpr (P == 1) {
         if (p.segs > 1) {             // frames wider than a wave: the variant with the edge loads
-            if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_U8, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+            if (pt == PT_KEY) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_KEY, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+            else if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_U8, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
             else if (pt == PT_I16) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_I16, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
             else hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_U16, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
             PMI_HIP(hipGetLastError());
             return PMI_OK;
         }
     }
-    if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_U8>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+    if (pt == PT_KEY) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_KEY>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+    else if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_U8>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
     else if (pt == PT_I16) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_I16>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
     else hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_U16>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
     PMI_HIP(hipGetLastError());
@@ -1046,7 +1144,7 @@ static int g_fast_cus = 0;
 int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
                          int64_t label_off, int nframes, int box, double min_ng, const float *d_tab, Record *recs,
                          long long cap, unsigned long long *n_total, int *frame_count, hipStream_t s, bool *handled,
-                         const int *gate, uint32_t *pix, unsigned *pix_cnt, unsigned pix_cap, bool defer)
+                         const int *gate, uint32_t *pix, unsigned *pix_cnt, unsigned pix_cap, bool defer, const float *fmovie, int gate_want)
 {
     *handled = false;
     static const bool force_generic = tuning_env("PMI_IDENTIFY_GENERIC") != nullptr;
@@ -1056,7 +1154,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     if (!unit_vectors_match()) return PMI_OK;          // never expected; the generic kernel uses the runtime table
     // uint16, uint8 and int16 movies (see Px); rows need no alignment beyond the pixel's own: gfx950 runs buffer and
     // global loads in unaligned mode, so odd widths only cost the loads that straddle a 64-byte boundary
-    const int pt = dtype == PMI_U16 ? PT_U16 : (dtype == PMI_U8 ? PT_U8 : (dtype == PMI_I16 ? PT_I16 : -1));
+    const int pt = fmovie ? (dtype == PMI_U16 ? PT_KEY : -1) : (dtype == PMI_U16 ? PT_U16 : (dtype == PMI_U8 ? PT_U8 : (dtype == PMI_I16 ? PT_I16 : -1)));
     if (pt < 0) return PMI_OK;
     const int pxb = pt == PT_U8 ? 1 : 2;
     if (cx < 16 || ((uintptr_t)d_movie & (uintptr_t)(pxb - 1))) return PMI_OK;
@@ -1079,7 +1177,8 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     p.movie = d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;
     p.f_lo = f_lo; p.label_off = label_off; p.nframes = nframes; p.box = box; p.min_ng = min_ng; p.gate = gate;
     p.pix = pix; p.pix_cnt = pix_cnt; p.pix_cap = pix_cap;
-    p.defer = defer ? 1 : 0;
+    p.defer = defer && !fmovie ? 1 : 0;
+    p.fmovie = fmovie; p.gate_want = gate_want;
     p.segs = pack > 1 ? 1 : (nch + 63) / 64;
     // Rows per unit: long units amortise the 2H + 2 pipeline rows a unit spends on its halo, short ones balance the
     // persistent waves (every wave runs ceil(units / waves) units).  Pick the length with the least total work.

@@ -401,6 +401,59 @@ def _wide_movie_cases(be, orc, dtype):
     assert len(b[0]) > 20
 
 
+@pytest.mark.parametrize("kind", ["fractions", "negative_offset", "tiny_scale", "nan_inf", "ties", "mixed_chunks"])
+@pytest.mark.parametrize("box", [5, 7, 9, 13])
+def test_identify_float32_movies_with_any_content(be, orc, kind, box):
+    """float32 movies that are not 16-bit counts (the reference treats every movie as float32, picasso/localize.py:332): the
+    packed scan runs on 16-bit keys — the upper half of the order-preserving integer image of a float32 — and the first-argmax
+    rule, the float32 net gradient and the threshold are decided on the float32 pixels (identify_fast.hip PT_KEY).  Fractions,
+    a negative offset, values far below 1, NaN / +-inf pixels, plateaus of equal values and chunks of either kind in one
+    movie: the table is the oracle's, bit for bit."""
+    from picasso_amd import _lib
+    rng = np.random.default_rng(300 + box)
+    F, Y, X = 7, 120, 336
+    mov = rng.poisson(35, size=(F, Y, X)).astype(np.float64)
+    for f in range(F):
+        for _ in range(10):
+            y, x = rng.integers(9, Y - 9), rng.integers(9, X - 9)
+            s = rng.uniform(0.9, 1.0 + 0.15 * box)
+            yy, xx = np.mgrid[y - 8:y + 9, x - 8:x + 9]
+            mov[f, y - 8:y + 9, x - 8:x + 9] += rng.uniform(800, 5000) * np.exp(-0.5 * ((yy - y) ** 2 + (xx - x) ** 2) / s ** 2)
+    min_ngs = [3000.0, 300.0, -1e9]
+    if kind == "fractions":
+        mov = mov * 1.37 + 0.25
+    elif kind == "negative_offset":
+        mov = mov * 0.731 - 5000.0
+    elif kind == "tiny_scale":
+        mov = mov * 1e-3
+        min_ngs = [3.0, 0.3, -1e9]
+    elif kind == "nan_inf":
+        mov = mov + 0.5
+        for v in (np.nan, np.inf, -np.inf, -np.nan):
+            for _ in range(12):
+                mov[rng.integers(0, F), rng.integers(0, Y), rng.integers(0, X)] = v
+    elif kind == "ties":
+        mov = np.round(mov / 16.0) * 16.0 + 0.5             # many equal neighbours, equal keys and equal pixels
+        mov[2, 40:60, 100:140] = 7000.5                     # a plateau
+    mov = mov.astype(np.float32)
+    if kind == "mixed_chunks":
+        mov[:3] = np.rint(mov[:3])                          # frames 0..2 hold counts (narrowed exactly), the others fractions
+        mov[3:] += 0.125
+    assert _lib.load().pmi_identify_set_narrow_chunk(3) == 0          # several chunks on a small movie
+    try:
+        n_last = 0
+        for min_ng in min_ngs:
+            for roi in (None, ((5, 11), (Y - 3, X - 13))):
+                a = be.identify_arrays(mov, min_ng, box, roi=roi)
+                b = orc.identify(mov, min_ng, box, roi=roi, threads=4)
+                assert len(a[0]) == len(b[0]) and all(np.array_equal(p, q, equal_nan=True) for p, q in zip(a, b)), \
+                    (kind, box, min_ng, roi, len(a[0]), len(b[0]))
+                n_last = len(b[0])
+        assert n_last > 20
+    finally:
+        assert _lib.load().pmi_identify_set_narrow_chunk(0) == 0
+
+
 def test_identify_capacity_retry(be, orc, testdata_movie):
     """More rows than the first capacity guess: PMI_ERR_CAPACITY -> retry with the exact count."""
     rng = np.random.default_rng(5)

@@ -103,7 +103,13 @@ int pmi_scratch_bank(int bank);
  * [f_lo, f_hi] (inclusive) are skipped.  A pixel is reported when it is the
  * first maximum of its box x box window and its net gradient is > min_ng.
  * Output rows are ordered by (frame, y, x); coordinates are frame coordinates.
- * If more than `cap` rows exist, returns PMI_ERR_CAPACITY and *out_n = needed. */
+ * If more than `cap` rows exist, returns PMI_ERR_CAPACITY and *out_n = needed.
+ * Every pixel type compares as float32, as in the reference (picasso/localize.py:332).  uint16 / int16 / uint8 movies take the
+ * packed scan; float32 / int32 / uint32 movies whose pixels are 16-bit counts are narrowed exactly, chunk by chunk, and take
+ * it too; a float32 chunk with any other content (fractions, negatives, NaN, +-inf) is scanned on 16-bit keys — the upper
+ * half of the order-preserving integer image of a float32 — with the first-argmax rule, the net gradient and the threshold
+ * decided on the float32 pixels; the generic kernel serves boxes 19 / 21, 32-bit integers beyond 16 bits and crops narrower
+ * than a stencil.  Same table whichever kernel runs. */
 int pmi_identify(const void *movie, int dtype, int64_t F, int64_t Y, int64_t X,
                  int box, double min_ng, const int64_t *roi4, int64_t f_lo, int64_t f_hi,
                  int32_t *out_frame, int32_t *out_y, int32_t *out_x, float *out_ng,

@@ -13,7 +13,8 @@ L = _lib.load()
 BOX = int(sys.argv[1]) if len(sys.argv) > 1 else 7
 CASES = [(h, w, "uint16") for h, w in ((64, 64), (128, 128), (256, 256), (512, 512), (1024, 1024), (2048, 2048), (128, 1024),
                                          (1024, 128), (1024, 64), (512, 200), (300, 300), (512, 511), (511, 333))]
-CASES += [(512, 512, "uint8"), (512, 511, "uint8"), (512, 512, "int16"), (512, 512, "uint16+20000"), (512, 512, "float32")]
+CASES += [(512, 512, "uint8"), (512, 511, "uint8"), (512, 512, "int16"), (512, 512, "uint16+20000"), (512, 512, "float32"),
+          (512, 512, "float32 x1.37"), (1024, 1024, "float32 x1.37")]
 if len(sys.argv) > 2:      # usage: ... box H W dtype
     CASES = [(int(sys.argv[2]), int(sys.argv[3]), sys.argv[4] if len(sys.argv) > 4 else "uint16")]
 for H, W, dt in CASES:
@@ -26,8 +27,10 @@ for H, W, dt in CASES:
     elif dt == "uint16+20000":   # a large camera offset
         mov = (mov.to(torch.int32) + 20000).to(torch.uint16)
     elif dt == "float32":
-        mov = mov.to(torch.float32)
-    code = {"uint16": 0, "uint16+20000": 0, "uint8": 1, "int16": 2, "float32": 5}[dt]
+        mov = mov.view(torch.int16).to(torch.float32)
+    elif dt == "float32 x1.37":      # fractions: 16-bit keys + exact decisions on the float32 pixels
+        mov = mov.view(torch.int16).to(torch.float32) * 1.37 + 0.25
+    code = {"uint16": 0, "uint16+20000": 0, "uint8": 1, "int16": 2, "float32": 5, "float32 x1.37": 5}[dt]
     min_ng = 5000.0 / 8 if dt == "uint8" else 5000.0
     torch.cuda.synchronize()
     cap = max(4096, int(F * H * W / 1500))
@@ -43,6 +46,6 @@ for H, W, dt in CASES:
         L.pmi_last_kernel_ms(ctypes.byref(a), ctypes.byref(b))
         ts.append(a.value)
     gb = mov.numel() * mov.element_size() / 1e9
-    print(f"{H:5d} x {W:5d} {dt:8s} frames {F:7d}  rows {int(dn.item()):9d}  scan {min(ts[1:]):8.3f} ms  {gb / (min(ts[1:]) * 1e-3):6.0f} GB/s  "
+    print(f"{H:5d} x {W:5d} {dt:13s} frames {F:7d}  rows {int(dn.item()):9d}  scan {min(ts[1:]):8.3f} ms  {gb / (min(ts[1:]) * 1e-3):6.0f} GB/s  "
           f"{mov.numel() / (min(ts[1:]) * 1e-3) / 1e12:5.2f} Tpx/s", flush=True)
     del mov

@@ -55,6 +55,28 @@ OPS2(k_pk_add_f32, "v_pk_add_f32 %0, %0, %1")
 OPS2(k_fma_f64, "v_fma_f64 %0, %0, %1, %1")
 OPS2(k_mul_f64, "v_mul_f64 %0, %0, %1")
 OPS2(k_addd_f64, "v_add_f64 %0, %0, %1")
+#define OPS3(NAME, ASMSTR, TD, TS)                                                               \
+    __global__ void NAME(unsigned *out, int iters)                                               \
+    {                                                                                            \
+        TD a0 = (TD)threadIdx.x, a1 = a0 + 3, a2 = a0 + 5, a3 = a0 + 7, a4 = a0 + 11, a5 = a0 + 13, a6 = a0 + 17, a7 = a0 + 19; \
+        TS b = (TS)(threadIdx.x + 1.25);                                                         \
+        for (int i = 0; i < iters; i++) {                                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a0) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a1) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a2) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a3) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a4) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a5) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a6) : "v"(b));                                        \
+            asm volatile(ASMSTR "\n" : "+v"(a7) : "v"(b));                                        \
+        }                                                                                        \
+        out[blockIdx.x * blockDim.x + threadIdx.x] = (unsigned)(a0 + a1 + a2 + a3 + a4 + a5 + a6 + a7); \
+    }
+OPS3(k_cvt_f32_f64, "v_cvt_f32_f64 %0, %1", float, double)
+OPS3(k_cvt_f64_f32, "v_cvt_f64_f32 %0, %1", double, float)
+OPS3(k_rcp_f64, "v_rcp_f64 %0, %1", double, double)
+OPS3(k_sqrt_f64, "v_sqrt_f64 %0, %1", double, double)
+OPS3(k_cvt_f32_i32, "v_cvt_f32_i32 %0, %1", float, int)
 OPS(k_lshl_or, "v_lshl_or_b32 %0, %0, 1, %1")
 OPS(k_mov_dpp, "v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
 OPS(k_add_dpp, "v_add_f32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")
@@ -80,13 +102,13 @@ template <typename K> void run(const char *name, K k, int waves_per_simd)
 }
 int main()
 {
-    for (int w : {1, 2, 4, 8}) {
+    for (int w : {2, 8}) {
         run("v_pk_max_u16", k_pk_max, w); run("v_max_u32", k_max_u32, w); 
         
         run("v_exp_f32", k_exp, w);
         run("v_fma_f32", k_fma, w); run("v_mul_f32", k_mul_f32, w);
         run("v_pk_fma_f32", k_pk_fma_f32, w); run("v_pk_mul_f32", k_pk_mul_f32, w); run("v_pk_add_f32", k_pk_add_f32, w);
-        run("v_fma_f64", k_fma_f64, w); run("v_mul_f64", k_mul_f64, w); run("v_add_f64", k_addd_f64, w);
+        run("v_fma_f64", k_fma_f64, w); run("v_mul_f64", k_mul_f64, w); run("v_add_f64", k_addd_f64, w); run("v_cvt_f32_f64", k_cvt_f32_f64, w); run("v_cvt_f64_f32", k_cvt_f64_f32, w); run("v_rcp_f64", k_rcp_f64, w); run("v_sqrt_f64", k_sqrt_f64, w); run("v_cvt_f32_i32", k_cvt_f32_i32, w);
         run("v_rcp_f32", k_rcp, w);
          run("v_add_f32_dpp", k_add_dpp, w);
     }

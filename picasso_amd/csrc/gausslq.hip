@@ -1228,26 +1228,31 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
 // Jacobian (the widest lane group serves every box; the sums in MINPACK's order whatever the mode: those bits do not
 // depend on the lane layout), one spot per lane in the step, until none of its spots is running.  Nothing in here waits for
 // another wavefront.
-constexpr int LQ_FIN_GS = 64, LQ_FIN_E = 7;
-template <bool CR, bool FLAG, bool FRAG, bool STRICT = true>       // (STRICT a parameter so that the tree-sum branch of the body is discarded)
+// The lane group of the Jacobian follows the box as in lq_jacobian_kernel, in three shapes: 8 lanes x 7 rows up to 7x7 (eight of
+// the wavefront's running spots per pass), 32 x 8 up to 15x15 (two), 64 x 7 above (one).  With one 64-lane group for every box
+// a 3x3 batch — nine residuals for six parameters, a third of the fits still running after the queued rounds — took 57 ms per
+// 2^20 spots instead of 17.
+template <int GS, int E, bool CR, bool FLAG, bool FRAG, bool STRICT = true>       // (STRICT a parameter so that the tree-sum branch of the body is discarded)
 __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_finish_kernel(Params p, LqState st, const int32_t *__restrict__ list,
                                                                                   const unsigned *__restrict__ list_n,
                                                                                   int32_t *__restrict__ tie_list, unsigned *__restrict__ tie_n)
 {
-    constexpr int GS = LQ_FIN_GS, E = LQ_FIN_E;
+    constexpr int NGRP = LQ_STEP_NT / GS;
     constexpr bool FROM_MOVIE = false;
     static_assert(STRICT, "the finishing kernel adds in MINPACK's order");
+    static_assert(LQ_STEP_NT == 64, "one wavefront per workgroup");
     // dynamic LDS: [64] spot indices, the x profile of the current evaluation (box x 64 floats), the tile of 64 x m floats
-    // (boxes up to 9), the chains' 6 columns of box^2 (+ 1) doubles
+    // (boxes up to 9), the chains' 6 columns of box^2 (+ 1) doubles per lane group
     extern __shared__ __attribute__((aligned(16))) char s_dyn[];
     const int size = p.box, m = size * size, hsz = size / 2;
     const bool staged = m <= LQ_TILE_MAXPIX;
     int64_t (&s_idx)[LQ_STEP_NT] = *reinterpret_cast<int64_t (*)[LQ_STEP_NT]>(s_dyn);
     float (*s_px)[LQ_STEP_NT] = reinterpret_cast<float (*)[LQ_STEP_NT]>(s_dyn + LQ_STEP_NT * sizeof(int64_t));
     float *s_tile = reinterpret_cast<float *>(s_dyn + LQ_STEP_NT * sizeof(int64_t) + (size_t)size * LQ_STEP_NT * sizeof(float));
+    const int tid = threadIdx.x, lane = tid % GS, grp = tid / GS;
     double *sbuf = reinterpret_cast<double *>(s_dyn + ((LQ_STEP_NT * sizeof(int64_t) + (size_t)size * LQ_STEP_NT * sizeof(float) +
-                                                         (staged ? (size_t)LQ_STEP_NT * m * sizeof(float) : 0) + 15) & ~(size_t)15));
-    const int tid = threadIdx.x, lane = tid;                   // one group = the wavefront
+                                                         (staged ? (size_t)LQ_STEP_NT * m * sizeof(float) : 0) + 15) & ~(size_t)15)) +
+                   (size_t)grp * (size_t)(6 * ((m + 1) & ~1));
     const int64_t items = (int64_t)*list_n;
     int ri[E], rj[E];
     bool act[E];
@@ -1276,12 +1281,21 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_finish_kerne
         for (;;) {
             const unsigned long long run = __ballot(running);
             if (run == 0ull) break;
-            // (a) a Jacobian for every running spot, one after the other
-            for (unsigned long long rest = run; rest != 0ull; rest &= rest - 1ull) {
-                const int src = (int)__builtin_ctzll(rest);
-                const int64_t s = (int64_t)__builtin_amdgcn_readlane((int)s_mine, src);      // spot indices are below 2^31
+            // (a) a Jacobian for every running spot, NGRP of them per pass: group g takes the g-th of those left
+            const int any_src = (int)__builtin_ctzll(run);
+            for (unsigned long long rest = run; rest != 0ull;) {
+                int src = -1;
+#pragma unroll
+                for (int g = 0; g < NGRP; g++) {
+                    if (rest != 0ull) {
+                        if (g == grp) src = (int)__builtin_ctzll(rest);
+                        rest &= rest - 1ull;
+                    }
+                }
+                // a group without a spot repeats one and does not store (keeps the groups in lockstep)
+                const bool store = src >= 0;
+                const int64_t s = (int64_t)__shfl((int)s_mine, store ? src : any_src);       // spot indices are below 2^31
                 const int64_t ls = s - st.first;
-                const bool store = true;
 #include "lq_jacobian_body.inc"
             }
             __threadfence();                                   // the factors the lanes above wrote, read by the lane of each spot below
@@ -1382,6 +1396,15 @@ __global__ void lq_stats_add_kernel(const unsigned *__restrict__ tie_n, unsigned
     if (threadIdx.x >= 1 && threadIdx.x < 8) stats[threadIdx.x] += tie_n[threadIdx.x];
 }
 
+template <bool CR, bool FLAG, bool FRAG>
+static void launch_finish(int shape, dim3 grid, size_t lds, hipStream_t s, const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n,
+                          int32_t *tie_list, unsigned *tie_n)
+{
+    if (shape == 0) hipLaunchKernelGGL((lq_finish_kernel<8, 7, CR, FLAG, FRAG>), grid, dim3(LQ_STEP_NT), lds, s, p, st, list, list_n, tie_list, tie_n);
+    else if (shape == 1) hipLaunchKernelGGL((lq_finish_kernel<32, 8, CR, FLAG, FRAG>), grid, dim3(LQ_STEP_NT), lds, s, p, st, list, list_n, tie_list, tie_n);
+    else hipLaunchKernelGGL((lq_finish_kernel<64, 7, CR, FLAG, FRAG>), grid, dim3(LQ_STEP_NT), lds, s, p, st, list, list_n, tie_list, tie_n);
+}
+
 // One call = batches of 2 Mi spots; a batch = start values, LQ_ROUNDS rounds of (Jacobian + QR, step) over the spots
 // still running — on photon data every fit is done by then —, one launch of lq_finish_kernel for whatever is left, then
 // the second pass of the mode (refit: the spots with a decision near its threshold; strict: those with a float32
@@ -1427,11 +1450,13 @@ static int launch(Params p, hipStream_t s)
     const size_t init_lds = 256 * sizeof(int64_t) + (staged ? (size_t)256 * mpix * sizeof(float) : 0);
     const size_t step_lds = LQ_STEP_NT * sizeof(int64_t) + (size_t)p.box * LQ_STEP_NT * sizeof(float) +
                             (staged ? (size_t)LQ_STEP_NT * mpix * sizeof(float) : 0);
-    const size_t fin_lds = ((step_lds + 15) & ~(size_t)15) + (size_t)6 * ((mpix + 1) & ~1) * sizeof(double);
+    const int fin_shape = p.box <= 7 ? 0 : (p.box <= 15 ? 1 : 2);          // lq_finish_kernel's lane group: 8 x 7, 32 x 8, 64 x 7
+    const size_t fin_lds = ((step_lds + 15) & ~(size_t)15) + (size_t)(fin_shape == 0 ? 8 : (fin_shape == 1 ? 2 : 1)) * 6 * ((mpix + 1) & ~1) * sizeof(double);
     const dim3 fin_grid((unsigned)std::min<int64_t>((int64_t)cus * 8, std::max<int64_t>(1, cap)));
     // rounds queued before the finishing kernel: a fit of an n x n box takes (nfev - 1) / 7 of them — 2 to 4 at 7x7 (none left
     // after five), up to ten at 13x13, where the finishing kernel's one spot per Jacobian would be the slower way for many
-    const int rounds = p.box <= 7 ? LQ_ROUNDS : (p.box <= 9 ? LQ_ROUNDS + 1 : (p.box <= 13 ? LQ_ROUNDS + 4 : LQ_ROUNDS + 7));
+    // (3x3: nine residuals for six parameters — a third of the fits are still running after five rounds, and a round costs little)
+    const int rounds = p.box <= 3 ? LQ_ROUNDS + 7 : (p.box <= 7 ? LQ_ROUNDS : (p.box <= 9 ? LQ_ROUNDS + 1 : (p.box <= 13 ? LQ_ROUNDS + 4 : LQ_ROUNDS + 7)));
     for (int64_t first = 0; first < Ntotal; first += BATCH) {
         const int64_t count = std::min<int64_t>(BATCH, Ntotal - first);
         st.first = first;
@@ -1462,24 +1487,22 @@ static int launch(Params p, hipStream_t s)
             PMI_HIP(hipGetLastError());
             cur = nxt; cur_n = nxt_n;
         }
-        if (all_strict) hipLaunchKernelGGL((lq_finish_kernel<false, false, true>), fin_grid, dim3(LQ_STEP_NT), fin_lds, s, p, st, cur, cur_n, tie_list, tie_n);
-        else hipLaunchKernelGGL((lq_finish_kernel<false, true, false>), fin_grid, dim3(LQ_STEP_NT), fin_lds, s, p, st, cur, cur_n, tie_list, tie_n);
+        if (all_strict) launch_finish<false, false, true>(fin_shape, fin_grid, fin_lds, s, p, st, cur, cur_n, tie_list, tie_n);
+        else launch_finish<false, true, false>(fin_shape, fin_grid, fin_lds, s, p, st, cur, cur_n, tie_list, tie_n);
         hipLaunchKernelGGL(lq_stats_add_kernel, dim3(1), dim3(64), 0, s, (const unsigned *)tie_n, stats, no_strict ? 0 : 1);
         // ---- pass 1: the spots of tie_list again from their start values (refit: sequential sums; strict: exp rounded correctly)
         if (!no_strict) {
             hipLaunchKernelGGL((lq_init_kernel<FROM_MOVIE>), dim3((unsigned)((count + 255) / 256)), dim3(256), init_lds, s, p, st, count,
                                (const int32_t *)tie_list, (const unsigned *)tie_n);
-            if (all_strict) hipLaunchKernelGGL((lq_finish_kernel<true, false, false>), fin_grid, dim3(LQ_STEP_NT), fin_lds, s, p, st, (const int32_t *)tie_list,
-                                               (const unsigned *)tie_n, (int32_t *)nullptr, (unsigned *)nullptr);
-            else hipLaunchKernelGGL((lq_finish_kernel<false, false, false>), fin_grid, dim3(LQ_STEP_NT), fin_lds, s, p, st, (const int32_t *)tie_list,
-                                    (const unsigned *)tie_n, (int32_t *)nullptr, (unsigned *)nullptr);
+            if (all_strict) launch_finish<true, false, false>(fin_shape, fin_grid, fin_lds, s, p, st, tie_list, tie_n, nullptr, nullptr);
+            else launch_finish<false, false, false>(fin_shape, fin_grid, fin_lds, s, p, st, tie_list, tie_n, nullptr, nullptr);
         }
         PMI_HIP(hipGetLastError());
     }
     g_lq_stats[g_lq_stats_second ? 1 : 0] = stats;
     g_lq_stats_stream[g_lq_stats_second ? 1 : 0] = s;
     if (!g_lq_stats_second) g_lq_stats[1] = nullptr;
-    g_lq_stats_generation = scratch_generation();
+    g_lq_stats_generation = scratch_generation(SCR_LQ_STATS);
     g_lq_rounds[0] = rounds; g_lq_rounds[1] = no_strict ? 0 : 1;
     return PMI_OK;
 }
@@ -1487,7 +1510,7 @@ static int launch(Params p, hipStream_t s)
 static int read_lq_stats(unsigned (&h)[16])
 {
     for (unsigned &v : h) v = 0;
-    if (!g_lq_stats[0] || g_lq_stats_generation != scratch_generation()) return PMI_OK;      // no fit yet, or its buffers are gone
+    if (!g_lq_stats[0] || g_lq_stats_generation != scratch_generation(SCR_LQ_STATS)) return PMI_OK;      // no fit yet, or its buffers are gone
     for (int k = 0; k < 2; k++) {
         if (!g_lq_stats[k]) continue;
         unsigned part[16];

@@ -54,7 +54,7 @@ int scratch(int slot, size_t bytes, void **ptr);
 int scratch_release_all();
 int scratch_enter_inner();           // -> the bank to hand back to scratch_leave_inner
 void scratch_leave_inner(int was);
-unsigned scratch_generation();      // bumped whenever buffers are released: pointers taken before are stale
+unsigned scratch_generation(int slot);      // bumped whenever a buffer of that slot (any bank) is released: pointers into it taken before are stale
 // Fused pipelines: *d_rows = *d_total if it fits the caller's capacity, else 0 (the identification columns were not
 // written; the caller sees *d_total > cap and resubmits), so that the fit stages never follow stale rows.
 int rows_to_fit(const int64_t *d_total, int64_t cap, const int64_t **d_rows, hipStream_t s);

@@ -39,15 +39,15 @@ static ScratchBuf g_scratch_banks[SCR_BANKS][SCR_NUM];
 // (pmi_scratch_bank) and never see each other's records or fit state
 static thread_local int g_scratch_bank = 0;
 static std::mutex g_scratch_mu;
-static unsigned g_scratch_generation = 0;
-unsigned scratch_generation() { std::lock_guard<std::mutex> lk(g_scratch_mu); return g_scratch_generation; }
+static unsigned g_scratch_generation[SCR_NUM] = {};       // per slot: a record in one slot outlives the growth of another
+unsigned scratch_generation(int slot) { std::lock_guard<std::mutex> lk(g_scratch_mu); return g_scratch_generation[slot]; }
 
 int scratch(int slot, size_t bytes, void **ptr)
 {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
     ScratchBuf &b = g_scratch_banks[g_scratch_bank][slot];
     if (b.bytes < bytes) {
-        if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; g_scratch_generation++; }
+        if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; g_scratch_generation[slot]++; }
         size_t want = bytes + bytes / 4 + 4096;   // headroom so repeated calls stop reallocating
         PMI_HIP(hipMalloc(&b.p, want));
         b.bytes = want;
@@ -59,7 +59,7 @@ int scratch(int slot, size_t bytes, void **ptr)
 int scratch_release_all()
 {
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    g_scratch_generation++;
+    for (unsigned &g : g_scratch_generation) g++;
     for (auto &bank : g_scratch_banks)
         for (auto &b : bank)
             if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }

@@ -582,35 +582,6 @@ static double g_mle_margin = 0.001;
 // [0] = spots re-fitted, [1..FLAG_REASONS] = spots flagged per criterion), valid while the scratch generation stands
 static thread_local const unsigned *g_last_stats[2] = {nullptr, nullptr};      // [1]: the second frame range of a fused call
 static thread_local unsigned g_last_stats_generation = 0;
-// The side stream of the first re-fit (fit_impl): one per frame range in flight, made on first use
-struct RefitLane {
-    hipStream_t st = nullptr;
-    hipEvent_t fork = nullptr, done = nullptr;
-    int make()
-    {
-        if (st) return PMI_OK;
-        PMI_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
-        PMI_HIP(hipEventCreateWithFlags(&fork, hipEventDisableTiming));
-        PMI_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
-        return PMI_OK;
-    }
-};
-static thread_local RefitLane g_refit_lane[2];
-struct RefitJoin {
-    RefitLane *lane = nullptr;
-    hipStream_t s = nullptr;
-    void arm(RefitLane *l, hipStream_t st) { lane = l; s = st; }
-    bool armed() const { return lane != nullptr; }
-    int join()
-    {
-        RefitLane *l = lane;
-        lane = nullptr;
-        PMI_HIP(hipEventRecord(l->done, l->st));
-        PMI_HIP(hipStreamWaitEvent(s, l->done, 0));
-        return PMI_OK;
-    }
-    ~RefitJoin() { if (lane) (void)join(); }
-};
 static thread_local bool g_stats_second = false;                                  // the fit being queued is that second range
 
 __global__ void zero_words_kernel(unsigned *__restrict__ a, int na, unsigned *__restrict__ b, int nb)
@@ -659,7 +630,8 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     int rc;
     // per batch: three queue words (Newton stage, final stage, final stage of the second re-fit) and two counters (spots
     // flagged by the Newton loop, spots found unstable by the Fisher pass)
-    if ((rc = scratch(SCR_FIT, (size_t)nb * 32 + 64, &ptr)) != PMI_OK) return rc;
+    // (+ two queue words of the re-fit kernels over those two lists)
+    if ((rc = scratch(SCR_FIT, (size_t)nb * 40 + 64, &ptr)) != PMI_OK) return rc;
     // per spot of a batch: 21 doubles of Fisher triangle + 12 floats of Newton start state + a slot in each of the two lists
     const size_t per_batch = (size_t)std::min<int64_t>(p.N, BATCH);
     // (+ with the deferred exact stage: the list of the accepted candidates of the batch and its block counters)
@@ -673,11 +645,12 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     unsigned char *refit_mark = reinterpret_cast<unsigned char *>(acc_blk + acc_blocks);
     unsigned long long *queues = (unsigned long long *)ptr;
     unsigned *flag_counts = (unsigned *)(queues + 3 * nb);           // [0, nb): flagged, [nb, 2 nb): unstable
+    unsigned *strict_queues = flag_counts + 2 * nb;                  // [0, nb): first re-fit, [nb, 2 nb): second
     void *sptr = nullptr;
     if ((rc = scratch(SCR_STATS, 64, &sptr)) != PMI_OK) return rc;
     unsigned *stats = (unsigned *)sptr;
     // (one launch for the two small blocks; the marks of the re-fit are cleared by the start-value kernel where there is one)
-    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, (unsigned *)ptr, (int)(nb * 8), stats, 16);
+    hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, (unsigned *)ptr, (int)(nb * 10), stats, 16);
     p.flag_reasons = stats + 1;
     p.fisher = (double *)fptr;
     static const char *menv = tuning_env("PMI_MLE_MARGIN");       // overrides the margin of pmi_mle_set_mode (tuning runs)
@@ -709,6 +682,7 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         p.N = std::min<int64_t>(Ntotal, p.first + BATCH);
         p.flag_list = mode == PMI_MLE_REFIT ? flag_list : nullptr;
         p.flag_count = flag_counts + bi;
+        p.strict_queue = strict_queues + bi;
         p.refit_mark = mode == PMI_MLE_REFIT ? refit_mark : nullptr;
         if (p.refit_mark && !g8) PMI_HIP(hipMemsetAsync(refit_mark, 0, (size_t)(p.N - p.first), s));
         const int64_t count = p.N - p.first;
@@ -722,7 +696,6 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
                 if (from_movie) launch_fit_ppl<5, true>(ppl, grid, s, p, stages); else launch_fit_ppl<5, false>(ppl, grid, s, p, stages);
             }
         };
-        RefitJoin refit_join;                                // (joins the side stream on every way out of this batch)
         // Newton stage: boxes <= 15 run eight or four spots per wavefront (gaussmle_g8.hip), boxes 17..21 one
         // wavefront per spot; then the flagged spots again in the reference's arithmetic; then Fisher matrix and
         // log-likelihood at the final thetas
@@ -746,19 +719,9 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
             }
             launch_fit_g8(q, method, false, g_cu_count, state, FIT_STAGE_ITERATE_ONLY, s);
             PMI_HIP(hipGetLastError());
-            if (mode == PMI_MLE_REFIT) {
-                // The flagged spots (0.7 % on photon data) again in the reference's arithmetic.  The launch lasts as long as
-                // its slowest fit (up to max_it iterations of dependent float64 chains: 0.15 - 0.2 ms on a few thousand
-                // spots), so it runs on a side stream BESIDE the Fisher pass and the inverse of all the other spots; the
-                // Newton loop marked the flagged ones (refit_mark), their Fisher pass follows below once the re-fit is in.
-                RefitLane &lane = g_refit_lane[g_stats_second ? 1 : 0];
-                if ((rc = lane.make()) != PMI_OK) return rc;
-                PMI_HIP(hipEventRecord(lane.fork, s));
-                PMI_HIP(hipStreamWaitEvent(lane.st, lane.fork, 0));
-                refit_join.arm(&lane, s);
-                launch_fit_strict(q, method, false, flag_list, q.flag_count, count, g_cu_count, lane.st);
-                PMI_HIP(hipGetLastError());
-            }
+            if (mode == PMI_MLE_REFIT)
+                launch_fit_strict(q, method, false, flag_list, q.flag_count, count, g_cu_count, s);
+            PMI_HIP(hipGetLastError());
             launch_fit_g8(q, method, false, g_cu_count, state, FIT_STAGE_FINAL, s);
         } else {
         if (mode == PMI_MLE_STRICT) {
@@ -786,22 +749,12 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
         const bool second = mode == PMI_MLE_REFIT;
         crlb(nullptr, nullptr, second ? unstable_list : nullptr, second ? unstable_n : nullptr);
         PMI_HIP(hipGetLastError());
-        if (refit_join.armed()) {
-            // the re-fit that ran beside the two launches above: Fisher pass and inverse of its spots
-            if ((rc = refit_join.join()) != PMI_OK) return rc;
-            FitParams r = p;
-            r.spots = cut - p.first * (int64_t)(p.box * p.box);
-            r.final_list = flag_list; r.final_list_n = p.flag_count;
-            launch_fit_g8(r, method, false, g_cu_count, state, FIT_STAGE_FINAL, s);
-            PMI_HIP(hipGetLastError());
-            crlb(flag_list, p.flag_count, nullptr, nullptr);
-            PMI_HIP(hipGetLastError());
-        }
         if (second) {
             // Second re-fit: the spots whose iteration does not contract at the fitted theta (known only now, from the Fisher
             // matrix) — reference arithmetic, Fisher pass and inverse for these spots alone.  On photon data the list is empty
             // and the three launches exit at once.
             FitParams r = p;
+            r.strict_queue = strict_queues + nb + bi;
             if (cut) { r.spots = cut - p.first * (int64_t)(p.box * p.box); }
             const bool r_movie = cut ? false : from_movie;
             launch_fit_strict(r, method, r_movie, unstable_list, unstable_n, count, g_cu_count, s);

@@ -763,7 +763,6 @@ __global__ __launch_bounds__(FIT_NT) void g8_iterate_kernel(FitParams p, const f
                 if (gflag && p.flag_list) {
                     p.flag_list[atomicAdd(p.flag_count, 1u)] = (int32_t)sidx;
                     count_flag_reasons(p.flag_reasons, gflag);
-                    if (p.refit_mark) p.refit_mark[sidx - p.first] = 1;      // (the re-fit may still be running when crlb_kernel looks)
                 }
             }
             const unsigned long long want = pend | empty;

@@ -186,7 +186,9 @@ def config5(args, torch, orc, L, _lib, synth, cam, threads, timed, kernel_ms, ro
                       "config": {"workload": f"{F}-frame 512x512 uint16 astigmatic movie, {n} spots, identify(box 13) + fused cut + "
                                              "MLE sigmaxy + 17-column table, then bounded-Brent zfit", "frames": F, "box": 13},
                       "stages_ms": {"identify+gaussmle+table": 1e3 * t_m, "zfit": 1e3 * t_z},
-                      "mle": {"mode": backend.get_mle_mode()[0], "refit_spots": refit, "exact_stage_deferred_to_fit": bool(args.defer)},
+                      "mle": {"mode": backend.get_mle_mode()[0], "refit_spots": refit, "refit_reasons": backend.last_flag_reasons(),
+                              # (the library defers identify's exact stage to the fit for boxes <= 7 only: sixteen lanes per candidate cost more than they save at 13x13)
+                              "exact_stage_deferred_to_fit": False},
                       "roofline": roofline(movie.numel() * 2, scan_ms, fit_ms, n, "mle_fit_13x13 (g8 init/iterate/final + strict refit + crlb)",
                                            "fp32 valu issue; 406 B/spot algorithmic", 406.0),
                       "cpu_baseline": cpu}), flush=True)

@@ -19,7 +19,9 @@ bash tools/pmc_fit.sh /tmp/pmc_lqj "lq_jacobian" python3 tools/time_gausslq.py 1
 bash tools/pmc_fit.sh /tmp/pmc_lqs "lq_step" python3 tools/time_gausslq.py 1048576 7 > $OUT/${TAG}_lq_step_pmc.txt 2>&1
 python3 tools/bench_configs.py --only 3 > $OUT/${TAG}_config3.jsonl 2> $OUT/config3.err || tail -3 $OUT/config3.err
 python3 tools/bench_configs.py --only 5 > $OUT/${TAG}_config5.jsonl 2> $OUT/config5.err || tail -3 $OUT/config5.err
-python3 tools/bench_configs.py --only 5 --defer 0 --cpu-seconds 0 > $OUT/${TAG}_config5_nodefer.jsonl 2>> $OUT/config5.err
+(cd /tmp && rocprofv3 --kernel-trace --stats -d /tmp/prof_c5 -- python3 $OLDPWD/tools/bench_configs.py --only 5 --cpu-seconds 0 --steps 3 > /tmp/prof_c5.log 2>&1)
+python3 tools/rocprof_summary.py /tmp/prof_c5 > $OUT/${TAG}_config5_kernel_stats.txt
+python3 tools/time_mle_eps.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_mle_eps.jsonl
 python3 tools/time_identify_shapes.py 7 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_identify_shapes.txt
 (for m in refit strict; do for b in 3 5 7 9 13 21; do PMI_LQ_MODE=$m python3 tools/time_gausslq.py 1048576 $b 2>&1 | tail -2 | head -1 | sed "s/^/[$m] /"; done; done; python3 tools/time_lq_ranges.py 2>&1 | grep -v amdgpu.ids) > $OUT/${TAG}_gausslq_times.txt 2>&1
 ls -la $OUT

@@ -239,6 +239,13 @@ struct EnormAcc {
 constexpr double LQ_PIVOT_TIE = 1e-9;         // relative distance of two running column norms below which the pivot choice is a tie
 constexpr double LQ_RANK = 1e-3;             // |R_jj| / |column| below which the factor counts as rank deficient (re-fit)
 constexpr double LQ_TIE = 1e-12;              // relative distance of a decision from its threshold below which a spot is re-fitted
+// doubles of chain scratch per lane group: six columns of box^2 (+ 1) rows.  (LQ_SBUF_PAD: the PMC counts bank conflicts in 30 %
+// of the strict Jacobian kernel's LDS cycles, so the groups' column blocks were moved apart by 2 / 4 / 8 / 10 doubles: 7x7
+// 9.0 -> 9.2 / 9.7 / 9.7 / 9.7 ms per 2^20 spots, 13x13 70.9 -> 68.8 / 69.3 / 69.3 / 69.0, 5x5 unchanged.  Left at 0.)
+#ifndef LQ_SBUF_PAD
+#define LQ_SBUF_PAD 0
+#endif
+__host__ __device__ constexpr size_t lq_sbuf_doubles(int m) { return (size_t)6 * (size_t)((m + 1) & ~1) + LQ_SBUF_PAD; }
 __device__ __forceinline__ void grp_sync()
 {
     __builtin_amdgcn_wave_barrier();
@@ -841,7 +848,7 @@ __global__ __launch_bounds__(LQ_WAVES * 64, lq_jacobian_min_waves(GS, E, STRICT)
 {
     constexpr int NGRP = 64 / GS;                              // spots per wavefront
     extern __shared__ __attribute__((aligned(16))) char s_rows[];      // strict mode: 6 columns of box^2 (+ 1) doubles per group of the workgroup (the columns a step sums, side by side)
-    double *sbuf = STRICT ? reinterpret_cast<double *>(s_rows) + (size_t)(((threadIdx.x >> 6) * NGRP) + (threadIdx.x & 63) / GS) * (size_t)(6 * ((p.box * p.box + 1) & ~1))
+    double *sbuf = STRICT ? reinterpret_cast<double *>(s_rows) + (size_t)(((threadIdx.x >> 6) * NGRP) + (threadIdx.x & 63) / GS) * lq_sbuf_doubles(p.box * p.box)
                           : nullptr;
     const int lane = (threadIdx.x & 63) % GS;                  // lane inside the group
     const int grp = (threadIdx.x & 63) / GS;
@@ -1252,7 +1259,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_finish_kerne
     const int tid = threadIdx.x, lane = tid % GS, grp = tid / GS;
     double *sbuf = reinterpret_cast<double *>(s_dyn + ((LQ_STEP_NT * sizeof(int64_t) + (size_t)size * LQ_STEP_NT * sizeof(float) +
                                                          (staged ? (size_t)LQ_STEP_NT * m * sizeof(float) : 0) + 15) & ~(size_t)15)) +
-                   (size_t)grp * (size_t)(6 * ((m + 1) & ~1));
+                   (size_t)grp * lq_sbuf_doubles(m);
     const int64_t items = (int64_t)*list_n;
     int ri[E], rj[E];
     bool act[E];
@@ -1328,7 +1335,7 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
         return dim3((unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
     };
     // strict mode: m doubles of LDS per group (the rows of one column at a time, summed in MINPACK's order)
-    auto lds_for = [&](int spots_per_wave) { return STRICT ? (size_t)LQ_WAVES * spots_per_wave * 6 * ((m + 1) & ~1) * sizeof(double) : (size_t)0; };
+    auto lds_for = [&](int spots_per_wave) { return STRICT ? (size_t)LQ_WAVES * spots_per_wave * lq_sbuf_doubles(m) * sizeof(double) : (size_t)0; };
     static const bool g16 = tuning_env("PMI_LQ_GROUP16") != nullptr;      // A/B: the 16-lane groups for boxes up to 7
     // (more than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel)
 #define LQ_JAC(GS, E, SPW) do { \
@@ -1451,7 +1458,7 @@ static int launch(Params p, hipStream_t s)
     const size_t step_lds = LQ_STEP_NT * sizeof(int64_t) + (size_t)p.box * LQ_STEP_NT * sizeof(float) +
                             (staged ? (size_t)LQ_STEP_NT * mpix * sizeof(float) : 0);
     const int fin_shape = p.box <= 7 ? 0 : (p.box <= 15 ? 1 : 2);          // lq_finish_kernel's lane group: 8 x 7, 32 x 8, 64 x 7
-    const size_t fin_lds = ((step_lds + 15) & ~(size_t)15) + (size_t)(fin_shape == 0 ? 8 : (fin_shape == 1 ? 2 : 1)) * 6 * ((mpix + 1) & ~1) * sizeof(double);
+    const size_t fin_lds = ((step_lds + 15) & ~(size_t)15) + (size_t)(fin_shape == 0 ? 8 : (fin_shape == 1 ? 2 : 1)) * lq_sbuf_doubles(mpix) * sizeof(double);
     const dim3 fin_grid((unsigned)std::min<int64_t>((int64_t)cus * 8, std::max<int64_t>(1, cap)));
     // rounds queued before the finishing kernel: a fit of an n x n box takes (nfev - 1) / 7 of them — 2 to 4 at 7x7 (none left
     // after five), up to ten at 13x13, where the finishing kernel's one spot per Jacobian would be the slower way for many

@@ -152,3 +152,13 @@ def test_fuzz_residuals_round3(be, orc):
         if int(z["box"]) != 3:
             continue                 # the 13x13 residual has a test of its own above
         check_case(be, orc, z["spots"], float(z["eps"]), int(z["max_it"]), str(z["method"]), os.path.basename(path))
+
+
+@pytest.mark.parametrize("box,n,groups", [(7, 120000, 12288), (13, 40000, 6144)])
+def test_refit_lists_longer_than_one_round_of_the_refit_kernel(be, orc, box, n, groups):
+    """The re-fit kernel deals the first `groups` entries of its list to its lane groups and hands the rest out through a
+    queue word (csrc/gaussmle_strict.hip).  At eps 1e-4 the margin flag sends a good share of these spots there: the list
+    is several rounds long, and every row must still be the oracle's."""
+    spots = knob_spots(box, n, 4242 + box)
+    check_case(be, orc, spots, 1e-4, 100, "sigmaxy", f"box {box}, {n} spots, eps 1e-4")
+    assert be.last_refit_count() > 1.5 * groups, be.last_refit_count()

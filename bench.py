@@ -44,6 +44,8 @@ def parse():
     ap.add_argument("--box", type=int, default=7)
     ap.add_argument("--min-ng", type=float, default=5000.0)
     ap.add_argument("--method", default="sigmaxy")
+    ap.add_argument("--eps", type=float, default=1e-3,
+                    help="convergence criterion of the MLE fit (the GUI's default; 1e-4 re-fits 11 %% of the spots: DESIGN.md section 7)")
     ap.add_argument("--cpu-seconds", type=float, default=15.0, help="CPU-baseline budget (0 = skip)")
     ap.add_argument("--profile-steps", type=int, default=5, help="extra instrumented steps for per-kernel time")
     ap.add_argument("--strict-steps", type=int, default=2,
@@ -126,7 +128,7 @@ def main():
 
     def run(table, d_n, cap):
         rc = L.pmi_localize_mle_dev(ctypes.c_void_p(movie.data_ptr()), 0, F, H, W, box, args.min_ng, None, 0, F - 1,
-                                    cam["Baseline"], cam["Sensitivity"], cam["Gain"], 1e-3, 100, method,
+                                    cam["Baseline"], cam["Sensitivity"], cam["Gain"], args.eps, 100, method,
                                     ctypes.c_void_p(table.data_ptr()), cap, ctypes.c_void_p(d_n.data_ptr()), stream)
         _lib.check(rc, "pmi_localize_mle_dev")
 
@@ -344,7 +346,7 @@ def main():
         kernels["mle_fit"]["bound"] = "fp32 valu (no MFMA shape); algorithmic bytes are 166 B/spot"
         cpu = None
         if world == 1 and args.cpu_seconds > 0:
-            cpu = cpu_baseline(movie, cam, box, args.min_ng, args.method, args.cpu_seconds)
+            cpu = cpu_baseline(movie, cam, box, args.min_ng, args.method, args.cpu_seconds, args.eps)
         result = {
             "metric": "localizations/sec (7x7 ROI, MLE)", "value": value, "unit": "localizations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -364,7 +366,7 @@ def main():
                                       + (" (double-buffered: overlaps the next step's compute)" if nbuf == 2 else "")
                                       if grouped else ""),
                        "frames": F, "height": H, "width": W, "box": box, "min_net_gradient": args.min_ng,
-                       "eps": 1e-3, "max_it": 100, "localizations_total": n_total,
+                       "eps": args.eps, "max_it": 100, "localizations_total": n_total,
                        "mle_mode": mle_mode, "refit_margin": mle_margin, "refit_spots_rank0": refit,
                        "frame_ranges_in_flight": args.ranges,
                        "all_gather": gather_impl,
@@ -414,7 +416,7 @@ def pmc_traffic_bytes(F, H, W, box, scan_kernel):
             f"{PMC_TRAFFIC_FILE} (rocprofv3 --pmc TCC_EA0_RDREQ_sum / WRITE_SIZE passes of tools/pmc_scan.sh, kernel {profiled})")
 
 
-def cpu_baseline(movie, cam, box, min_ng, method, budget_s):
+def cpu_baseline(movie, cam, box, min_ng, method, budget_s, eps=1e-3):
     """The CPU oracle (C restatement of the reference algorithm) on this box's host
     cores, on a bounded sample of the same movie: identify + get_spots + gaussmle."""
     from oracle import oracle as orc
@@ -429,7 +431,7 @@ def cpu_baseline(movie, cam, box, min_ng, method, budget_s):
         t0 = time.perf_counter()
         fr, y, x, ng = orc.identify(host, min_ng, box, threads=nthreads)
         spots = orc.get_spots(host, fr, y, x, box, cam)
-        orc.gaussmle(spots, 1e-3, 100, method, threads=nthreads)
+        orc.gaussmle(spots, eps, 100, method, threads=nthreads)
         return len(fr), time.perf_counter() - t0
 
     # The visible CPU count may exceed what the container may actually use (CPU quota): probe a
@@ -447,7 +449,7 @@ def cpu_baseline(movie, cam, box, min_ng, method, budget_s):
     n, dt = run(frames, threads)
     return {"value": n / dt, "unit": "localizations/s", "cores": threads, "kind": "port", "value_1_thread": n1 / dt1,
             "sample": f"first {frames} frames of the same movie ({n} spots), identify+get_spots+gaussmle "
-                      f"({method}, eps 1e-3, max_it 100), C/OpenMP restatement of the reference algorithm, "
+                      f"({method}, eps {eps:g}, max_it 100), C/OpenMP restatement of the reference algorithm, "
                       f"{dt:.1f} s"}
 
 

@@ -270,8 +270,10 @@ enum pmi_lq_mode { PMI_LQ_FAST = 0, PMI_LQ_REFIT = 1, PMI_LQ_STRICT = 2 };
 int pmi_gausslq_set_mode(int mode);
 int pmi_gausslq_get_mode(int *mode);
 int pmi_gausslq_last_refit_count(int64_t *n_refit);
-/* ... and which test sent them there (n <= 9 counters: pivot choice, lmpar's band, 0.1 fnorm1 < fnorm, the gain-ratio
- * thresholds, the ftol tests, a reduction at the noise level, the xtol test; a spot can carry several)        */
+/* ... and which test sent them there (n <= 10 counters: pivot choice, lmpar's band, 0.1 fnorm1 < fnorm, the gain-ratio
+ * thresholds, the ftol tests, a reduction at the noise level, the xtol test, [7] strict mode: a float32 rounding of the
+ * model within a few float64 ulps of a tie / a Jacobian outside the range of the short divisions; a spot can carry
+ * several; [8], [9]: rounds queued by the first pass, second passes run)                                     */
 int pmi_gausslq_last_tie_reasons(int64_t *counts, int n);
 int pmi_gausslq_dev(const float *d_spots, int64_t N, const int64_t *d_n, int box, float *d_thetas,
                     int32_t *d_info, int32_t *d_nfev, void *stream);

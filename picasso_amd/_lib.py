@@ -111,7 +111,10 @@ SYMBOLS = {
 }
 
 _lib = None
-_lock = threading.Lock()      # one context per process, calls serialised
+_lock = threading.Lock()      # one context per process, calls serialised — for every thread that never bound itself
+_tls = threading.local()       # .key = (device, bank) of a thread bound by bind_thread
+_bound_locks = {}
+_bound_locks_mu = threading.Lock()
 
 
 class HipBackendError(RuntimeError):
@@ -168,5 +171,29 @@ def ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p)
 
 
+def bind_thread(device: int, bank: int = 0) -> None:
+    """Make `device` the calling thread's device (pmi_set_device: HIP keeps the current device per thread) and `bank` its
+    scratch bank (pmi_scratch_bank).  Everything the library keeps on a device — scratch, tables, plans, side streams — is
+    keyed by the device current in the calling thread, so threads bound to different devices (or to the two banks of one
+    device) run side by side: `lock()` then serialises only threads bound alike.  A thread that never binds stays on HIP's
+    default device, bank 0, behind the one process-wide lock as before."""
+    L = load()
+    check(L.pmi_set_device(int(device)), "pmi_set_device")
+    check(L.pmi_scratch_bank(int(bank)), "pmi_scratch_bank")
+    _tls.key = (int(device), int(bank))
+
+
+def bound_to():
+    """(device, bank) the calling thread bound itself to, or None."""
+    return getattr(_tls, "key", None)
+
+
 def lock():
-    return _lock
+    key = getattr(_tls, "key", None)
+    if key is None:
+        return _lock
+    with _bound_locks_mu:
+        lk = _bound_locks.get(key)
+        if lk is None:
+            lk = _bound_locks[key] = threading.Lock()
+        return lk

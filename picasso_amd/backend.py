@@ -210,10 +210,11 @@ def last_lq_refit_count() -> int:
 LQ_MODES = {"fast": 0, "refit": 1, "strict": 2}
 
 
-def set_lq_mode(mode: str = "refit"):
+def set_lq_mode(mode: str = "strict"):
     """How the sums over the residual rows of the least-squares fit run (pmi_gausslq_set_mode): "fast" = tree sums
     only; "refit" = tree sums, spots with a decision of lmdif near its threshold fitted again in MINPACK's order;
-    "strict" = every spot in MINPACK's order (scipy.optimize.leastsq at picasso/gausslq.py:240-242, bit for bit)."""
+    "strict" (the library's default, and this function's) = every spot in MINPACK's order (scipy.optimize.leastsq at
+    picasso/gausslq.py:240-242: the oracle's bits)."""
     if mode not in LQ_MODES:
         raise ValueError(f"unknown gausslq mode {mode!r}")
     _lib.check(_lib.load().pmi_gausslq_set_mode(LQ_MODES[mode]), "pmi_gausslq_set_mode")
@@ -225,7 +226,7 @@ def get_lq_mode() -> str:
     return {v: k for k, v in LQ_MODES.items()}[m.value]
 
 
-LQ_TIE_REASONS = ("pivot", "lmpar", "fnorm", "ratio", "ftol", "noise", "xtol", "rounds_first_pass", "rounds_second_pass")
+LQ_TIE_REASONS = ("pivot", "lmpar", "fnorm", "ratio", "ftol", "noise", "xtol", "fragile", "rounds_first_pass", "rounds_second_pass")
 
 
 def last_lq_tie_reasons() -> dict:

@@ -22,213 +22,12 @@
 #include <cstdlib>
 #include <cstring>
 
-#include "fit_common.h"
-#include "exp_cr.h"
+#include "lq_common.h"
 
 #pragma clang fp contract(off)
 
 namespace pmi {
 namespace lq {
-
-constexpr double EPSMCH = 2.220446049250313e-16;
-constexpr double DWARF = 2.2250738585072014e-308;
-constexpr double RDWARF = 3.834e-20, RGIANT = 1.304e19;
-constexpr int LQ_WAVES = 4;
-#ifndef LQ_MIN_WAVES
-#define LQ_MIN_WAVES 2
-#endif
-
-struct Params {
-    const float *spots;
-    const void *movie;
-    const int32_t *frame, *y, *x;
-    int dtype;
-    int64_t Y, X;
-    float baseline, sensitivity, gain;
-    ConstDiv gdiv;
-    int64_t N;
-    const int64_t *d_n;
-    int box;
-    float *thetas;
-    int32_t *info, *nfev;
-};
-
-__device__ __forceinline__ double readlane_d(double v, int lane)
-{
-    long long b = __builtin_bit_cast(long long, v);
-    int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), lane);
-    int hi = __builtin_amdgcn_readlane((int)(b >> 32), lane);
-    return __builtin_bit_cast(double, ((long long)hi << 32) | (unsigned)lo);
-}
-__device__ __forceinline__ double wave_max_d(double v)
-{
-    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-    return v;
-}
-
-// A spot is fitted by a group of GS lanes: the whole wavefront (GS = 64) or one 16-lane DPP row
-// (GS = 16, four spots per wavefront — for boxes up to 7x7 the 6x6 stage, which every lane of the
-// group executes identically, is most of the work).  All lanes of a group follow the same control
-// flow, so row-wide DPP and bpermute never read an inactive lane.
-template <int GS> struct Grp;
-template <> struct Grp<64> {
-    static __device__ __forceinline__ double sum_d(double v) { return wave_sum_d(v); }
-    static __device__ __forceinline__ double max_d(double v) { return wave_max_d(v); }
-    static __device__ __forceinline__ float min_f(float v) { return wave_min(v); }
-    static __device__ __forceinline__ double bcast_d(double v, int k) { return readlane_d(v, k); }
-    static __device__ __forceinline__ bool any(bool c) { return __builtin_amdgcn_ballot_w64(c) != 0; }
-};
-template <> struct Grp<16> {
-    static __device__ __forceinline__ double sum_d(double v)
-    {
-        v += dpp_d<0xB1>(v);          // quad_perm [1,0,3,2]
-        v += dpp_d<0x4E>(v);          // quad_perm [2,3,0,1]
-        v += dpp_d<0x141>(v);         // row_half_mirror
-        v += dpp_d<0x140>(v);         // row_mirror: every lane of the row holds the row sum
-        return v;
-    }
-    static __device__ __forceinline__ double max_d(double v)
-    {
-        for (int off = 8; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-        return v;
-    }
-    static __device__ __forceinline__ float min_f(float v)
-    {
-        for (int off = 8; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-        return v;
-    }
-    static __device__ __forceinline__ double bcast_d(double v, int k)
-    {
-        return __shfl(v, (int)((threadIdx.x & 63u) & ~15u) + k);
-    }
-    static __device__ __forceinline__ bool any(bool c)
-    {
-        const unsigned long long b = __builtin_amdgcn_ballot_w64(c);
-        return ((b >> ((threadIdx.x & 63u) & ~15u)) & 0xffffull) != 0;
-    }
-};
-template <> struct Grp<8> {           // half a DPP row: eight spots per wavefront (boxes up to 7x7: 49 residuals = 7 per lane)
-    static __device__ __forceinline__ double sum_d(double v)
-    {
-        v += dpp_d<0xB1>(v);          // quad_perm [1,0,3,2]
-        v += dpp_d<0x4E>(v);          // quad_perm [2,3,0,1]
-        v += dpp_d<0x141>(v);         // row_half_mirror: every lane of the half row holds its sum
-        return v;
-    }
-    static __device__ __forceinline__ double max_d(double v)
-    {
-        for (int off = 4; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-        return v;
-    }
-    static __device__ __forceinline__ float min_f(float v)
-    {
-        for (int off = 4; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-        return v;
-    }
-    static __device__ __forceinline__ double bcast_d(double v, int k)
-    {
-        return __shfl(v, (int)((threadIdx.x & 63u) & ~7u) + k);
-    }
-    static __device__ __forceinline__ bool any(bool c)
-    {
-        const unsigned long long b = __builtin_amdgcn_ballot_w64(c);
-        return ((b >> ((threadIdx.x & 63u) & ~7u)) & 0xffull) != 0;
-    }
-};
-template <> struct Grp<32> {          // half a wavefront: two DPP rows, the partner row through bpermute
-    static __device__ __forceinline__ double sum_d(double v)
-    {
-        v = Grp<16>::sum_d(v);
-        return v + __shfl_xor(v, 16);
-    }
-    static __device__ __forceinline__ double max_d(double v)
-    {
-        for (int off = 16; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
-        return v;
-    }
-    static __device__ __forceinline__ float min_f(float v)
-    {
-        for (int off = 16; off >= 1; off >>= 1) v = fminf(v, __shfl_xor(v, off));
-        return v;
-    }
-    static __device__ __forceinline__ double bcast_d(double v, int k)
-    {
-        return __shfl(v, (int)((threadIdx.x & 63u) & ~31u) + k);
-    }
-    static __device__ __forceinline__ bool any(bool c)
-    {
-        const unsigned long long b = __builtin_amdgcn_ballot_w64(c);
-        return ((b >> ((threadIdx.x & 63u) & ~31u)) & 0xffffffffull) != 0;
-    }
-};
-// Indexing a 6-vector by a run-time (wave-uniform) index without leaving registers.
-// The empty asm hides the loads from InstCombine, which otherwise rewrites the select
-// chain into one load through a computed address and pins the array in scratch memory.
-__device__ __forceinline__ double opaque(double v) { asm("" : "+v"(v)); return v; }
-__device__ __forceinline__ double get6(const double (&a)[6], int i)
-{
-    double v = opaque(a[0]);
-#pragma unroll
-    for (int k = 1; k < 6; k++) { const double ak = opaque(a[k]); v = (i == k) ? ak : v; }
-    return v;
-}
-__device__ __forceinline__ void set6(double (&a)[6], int i, double v)
-{
-#pragma unroll
-    for (int k = 0; k < 6; k++) { const double ak = opaque(a[k]); a[k] = (i == k) ? v : ak; }
-}
-
-// MINPACK enorm over six wave-uniform values, sequential as published.
-__device__ __forceinline__ double enorm6(const double (&x)[6])
-{
-    double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0;
-    const double agiant = RGIANT / 6.0;
-#pragma unroll
-    for (int i = 0; i < 6; i++) {
-        const double xabs = fabs(x[i]);
-        if (xabs > RDWARF && xabs < agiant) { s2 += xabs * xabs; }
-        else if (xabs <= RDWARF) {
-            if (xabs > x3max) { double r = x3max / xabs; s3 = 1 + s3 * r * r; x3max = xabs; }
-            else if (xabs != 0) { double r = xabs / x3max; s3 += r * r; }
-        } else {
-            if (xabs > x1max) { double r = x1max / xabs; s1 = 1 + s1 * r * r; x1max = xabs; }
-            else { double r = xabs / x1max; s1 += r * r; }
-        }
-    }
-    if (s1 != 0) return x1max * sqrt(s1 + (s2 / x1max) / x1max);
-    if (s2 != 0) {
-        if (s2 >= x3max) return sqrt(s2 * (1 + (x3max / s2) * (x3max * s3)));
-        return sqrt(x3max * ((s2 / x3max) + (x3max * s3)));
-    }
-    return x3max * sqrt(s3);
-}
-
-// MINPACK enorm, one component at a time in the published order (the trial residuals are never stored)
-struct EnormAcc {
-    double s1 = 0, s2 = 0, s3 = 0, x1max = 0, x3max = 0, agiant;
-    __device__ __forceinline__ explicit EnormAcc(int n) : agiant(RGIANT / (double)n) {}
-    __device__ __forceinline__ void add(double xv)
-    {
-        const double xabs = fabs(xv);
-        if (xabs > RDWARF && xabs < agiant) { s2 += xabs * xabs; }
-        else if (xabs <= RDWARF) {
-            if (xabs > x3max) { double r = x3max / xabs; s3 = 1 + s3 * r * r; x3max = xabs; }
-            else if (xabs != 0) { double r = xabs / x3max; s3 += r * r; }
-        } else {
-            if (xabs > x1max) { double r = x1max / xabs; s1 = 1 + s1 * r * r; x1max = xabs; }
-            else { double r = xabs / x1max; s1 += r * r; }
-        }
-    }
-    __device__ __forceinline__ double norm() const
-    {
-        if (s1 != 0) return x1max * sqrt(s1 + (s2 / x1max) / x1max);
-        if (s2 != 0) {
-            if (s2 >= x3max) return sqrt(s2 * (1 + (x3max / s2) * (x3max * s3)));
-            return sqrt(x3max * ((s2 / x3max) + (x3max * s3)));
-        }
-        return x3max * sqrt(s3);
-    }
-};
 
 // ---- strict mode: the sums over the m rows in MINPACK's own (sequential) order ------------------------------------
 // The group kernels hold residual row r in lane r % GS, element r / GS, and add over the rows with DPP trees; MINPACK
@@ -336,30 +135,6 @@ __device__ __forceinline__ double enorm_rows(const double (&v)[E], int lane, int
     }
     return x3max * sqrt(s3);
 }
-
-// Residuals of the float32-stored model (gausslq.py:151-203).  The 2 * size profile values of an evaluation are spread
-// over the lanes of the group: one per lane (x profile at flat index f = lane < size, y profile at f - size), except for
-// the 8-lane groups, where lane l holds x-profile value l in slot 0 and y-profile value l in slot 1.  `which` = the
-// slots to evaluate (bit 0: x / the only slot, bit 1: y): a forward difference in x0 or sx leaves the y profile as it
-// is, one in the photons or the background leaves both — the values are the same function of the same arguments, so
-// what is reused is bit for bit what would have been recomputed (6 instead of 14 float64 exp per lane and Jacobian in
-// the 8-lane groups, 5 instead of 7 in the others).
-// A profile value is stored in float32 (gausslq.py:203): nrm * exp(..) is rounded to float64, then to float32.  The
-// device's exp and a CPU libm's are different functions within an ulp of the true one; where the float64 product sits
-// within a few of its ulps of a float32 rounding boundary, the last bit of exp decides the stored value.  `fragile`
-// reports that (strict mode: such a spot is fitted again with exp rounded correctly, exp_cr.h — 2 of 29 million fuzz
-// spots ended 8e-5 px from the oracle before this); in the float32 subnormal range fewer bits are kept.
-__device__ __forceinline__ unsigned fragile_f32_rounding(double p)
-{
-    // Does the float32 value change when p moves by 8 of its ulps either way?  In the normal float32 range 29 bits are
-    // dropped: fragile within 8 of their midpoint 2^28 — three 32-bit instructions on the low word (this sits in the hot
-    // profile loops of kernels that have no register to spare; asking the conversion itself, (float)(p (1 +- 2^-50)) != (float)p,
-    // costs three quarter-rate conversions per value: 7x7 +5 %, 13x13 +19 %).  Among the float32 subnormals fewer bits are
-    // kept and the test is not the right one — but a profile value below 1e-38 enters the model as photons x value + background,
-    // rounded to float32 again: whichever way it rounds, nothing a float64 sum of the fit can see.
-    return (unsigned)((((unsigned)__double2loint(p) & 0x1fffffffu) - 0x0ffffff8u) <= 16u);
-}
-template <bool CR> __device__ __forceinline__ double lq_exp(double x) { if constexpr (CR) return exp_cr(x); else return exp(x); }
 
 template <int GS, bool CR = false>
 __device__ __forceinline__ void profiles(const double (&th)[6], int size, int lane, int which, float (&prof)[GS == 8 ? 2 : 1], unsigned &fragile)
@@ -665,7 +440,6 @@ __device__ __forceinline__ void qrfac_step(double (&a)[6][E], double (&wa1)[6], 
 // order (enorm, qrfac's Householder products, Q^T fvec) — while the other lanes of the group do the same for the other
 // columns of the step.  The LDS reads of sixteen slots are issued together (a dependent add per read pays the LDS
 // latency per element otherwise: measured 100+ cycles per element).
-typedef double d2_t __attribute__((ext_vector_type(2)));
 template <int GS, int E>
 __device__ __forceinline__ void col_to_lds(const double (&v)[E], int lane, int row_lo, int m, double *col)
 {
@@ -689,43 +463,6 @@ __device__ __forceinline__ bool col_is_odd(const double (&v)[E], int lane, int r
         odd = odd || (r >= row_lo && r < m && !((xabs > RDWARF && xabs < agiant) || xabs == 0));
     }
     return odd;
-}
-template <int NB, bool SQUARE>
-__device__ __forceinline__ double chain_batch(const __attribute__((address_space(3))) d2_t *p, double acc)
-{
-    d2_t v[NB];
-#pragma unroll
-    for (int i = 0; i < NB; i++) v[i] = p[i];
-    if constexpr (NB == 8)
-        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]), "+v"(v[4]), "+v"(v[5]), "+v"(v[6]), "+v"(v[7]));
-    else
-        asm volatile("" : "+v"(v[0]), "+v"(v[1]), "+v"(v[2]), "+v"(v[3]));
-#pragma unroll
-    for (int i = 0; i < NB; i++) {
-        acc += SQUARE ? v[i].x * v[i].x : v[i].x;
-        acc += SQUARE ? v[i].y * v[i].y : v[i].y;
-    }
-    return acc;
-}
-// sum (SQUARE: of the squares) of the mp slots (mp even) of an LDS column, in slot order.  (Reading the next sixteen
-// slots while the current sixteen are added — 32 more registers in a kernel that sits at 256 — measured slower: 7x7 8.9 ->
-// 10.8 ms per 1e6 spots.)
-template <bool SQUARE>
-__device__ __forceinline__ double chain_sum(const double *col, int mp)
-{
-    const __attribute__((address_space(3))) d2_t *p = (const __attribute__((address_space(3))) d2_t *)col;
-    double acc = 0;
-    int b = 0;
-#pragma unroll 1
-    for (; b + 16 <= mp; b += 16) acc = chain_batch<8, SQUARE>(p + b / 2, acc);
-    if (b + 8 <= mp) { acc = chain_batch<4, SQUARE>(p + b / 2, acc); b += 8; }
-#pragma unroll 1
-    for (; b < mp; b += 2) {
-        const d2_t v = p[b / 2];
-        acc += SQUARE ? v.x * v.x : v.x;
-        acc += SQUARE ? v.y * v.y : v.y;
-    }
-    return acc;
 }
 // MINPACK enorm of an LDS column holding n = m - row_lo components (zeros elsewhere): the common branch as a chain of
 // squares; `odd` (this lane's column has a component outside (RDWARF, agiant)) takes the published scaled accumulators
@@ -825,16 +562,6 @@ __device__ __forceinline__ void qrfac_strict_step(double (&a)[7][E], double (&wa
 // 63 spilled registers) was most of the kernel.  Here (b) runs ONE SPOT PER LANE in its own kernel, the state of a
 // fit travels through a scratch record (LqState), and the spots that need another Jacobian are compacted into the
 // list of the next round.
-constexpr int LQ_NSD = 64, LQ_NSI = 10;         // doubles / ints of state per spot
-struct LqState {                                 // structure of arrays, stride = spots of the batch
-    double *d;                                   // [0..5] x  [6..11] diag  12 fnorm  13 delta  14 par  15 xnorm
-                                                 // [16..51] R (row-major 6x6, upper)  [52..57] qtf  [58..63] acnorm
-    int32_t *i;                                  // [0..5] ipvt  6 iter  7 nfev  8 info (-1 fresh, 0 running, > 0 done)
-                                                 // 9 tie: some decision of this fit was taken within rounding distance of its threshold
-    int64_t stride, first;                       // state index of spot s = s - first
-};
-#define LQD(st, f, ls) (st).d[(int64_t)(f) * (st).stride + (ls)]
-#define LQI(st, f, ls) (st).i[(int64_t)(f) * (st).stride + (ls)]
 
 // (a): residuals at x, Jacobian, QR.  list == nullptr: spots [first, min(first + count, n)).
 // Waves per SIMD the Jacobian kernel leaves room for: three where a lane holds at most four rows of a small box (boxes
@@ -1077,6 +804,7 @@ __device__ __forceinline__ int lq_step_spot(const Params &p, const LqState &st, 
     // kernel (slot 9).  The group kernel's tree sums differ from MINPACK's sequential ones in the last bits of float64,
     // so such a decision may be MINPACK's other branch: the spot is fitted again with sequential sums (tie_list).
     tie = (FLAG || FRAG) && flagging ? (unsigned)LQI(st, 9, ls) : 0u;       // bit 0: the pivot choice of the Jacobian kernel; 1: lmpar; 2..6 below
+    if (!FRAG) tie &= ~128u;                                  // bit 7 (a float32 rounding that hangs on an exp, set by every strict Jacobian) is the strict first pass's alone
     double gnorm = 0, fnorm1, actred, prered, dirder, ratio, pnorm;
     if (iter == 1) {
 #pragma unroll
@@ -1219,7 +947,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
     if (info != 0) {
         if ((FLAG || FRAG) && tie && tie_list) {
             tie_list[atomicAdd(tie_n, 1u)] = (int32_t)s;
-            for (int b = 0; b < 7; b++)
+            for (int b = 0; b < 8; b++)
                 if (tie & (1u << b)) atomicAdd(tie_n + 1 + b, 1u);      // why (diagnostics: pmi_gausslq_last_tie_reasons)
         }
     } else {
@@ -1314,7 +1042,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_finish_kerne
                     running = false;
                     if ((FLAG || FRAG) && tie && tie_list) {
                         tie_list[atomicAdd(tie_n, 1u)] = (int32_t)s_mine;
-                        for (int b = 0; b < 7; b++)
+                        for (int b = 0; b < 8; b++)
                             if (tie & (1u << b)) atomicAdd(tie_n + 1 + b, 1u);
                     }
                 }
@@ -1324,8 +1052,11 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_finish_kerne
     }
 }
 
+// strict mode, boxes up to 7x7: one image column per lane (gausslq_w.hip)
+void launch_jacobian_w(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count, dim3 grid, hipStream_t s);
+
 template <bool FROM_MOVIE, bool STRICT, bool CR = false>
-static void launch_jacobian(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count,
+static int launch_jacobian(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count,
                             int cus, hipStream_t s)
 {
     const int m = p.box * p.box;
@@ -1337,11 +1068,22 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
     // strict mode: m doubles of LDS per group (the rows of one column at a time, summed in MINPACK's order)
     auto lds_for = [&](int spots_per_wave) { return STRICT ? (size_t)LQ_WAVES * spots_per_wave * lq_sbuf_doubles(m) * sizeof(double) : (size_t)0; };
     static const bool g16 = tuning_env("PMI_LQ_GROUP16") != nullptr;      // A/B: the 16-lane groups for boxes up to 7
+    static const bool old7 = tuning_env("PMI_LQ_OLD7") != nullptr;         // A/B: the lane = row % 8 kernel for the strict rounds of boxes up to 7
+    if constexpr (STRICT && !CR && !FROM_MOVIE) {
+        if (p.box <= 7 && !old7) {
+            launch_jacobian_w(p, st, list, list_n, count, grid_for(8), s);
+            return PMI_OK;
+        }
+    }
     // (more than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel)
 #define LQ_JAC(GS, E, SPW) do { \
         if (lds_for(SPW) > 65536) { \
-            static bool asked = false; \
-            if (!asked) { (void)hipFuncSetAttribute((const void *)lq_jacobian_kernel<GS, E, FROM_MOVIE, STRICT, CR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); asked = true; } \
+            static bool asked[PMI_MAX_DEVICES] = {};     /* the opt-in is recorded per device and kernel */ \
+            const int dv = current_device(); \
+            if (!__atomic_load_n(&asked[dv], __ATOMIC_ACQUIRE)) { \
+                PMI_HIP(hipFuncSetAttribute((const void *)lq_jacobian_kernel<GS, E, FROM_MOVIE, STRICT, CR>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); \
+                __atomic_store_n(&asked[dv], true, __ATOMIC_RELEASE); \
+            } \
         } \
         hipLaunchKernelGGL((lq_jacobian_kernel<GS, E, FROM_MOVIE, STRICT, CR>), grid_for(SPW), block, lds_for(SPW), s, p, st, list, list_n, count); \
     } while (0)
@@ -1366,6 +1108,7 @@ static void launch_jacobian(const Params &p, const LqState &st, const int32_t *l
         else LQ_JAC(64, 7, 1);
     }
 #undef LQ_JAC
+    return PMI_OK;
 }
 
 // Rounds of (Jacobian + QR, step) over the spots still running that are queued before the finishing kernel takes over (boxes
@@ -1393,14 +1136,15 @@ static int lq_mode_now()
 // statistics of the calling thread's last fit: a device buffer of its own ([0] spots fitted again, [1..7] why), read when asked for
 static thread_local const unsigned *g_lq_stats[2] = {nullptr, nullptr};          // [1]: the second frame range of a fused call
 static thread_local unsigned g_lq_stats_generation = 0;
-static thread_local hipStream_t g_lq_stats_stream[2] = {nullptr, nullptr};
+static thread_local hipEvent_t g_lq_stats_done[PMI_MAX_DEVICES][2] = {};       // recorded after the statistics kernel of the fit: the caller's stream may be gone when they are read
+static thread_local int g_lq_stats_device = 0;
 static thread_local bool g_lq_stats_second = false;                               // the fit being queued is that second range
 static thread_local int g_lq_rounds[2] = {0, 0};
 
 __global__ void lq_stats_add_kernel(const unsigned *__restrict__ tie_n, unsigned *__restrict__ stats, int refitted)
 {
     if (threadIdx.x == 0 && refitted) stats[0] += tie_n[0];
-    if (threadIdx.x >= 1 && threadIdx.x < 8) stats[threadIdx.x] += tie_n[threadIdx.x];
+    if (threadIdx.x >= 1 && threadIdx.x < 9) stats[threadIdx.x] += tie_n[threadIdx.x];
 }
 
 template <bool CR, bool FLAG, bool FRAG>
@@ -1421,9 +1165,7 @@ template <bool FROM_MOVIE_IN>
 static int launch(Params p, hipStream_t s)
 {
     constexpr bool FROM_MOVIE = false;             // the rounds always read (N, box, box) float32 spots (lq_cut_kernel)
-    int dev = 0, cus = 256;
-    (void)hipGetDevice(&dev);
-    (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    const int cus = device_cu_count();
     const int64_t BATCH = (int64_t)1 << LQ_BATCH_LOG2;
     const int64_t Ntotal = p.N;                    // a capacity when the row count lives on the device: batches past the rows exit at once
     const int64_t cap = std::min<int64_t>(Ntotal, BATCH);
@@ -1472,7 +1214,7 @@ static int launch(Params p, hipStream_t s)
             hipLaunchKernelGGL(lq_cut_kernel, dim3(cb), dim3(256), 0, s, p, first, count, cut);
             p.spots = cut - first * mpix;          // indexed by the absolute spot number
         }
-        PMI_HIP(hipMemsetAsync(counters, 0, (NCTR + 8) * sizeof(unsigned), s));
+        PMI_HIP(hipMemsetAsync(counters, 0, (NCTR + 16) * sizeof(unsigned), s));
         hipLaunchKernelGGL((lq_init_kernel<FROM_MOVIE>), dim3((unsigned)((count + 255) / 256)), dim3(256), init_lds, s, p, st, count,
                            (const int32_t *)nullptr, (const unsigned *)nullptr);
         // ---- pass 0: every spot of the batch (refit / fast: tree sums, decisions near a threshold collected in tie_list;
@@ -1482,8 +1224,8 @@ static int launch(Params p, hipStream_t s)
         for (int round = 0; round < rounds; round++) {
             int32_t *nxt = lists[round & 1];
             unsigned *nxt_n = counters + round;
-            if (all_strict) launch_jacobian<FROM_MOVIE, true>(p, st, cur, cur_n, count, cus, s);
-            else launch_jacobian<FROM_MOVIE, false>(p, st, cur, cur_n, count, cus, s);
+            if ((rc = all_strict ? launch_jacobian<FROM_MOVIE, true>(p, st, cur, cur_n, count, cus, s)
+                                 : launch_jacobian<FROM_MOVIE, false>(p, st, cur, cur_n, count, cus, s)) != PMI_OK) return rc;
             const unsigned sb = (unsigned)((count + LQ_STEP_NT - 1) / LQ_STEP_NT);
             if (all_strict)
                 hipLaunchKernelGGL((lq_step_kernel<FROM_MOVIE, false, true, false>), dim3(sb), dim3(LQ_STEP_NT), step_lds, s, p, st, cur, cur_n, count,
@@ -1506,10 +1248,13 @@ static int launch(Params p, hipStream_t s)
         }
         PMI_HIP(hipGetLastError());
     }
+    g_lq_stats_device = current_device();
+    hipEvent_t &done = g_lq_stats_done[g_lq_stats_device][g_lq_stats_second ? 1 : 0];
+    if (!done) PMI_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    PMI_HIP(hipEventRecord(done, s));
     g_lq_stats[g_lq_stats_second ? 1 : 0] = stats;
-    g_lq_stats_stream[g_lq_stats_second ? 1 : 0] = s;
     if (!g_lq_stats_second) g_lq_stats[1] = nullptr;
-    g_lq_stats_generation = scratch_generation(SCR_LQ_STATS);
+    g_lq_stats_generation = scratch_generation_of(g_lq_stats_device, SCR_LQ_STATS);
     g_lq_rounds[0] = rounds; g_lq_rounds[1] = no_strict ? 0 : 1;
     return PMI_OK;
 }
@@ -1517,11 +1262,11 @@ static int launch(Params p, hipStream_t s)
 static int read_lq_stats(unsigned (&h)[16])
 {
     for (unsigned &v : h) v = 0;
-    if (!g_lq_stats[0] || g_lq_stats_generation != scratch_generation(SCR_LQ_STATS)) return PMI_OK;      // no fit yet, or its buffers are gone
+    if (!g_lq_stats[0] || g_lq_stats_generation != scratch_generation_of(g_lq_stats_device, SCR_LQ_STATS)) return PMI_OK;      // no fit yet, or its buffers are gone
     for (int k = 0; k < 2; k++) {
         if (!g_lq_stats[k]) continue;
         unsigned part[16];
-        PMI_HIP(hipStreamSynchronize(g_lq_stats_stream[k]));
+        PMI_HIP(hipEventSynchronize(g_lq_stats_done[g_lq_stats_device][k]));
         PMI_HIP(hipMemcpy(part, g_lq_stats[k], 64, hipMemcpyDeviceToHost));
         for (int i = 0; i < 16; i++) h[i] += part[i];
     }
@@ -1620,7 +1365,7 @@ int pmi_gausslq_last_tie_reasons(int64_t *counts, int n)
     unsigned h[16];
     const int rc = pmi::lq::read_lq_stats(h);
     if (rc != PMI_OK) return rc;
-    for (int i = 0; counts && i < n; i++) counts[i] = i < 7 ? h[1 + i] : (i < 9 ? pmi::lq::g_lq_rounds[i - 7] : 0);
+    for (int i = 0; counts && i < n; i++) counts[i] = i < 8 ? h[1 + i] : (i < 10 ? pmi::lq::g_lq_rounds[i - 8] : 0);
     return PMI_OK;
 }
 
@@ -1701,7 +1446,7 @@ int pmi_locs_from_fits_lq_dev(const int32_t *d_frame, const int32_t *d_y, const 
 namespace pmi {
 namespace lq {
 struct SideLane { hipStream_t s2 = nullptr; hipEvent_t ev_start = nullptr, ev_scan_a = nullptr, ev_b = nullptr; };
-static thread_local SideLane g_lq_side;
+static thread_local SideLane g_lq_side_of[PMI_MAX_DEVICES];      // per device the thread has used (streams and events belong to a device)
 // rows: [0] rows of A to fit, [1] rows of B to fit, [2] rows of A for the table, [3] rows of B for the table, [4] row offset of B
 __global__ void lq_rows_a_kernel(const int64_t *__restrict__ n_a, int64_t cap, int64_t *__restrict__ rows) { rows[0] = *n_a > cap ? 0 : *n_a; }
 __global__ void lq_rows_b_kernel(const int64_t *__restrict__ n_a, const int64_t *__restrict__ n_b, int64_t cap, int64_t *__restrict__ rows,
@@ -1762,7 +1507,7 @@ int pmi_localize_lq_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, in
         PMI_HIP(hipGetLastError());
         return PMI_OK;
     }
-    lq::SideLane &side = lq::g_lq_side;
+    lq::SideLane &side = lq::g_lq_side_of[current_device()];
     if (!side.s2) {
         PMI_HIP(hipStreamCreateWithFlags(&side.s2, hipStreamNonBlocking));
         PMI_HIP(hipEventCreateWithFlags(&side.ev_start, hipEventDisableTiming));

@@ -509,7 +509,6 @@ static void launch_fit_ppl(int ppl, dim3 grid, hipStream_t s, const FitParams &p
     }
 }
 
-static int g_cu_count = 0;
 
 bool launch_fit_g8(const FitParams &p, int method, bool from_movie, int cu_count, float *state, int stages, hipStream_t s);   // gaussmle_g8.hip
 void launch_fit_strict(const FitParams &p, int method, bool from_movie, const int32_t *list, const unsigned *list_n,
@@ -615,6 +614,7 @@ static double g_mle_margin = 0.001;
 // [0] = spots re-fitted, [1..FLAG_REASONS] = spots flagged per criterion), valid while the scratch generation stands
 static thread_local const unsigned *g_last_stats[2] = {nullptr, nullptr};      // [1]: the second frame range of a fused call
 static thread_local unsigned g_last_stats_generation = 0;
+static thread_local int g_last_stats_device = 0;                                  // the device those buffers live on
 static thread_local bool g_stats_second = false;                                  // the fit being queued is that second range
 
 __global__ void zero_words_kernel(unsigned *__restrict__ a, int na, unsigned *__restrict__ b, int nb)
@@ -648,11 +648,7 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     if (p.N < 0) { set_error("negative N"); return PMI_ERR_ARG; }
     if (p.N == 0) return PMI_OK;
     if (p.N > 0x7fffffffLL) { set_error("too many spots for one call"); return PMI_ERR_ARG; }
-    if (!g_cu_count) {
-        int dev = 0;
-        PMI_HIP(hipGetDevice(&dev));
-        PMI_HIP(hipDeviceGetAttribute(&g_cu_count, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    const int g_cu_count = device_cu_count();
     const int mode = mle_mode_now();
     // Spots are processed in batches so that the Fisher scratch (168 B per spot) stays bounded;
     // every batch has its own queue words and flag counter.  With a device-side row count (d_n) the
@@ -809,7 +805,8 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     PMI_HIP(hipGetLastError());
     g_last_stats[g_stats_second ? 1 : 0] = stats;
     if (!g_stats_second) g_last_stats[1] = nullptr;
-    g_last_stats_generation = scratch_generation(SCR_STATS);
+    g_last_stats_device = current_device();
+    g_last_stats_generation = scratch_generation_of(g_last_stats_device, SCR_STATS);
     tm.stop();
     return PMI_OK;
 }
@@ -817,7 +814,7 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
 static int read_last_stats(unsigned (&h)[16], hipStream_t s)
 {
     for (unsigned &v : h) v = 0;
-    if (!g_last_stats[0] || g_last_stats_generation != scratch_generation(SCR_STATS)) return PMI_OK;      // no fit yet, or its buffers are gone
+    if (!g_last_stats[0] || g_last_stats_generation != scratch_generation_of(g_last_stats_device, SCR_STATS)) return PMI_OK;      // no fit yet, or its buffers are gone
     PMI_HIP(hipStreamSynchronize(s));
     for (const unsigned *src : g_last_stats) {
         if (!src) continue;
@@ -1086,7 +1083,7 @@ namespace pmi {
 static bool g_localize_handoff = false;
 static bool g_localize_defer = true;
 struct SideLane { hipStream_t s2 = nullptr; hipEvent_t ev_start = nullptr, ev_scan_a = nullptr, ev_b = nullptr; };
-static thread_local SideLane g_side;
+static thread_local SideLane g_side_of[PMI_MAX_DEVICES];       // streams and events belong to a device: one lane per device the thread has used
 
 // rows: [0] rows of A to fit, [1] rows of B to fit, [2] rows of A for the table, [3] rows of B for the table, [4] row offset of B
 __global__ void range_rows_a_kernel(const int64_t *__restrict__ n_a, int64_t cap, int64_t *__restrict__ rows)
@@ -1255,7 +1252,7 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
         PMI_HIP(hipGetLastError());
         return PMI_OK;
     }
-    SideLane &side = g_side;
+    SideLane &side = g_side_of[current_device()];
     if (!side.s2) {
         PMI_HIP(hipStreamCreateWithFlags(&side.s2, hipStreamNonBlocking));
         PMI_HIP(hipEventCreateWithFlags(&side.ev_start, hipEventDisableTiming));

@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cmath>
 #include <type_traits>
+#include <mutex>
 #include <vector>
 
 #include "pmi_common.h"
@@ -309,11 +310,14 @@ __global__ __launch_bounds__(SORT_THREADS) void sort_in_frame_kernel(const Recor
 
 // float32 unit-vector tables, built on the host with IEEE float ops exactly as
 // localize.py:279-286 does, cached on the device per box size.
-static float *g_unit_tables[PMI_MAX_BOX + 1] = {nullptr};
+static float *g_unit_tables[PMI_MAX_DEVICES][PMI_MAX_BOX + 1] = {};      // a table lives on the device it was made on
+static std::mutex g_unit_tables_mu;
 
 static int unit_table(int box, const float **d_tab)
 {
-    if (!g_unit_tables[box]) {
+    const int dev = current_device();
+    std::lock_guard<std::mutex> lk(g_unit_tables_mu);
+    if (!g_unit_tables[dev][box]) {
         std::vector<float> tab(2 * box * box);
         int h = box / 2;
         for (int k = 0; k < box; k++)
@@ -327,9 +331,9 @@ static int unit_table(int box, const float **d_tab)
         float *d = nullptr;
         PMI_HIP(hipMalloc(&d, tab.size() * sizeof(float)));
         PMI_HIP(hipMemcpy(d, tab.data(), tab.size() * sizeof(float), hipMemcpyHostToDevice));
-        g_unit_tables[box] = d;
+        g_unit_tables[dev][box] = d;
     }
-    *d_tab = g_unit_tables[box];
+    *d_tab = g_unit_tables[dev][box];
     return PMI_OK;
 }
 
@@ -345,8 +349,6 @@ static int launch_scan(const void *d_movie, const IdParams &p, const float *d_ta
                        unsigned long long *n_total, int *frame_count, hipStream_t s)
 {
     size_t lds = scan_lds_bytes(p.box);
-    static bool attr_set[8] = {false};
-    (void)attr_set;
     PMI_HIP(hipFuncSetAttribute((const void *)identify_scan_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     long long blocks = (long long)p.nframes * p.tiles_y * p.tiles_x;
     if (blocks > 0x7fffffffLL) { set_error("identify: too many tiles (%lld)", blocks); return PMI_ERR_ARG; }

@@ -1138,7 +1138,6 @@ static bool unit_vectors_match()
     return ok;
 }
 
-static int g_fast_cus = 0;
 
 // Returns PMI_OK and sets *handled when the fast path applies.
 int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, int y0, int x0, int cy, int cx, int64_t f_lo,
@@ -1159,11 +1158,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     const int pxb = pt == PT_U8 ? 1 : 2;
     if (cx < 16 || ((uintptr_t)d_movie & (uintptr_t)(pxb - 1))) return PMI_OK;
     if (cy > 65535 || cx > 65520 || X > 65535 || Y * X * pxb >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets, 16-bit list columns
-    if (!g_fast_cus) {
-        int dev = 0;
-        PMI_HIP(hipGetDevice(&dev));
-        PMI_HIP(hipDeviceGetAttribute(&g_fast_cus, hipDeviceAttributeMultiprocessorCount, dev));
-    }
+    const int g_fast_cus = device_cu_count();
     // narrow frames: several row ranges side by side in one wavefront instead of idle lanes
     const int nch = ((x0 & 7) + cx + 7) / 8;
     static const bool no_pack = tuning_env("PMI_IDENTIFY_NOPACK") != nullptr;

@@ -30,7 +30,15 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
         if (e_ != hipSuccess) return pmi::hip_fail(e_, #call, __FILE__, __LINE__); \
     } while (0)
 
-// Grow-only scratch arena per process (one GPU per process).  slot = purpose id.
+// Library state that lives in device memory or belongs to a device — scratch banks, unit-vector tables, the opt-in to more
+// than 64 KB of dynamic LDS per kernel, FFT plans, side streams — is keyed by the device current in the calling thread
+// (hipGetDevice), so that ONE process can drive several GPUs from one host thread each (localize_streamed(devices=...),
+// INTEGRATION.md).  Settings (the modes, the number of frame ranges) stay process-wide.
+constexpr int PMI_MAX_DEVICES = 16;
+int current_device();                 // the calling thread's device, 0 if it cannot be asked; pmi_set_device refuses >= PMI_MAX_DEVICES
+int device_cu_count();                // compute units of that device (cached per device)
+
+// Grow-only scratch arena per device.  slot = purpose id.
 enum ScratchSlot {
     SCR_RECORDS = 0,      // unordered identification records
     SCR_RECORDS2,         // frame-grouped records
@@ -54,7 +62,8 @@ int scratch(int slot, size_t bytes, void **ptr);
 int scratch_release_all();
 int scratch_enter_inner();           // -> the bank to hand back to scratch_leave_inner
 void scratch_leave_inner(int was);
-unsigned scratch_generation(int slot);      // bumped whenever a buffer of that slot (any bank) is released: pointers into it taken before are stale
+unsigned scratch_generation(int slot);      // of the current device; bumped whenever a buffer of that slot (any bank) is released: pointers into it taken before are stale
+unsigned scratch_generation_of(int device, int slot);
 // Fused pipelines: *d_rows = *d_total if it fits the caller's capacity, else 0 (the identification columns were not
 // written; the caller sees *d_total > cap and resubmits), so that the fit stages never follow stale rows.
 int rows_to_fit(const int64_t *d_total, int64_t cap, const int64_t **d_rows, hipStream_t s);

@@ -34,20 +34,40 @@ struct ScratchBuf { void *p = nullptr; size_t bytes = 0; };
 // scanned) gives each its own scratch (pmi_scratch_bank); everything else lives in bank 0.
 constexpr int SCR_USER_BANKS = 2;                 // what pmi_scratch_bank selects
 constexpr int SCR_BANKS = 2 * SCR_USER_BANKS;      // + one inner bank each: the second frame range a fused call keeps in flight
-static ScratchBuf g_scratch_banks[SCR_BANKS][SCR_NUM];
+static ScratchBuf g_scratch_banks[PMI_MAX_DEVICES][SCR_BANKS][SCR_NUM];      // [device]: a buffer belongs to the device it was allocated on
 // the bank is a property of the calling thread: two host threads that drive two streams select a bank each
 // (pmi_scratch_bank) and never see each other's records or fit state
 static thread_local int g_scratch_bank = 0;
 static std::mutex g_scratch_mu;
-static unsigned g_scratch_generation[SCR_NUM] = {};       // per slot: a record in one slot outlives the growth of another
-unsigned scratch_generation(int slot) { std::lock_guard<std::mutex> lk(g_scratch_mu); return g_scratch_generation[slot]; }
+static unsigned g_scratch_generation[PMI_MAX_DEVICES][SCR_NUM] = {};       // per device and slot: a record in one slot outlives the growth of another
+unsigned scratch_generation_of(int device, int slot) { std::lock_guard<std::mutex> lk(g_scratch_mu); return g_scratch_generation[device][slot]; }
+unsigned scratch_generation(int slot) { return scratch_generation_of(current_device(), slot); }
+
+int current_device()
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PMI_MAX_DEVICES) return 0;
+    return dev;
+}
+int device_cu_count()
+{
+    static int cus[PMI_MAX_DEVICES] = {};
+    const int dev = current_device();
+    int n = __atomic_load_n(&cus[dev], __ATOMIC_RELAXED);
+    if (!n) {
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        __atomic_store_n(&cus[dev], n, __ATOMIC_RELAXED);
+    }
+    return n;
+}
 
 int scratch(int slot, size_t bytes, void **ptr)
 {
+    const int dev = current_device();
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    ScratchBuf &b = g_scratch_banks[g_scratch_bank][slot];
+    ScratchBuf &b = g_scratch_banks[dev][g_scratch_bank][slot];
     if (b.bytes < bytes) {
-        if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; g_scratch_generation[slot]++; }
+        if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; g_scratch_generation[dev][slot]++; }
         size_t want = bytes + bytes / 4 + 4096;   // headroom so repeated calls stop reallocating
         PMI_HIP(hipMalloc(&b.p, want));
         b.bytes = want;
@@ -58,12 +78,23 @@ int scratch(int slot, size_t bytes, void **ptr)
 
 int scratch_release_all()
 {
+    // every device's buffers: each is synchronised and freed with its own device current, the caller's device is restored
+    const int was = current_device();
     std::lock_guard<std::mutex> lk(g_scratch_mu);
-    for (unsigned &g : g_scratch_generation) g++;
-    for (auto &bank : g_scratch_banks)
-        for (auto &b : bank)
-            if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; }
-    return PMI_OK;
+    int rc = PMI_OK;
+    for (int dev = 0; dev < PMI_MAX_DEVICES; dev++) {
+        bool any = false;
+        for (auto &bank : g_scratch_banks[dev])
+            for (auto &b : bank) any = any || b.p;
+        for (unsigned &g : g_scratch_generation[dev]) g++;
+        if (!any) continue;
+        if (hipSetDevice(dev) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rc = PMI_ERR_HIP; set_error("pmi_release_scratch: device %d cannot be synchronised", dev); continue; }
+        for (auto &bank : g_scratch_banks[dev])
+            for (auto &b : bank)
+                if (b.p) { if (hipFree(b.p) != hipSuccess) rc = PMI_ERR_HIP; b.p = nullptr; b.bytes = 0; }
+    }
+    (void)hipSetDevice(was);
+    return rc;
 }
 int scratch_select_bank(int bank)
 {
@@ -111,6 +142,11 @@ int pmi_device_count(void)
 
 int pmi_set_device(int device)
 {
+    // the calling THREAD's device (HIP keeps it per thread); everything the library keeps on a device is keyed by it
+    if (device < 0 || device >= pmi::PMI_MAX_DEVICES || device >= pmi_device_count()) {
+        pmi::set_error("pmi_set_device: no device %d (%d visible, at most %d supported)", device, pmi_device_count(), pmi::PMI_MAX_DEVICES);
+        return PMI_ERR_ARG;
+    }
     PMI_HIP(hipSetDevice(device));
     return PMI_OK;
 }

@@ -20,7 +20,7 @@ from typing import Callable, Literal
 import numpy as np
 import pandas as pd
 
-from . import __version__, avgroi, backend, gausslq, gaussmle, lib
+from . import __version__, _lib, avgroi, backend, gausslq, gaussmle, lib
 
 _CHUNK_BYTES = 1 << 30      # movie bytes per device call = progress / abort granularity
 FITTING_METHODS = ["gausslq", "gausslq-gpu", "gaussmle", "avg"]
@@ -535,15 +535,126 @@ def localize_resident(movie: np.ndarray, camera_info: dict, parameters: dict, *,
     return pd.DataFrame(cols)
 
 
+class _DeviceLane:
+    """One lane of a streamed run: a device (and one of its two scratch banks), two staging allocations for the frame
+    chunks, a non-blocking stream and the table buffers.  `bind` runs first in every host thread that works for the lane
+    (its uploader and its worker): the library keys what it keeps on a device by the calling thread's device."""
+
+    def __init__(self, device, bank, call):
+        self.device, self.bank, self._call = device, bank, call
+        self.stages = [None, None]
+        self.stream = None
+        self.work = None
+
+    def bind(self):
+        if self.device is not None:
+            _lib.bind_thread(self.device, self.bank)
+
+    def open(self):
+        self.stream = backend.DeviceStream()
+        self.work = backend.DeviceWorkspace()
+
+    def upload(self, k: int, chunk: np.ndarray):
+        if self.stages[k] is None:
+            self.stages[k] = backend.DeviceMovie(chunk)
+        else:
+            self.stages[k].load(chunk)
+
+    def run(self, k: int, c0: int) -> pd.DataFrame:
+        cols = self._call(self.stages[k], self.stream.handle, self.work)
+        cols["frame"] = cols["frame"] + np.asarray(c0, cols["frame"].dtype)
+        return pd.DataFrame(cols)
+
+    def close(self):
+        for st in self.stages:
+            if st is not None:
+                st.free()
+        if self.work is not None:
+            self.work.free()
+        if self.stream is not None:
+            self.stream.destroy()
+
+
+def _run_lanes(movie, chunks, lanes, progress_callback=None, abort_callback=None, frames=None):
+    """The scheduler of `localize_streamed`: chunk i = frames [c0, c1) goes to lane i % len(lanes).  Every lane has one
+    host thread (the calling thread when there is one lane) that uploads the lane's next chunk — a blocking copy, the GIL
+    released — while a worker thread of the lane runs identify -> cut + fit -> table on the previous one in the lane's other
+    staging allocation.  Tables come back in frame order whatever order the lanes finish in (what the reference's worker
+    threads give, picasso/localize.py:424-454 + the sort at :478).  `progress_callback(n)`: frames handed to a device so
+    far, from whichever lane thread got there; `abort_callback()` is asked before every chunk: the run then stops, the
+    chunks in flight finish, and None is returned (identify's contract, picasso/localize.py:462-470).
+    A lane needs: bind(), open(), upload(k, chunk), run(k, c0) -> DataFrame, close()."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    frames = frames or _frames
+    results = [None] * len(chunks)
+    done_frames = [0]
+    mu = threading.Lock()
+    stop = threading.Event()
+    errors = []
+
+    def lane_loop(li, lane):
+        mine = [(i, c) for i, c in enumerate(chunks) if i % len(lanes) == li]
+        opened = False
+        try:
+            lane.bind()
+            lane.open()
+            opened = True
+            futures = []
+            with ThreadPoolExecutor(max_workers=1, initializer=lane.bind) as pool:
+                for n, (i, (c0, c1)) in enumerate(mine):
+                    if stop.is_set():
+                        break
+                    if callable(abort_callback) and abort_callback():
+                        stop.set()
+                        break
+                    if n >= 2:
+                        futures[n - 2][1].result()      # that chunk is done with the staging allocation this one takes
+                    lane.upload(n & 1, frames(movie, c0, c1))
+                    futures.append((i, pool.submit(lane.run, n & 1, c0)))
+                    if callable(progress_callback):
+                        with mu:
+                            done_frames[0] += c1 - c0
+                            progress_callback(done_frames[0])
+                for i, f in futures:
+                    results[i] = f.result()
+        except BaseException as exc:      # noqa: BLE001 - handed to the calling thread
+            errors.append(exc)
+            stop.set()
+        finally:
+            if opened:
+                lane.close()
+
+    if len(lanes) == 1:
+        lane_loop(0, lanes[0])
+    else:
+        threads = [threading.Thread(target=lane_loop, args=(li, lane), name=f"pmi-lane-{li}") for li, lane in enumerate(lanes)]
+        for t in threads:
+            t.start()
+        for t in threads:
+            t.join()
+    if errors:
+        raise errors[0]
+    if stop.is_set():
+        return None
+    return [r for r in results if r is not None]
+
+
 def localize_streamed(movie, camera_info: dict, parameters: dict, *, roi=None, frame_bounds=None,
                       fitting_method: str = "gaussmle", eps: float = 0.001, max_it: int = 100,
                       mle_method: str = "sigmaxy", chunk_bytes: int = 1 << 28,
-                      progress_callback=None) -> pd.DataFrame:
+                      progress_callback=None, abort_callback=None, devices=None) -> pd.DataFrame:
     """The fused device pipeline over a host movie of any length (ndarray, memmap or a picasso movie
     object): frames go up in chunks of about ``chunk_bytes`` through two staging allocations (the upload of
     one chunk overlaps the device work and the row copy of the previous one, which run on a stream of their
     own), each chunk runs identify -> cut+fit -> table on the device, only the table rows come back.  The movie crosses PCIe once
-    and neither host RAM nor HBM has to hold it whole.  Same rows as ``localize_resident``."""
+    and neither host RAM nor HBM has to hold it whole.  Same rows as ``localize_resident``.
+
+    ``devices``: the GPUs of this process to use, e.g. ``[0, 1, 2, 3]`` or ``"all"`` — one host thread (+ its worker) per
+    entry, the chunks dealt round robin, the tables concatenated in frame order; a device named twice gets two lanes on its
+    two scratch banks.  This is how ONE process — the unmodified CLI / GUI after ``install()`` — reaches several GPUs and
+    their PCIe links, as the reference reaches several cores with threads (picasso/localize.py:424-454).  ``None``: the
+    calling thread's current device, as before.  ``abort_callback``: see ``_run_lanes``; returns None when it fired."""
     if fitting_method not in ("gaussmle", "gausslq"):
         raise ValueError("localize_streamed supports fitting_method 'gaussmle' or 'gausslq'")
     box, min_ng = parameters["Box Size"], parameters["Min. Net Gradient"]
@@ -553,53 +664,76 @@ def localize_streamed(movie, camera_info: dict, parameters: dict, *, roi=None, f
     columns = backend.LQ_COLUMNS if fitting_method == "gausslq" else backend.LOC_COLUMNS
     parts = []
     if hi >= lo:
-        from concurrent.futures import ThreadPoolExecutor
         first = np.asarray(movie[lo])
         per = max(1, int(chunk_bytes) // max(first.nbytes, 1))
-        # Two staging allocations.  This thread uploads chunk i + 1 (a blocking default-stream copy; ctypes
-        # releases the GIL) while a worker thread runs chunk i on a non-blocking stream of its own — kernels,
-        # row copies, DataFrame — with table buffers that live for the whole run (no hipFree in between, which
-        # would wait for the upload).
-        stages = [None, None]
-        stream = backend.DeviceStream()
-        work = backend.DeviceWorkspace()
+        chunks = [(c0, min(hi + 1, c0 + per)) for c0 in range(lo, hi + 1, per)]
 
-        def on_device(stage, c0):
+        def call(stage, stream, work):
             if fitting_method == "gausslq":
-                cols = backend.localize_lq_device(stage.ptr, stage.dtype, stage.shape, box, min_ng, camera_info, roi=roi,
-                                                  stream=stream.handle, work=work)
-            else:
-                cols = backend.localize_mle_device(stage.ptr, stage.dtype, stage.shape, box, min_ng, camera_info,
-                                                   eps, max_it, mle_method, roi=roi, stream=stream.handle, work=work)
-            cols["frame"] = cols["frame"] + np.asarray(c0, cols["frame"].dtype)
-            return pd.DataFrame(cols)
+                return backend.localize_lq_device(stage.ptr, stage.dtype, stage.shape, box, min_ng, camera_info, roi=roi,
+                                                  stream=stream, work=work)
+            return backend.localize_mle_device(stage.ptr, stage.dtype, stage.shape, box, min_ng, camera_info,
+                                               eps, max_it, mle_method, roi=roi, stream=stream, work=work)
 
-        futures = []
-        try:
-            with ThreadPoolExecutor(max_workers=1) as pool:
-                for i, c0 in enumerate(range(lo, hi + 1, per)):
-                    c1 = min(hi + 1, c0 + per)
-                    k = i & 1
-                    if i >= 2:
-                        futures[i - 2].result()          # that chunk is done with staging allocation k
-                    chunk = _frames(movie, c0, c1)
-                    if stages[k] is None:
-                        stages[k] = backend.DeviceMovie(chunk)
-                    else:
-                        stages[k].load(chunk)
-                    futures.append(pool.submit(on_device, stages[k], c0))
-                    if callable(progress_callback):
-                        progress_callback(c1 - lo)
-                parts = [f.result() for f in futures]
-        finally:
-            for st in stages:
-                if st is not None:
-                    st.free()
-            work.free()
-            stream.destroy()
+        lanes = [_DeviceLane(dev, bank, call) for dev, bank in _lanes_for(_resolve_devices(devices), len(chunks))]
+        parts = _run_lanes(movie, chunks, lanes, progress_callback, abort_callback)
+        if parts is None:
+            return None
     if not parts:
         return pd.DataFrame({name: np.empty(0, dt) for name, dt in columns})
     return parts[0] if len(parts) == 1 else pd.concat(parts, ignore_index=True)
+
+
+_default_devices = None       # set_devices(): what localize_streamed(devices=None) uses
+
+
+def set_devices(devices) -> None:
+    """The GPUs `localize_streamed` — and through it `localize()` and `localize_file()` — uses when no `devices` argument
+    is given: None (the calling thread's current device), "all", or a list of device indices.  The environment variable
+    PICASSO_AMD_DEVICES ("all" or "0,1,2,3") sets the same default for a process nobody can pass arguments to (the
+    reference's CLI after `install()`)."""
+    global _default_devices
+    if devices is not None and not isinstance(devices, str):
+        devices = [int(d) for d in devices]
+    _default_devices = devices
+
+
+def _resolve_devices(devices):
+    if devices is not None:
+        return devices
+    if _default_devices is not None:
+        return _default_devices
+    import os
+    env = os.environ.get("PICASSO_AMD_DEVICES", "").strip()
+    if not env:
+        return None
+    return "all" if env == "all" else [int(t) for t in env.split(",") if t.strip()]
+
+
+def _lanes_for(devices, n_chunks: int):
+    """(device, scratch bank) of every lane.  None -> one lane on the calling thread's device (no binding: (None, 0));
+    "all" -> every visible device; a list -> as given, a device named twice on banks 0 and 1 (a third time is an error:
+    the library has two banks per device)."""
+    if devices is None:
+        return [(None, 0)]
+    if isinstance(devices, str):
+        if devices != "all":
+            raise ValueError("devices must be None, 'all' or a list of device indices")
+        devices = list(range(_lib.device_count()))
+    devices = [int(d) for d in devices]
+    if not devices:
+        raise ValueError("devices is empty")
+    count = _lib.device_count()
+    lanes, seen = [], {}
+    for d in devices:
+        if d < 0 or d >= count:
+            raise ValueError(f"no device {d}: {count} visible")
+        bank = seen.get(d, 0)
+        if bank >= 2:
+            raise ValueError(f"device {d} named more than twice: the library keeps two scratch banks per device")
+        seen[d] = bank + 1
+        lanes.append((d, bank))
+    return lanes[:max(1, n_chunks)]
 
 
 def _frames(movie, c0: int, c1: int) -> np.ndarray:
@@ -657,11 +791,17 @@ def _reference_module(given, name: str):
 
 
 def install(picasso_localize=None, picasso_gaussmle=None, picasso_gausslq=None, picasso_zfit=None,
-            picasso_render=None, picasso_imageprocess=None, picasso_postprocess=None) -> None:
+            picasso_render=None, picasso_imageprocess=None, picasso_postprocess=None, *, fused: bool = False,
+            devices=None) -> None:
     """Rebind the reference package's hot-path functions to this backend, so that
     picasso.__main__ and the GUI run on the GPU unchanged.  Modules not given are taken
     from the installed ``picasso`` package; the rows next to the path (z fit, render, RCC undrift) are rebound
-    when their module is available.  Rotated renders keep going to the reference's own functions."""
+    when their module is available.  Rotated renders keep going to the reference's own functions.
+
+    ``fused=True`` also rebinds ``picasso.localize.localize`` (what `picasso localize` calls, picasso/__main__.py:1086)
+    to this package's: same arguments, table and metadata, but the movie crosses PCIe once (`localize_streamed`) instead
+    of once for `identify` and once for `get_spots`.  ``devices`` (see `set_devices`) then spreads the frame chunks over
+    several GPUs of the process."""
     if picasso_localize is None:
         import picasso.localize as picasso_localize       # the installed reference
     if picasso_gaussmle is None:
@@ -672,6 +812,10 @@ def install(picasso_localize=None, picasso_gaussmle=None, picasso_gausslq=None, 
         setattr(picasso_localize, name, getattr(me, name))
     picasso_localize._fit2d_gaussmle = _fit2d_gaussmle
     picasso_localize._fit2d_gausslq = _fit2d_gausslq
+    if fused:
+        picasso_localize.localize = localize
+    if devices is not None:
+        set_devices(devices)
     for name in ("gaussmle", "gaussmle_async"):
         setattr(picasso_gaussmle, name, getattr(gaussmle, name))
     if picasso_gausslq is None:

@@ -286,6 +286,124 @@ def test_localize_streamed_chunking_logic(monkeypatch, testdata_movie):
         localize.localize_streamed(mov, cam, params, fitting_method="avg")
 
 
+def test_streamed_scheduler_deals_chunks_over_lanes_in_frame_order():
+    """`localize._run_lanes`, the scheduler behind `localize_streamed(devices=[...])`, with fake lanes (no GPU): chunks are
+    dealt round robin, every lane works in its own host thread with a bound worker, a lane reuses two staging slots and
+    never loads a slot its worker still reads, the tables come back in frame order whatever order the lanes finish in, the
+    progress callback counts frames monotonically, an abort stops new chunks and returns None, and an error of one lane
+    reaches the caller after the other lanes have closed.  Reference for the contract: the worker threads of
+    picasso/localize.py:424-454 + the sort at :478, the abort at :462-470."""
+    import threading
+    import time
+
+    class FakeLane:
+        def __init__(self, name, delay=0.0, fail_at=None):
+            self.name, self.delay, self.fail_at = name, delay, fail_at
+            self.bound, self.uploads, self.ran = set(), [], []
+            self.busy = [False, False]
+            self.opened = self.closed = 0
+            self.slots = [None, None]
+
+        def bind(self):
+            self.bound.add(threading.get_ident())
+
+        def open(self):
+            assert threading.get_ident() in self.bound
+            self.opened += 1
+
+        def upload(self, k, chunk):
+            assert threading.get_ident() in self.bound and not self.busy[k], "a staging slot was loaded while its chunk ran"
+            self.slots[k] = np.array(chunk)
+            self.uploads.append((k, int(chunk[0, 0, 0])))
+
+        def run(self, k, c0):
+            assert threading.get_ident() in self.bound
+            self.busy[k] = True
+            time.sleep(self.delay)
+            frames = self.slots[k][:, 0, 0].astype(np.uint32)
+            if self.fail_at is not None and c0 >= self.fail_at:
+                self.busy[k] = False
+                raise RuntimeError(f"lane {self.name} failed at {c0}")
+            self.ran.append(c0)
+            self.busy[k] = False
+            assert int(frames[0]) == c0
+            return pd.DataFrame({"frame": frames, "lane": np.full(len(frames), self.name)})
+
+        def close(self):
+            self.closed += 1
+
+    F = 103
+    movie = np.arange(F, dtype=np.uint16)[:, None, None] * np.ones((1, 2, 2), np.uint16)      # pixel value = frame number
+    chunks = [(c0, min(F, c0 + 10)) for c0 in range(0, F, 10)]
+    # three lanes of very different speed
+    lanes = [FakeLane(0, 0.02), FakeLane(1, 0.0), FakeLane(2, 0.005)]
+    seen = []
+    parts = localize._run_lanes(movie, chunks, lanes, progress_callback=seen.append)
+    got = pd.concat(parts, ignore_index=True)
+    assert got["frame"].tolist() == list(range(F))
+    assert got["lane"].tolist() == [(f // 10) % 3 for f in range(F)]
+    assert seen == sorted(seen) and seen[-1] == F and len(seen) == len(chunks)
+    for li, lane in enumerate(lanes):
+        assert lane.opened == lane.closed == 1 and len(lane.bound) == 2          # its thread and its worker
+        assert lane.ran == [c0 for i, (c0, _) in enumerate(chunks) if i % 3 == li]
+        assert [k for k, _ in lane.uploads] == [n & 1 for n in range(len(lane.uploads))]
+    assert len({t for lane in lanes for t in lane.bound}) == 6                 # no thread shared between lanes
+    # one lane: everything in the calling thread + one worker
+    solo = FakeLane(9)
+    parts = localize._run_lanes(movie, chunks, [solo])
+    assert pd.concat(parts, ignore_index=True)["frame"].tolist() == list(range(F))
+    assert threading.get_ident() in solo.bound and len(solo.bound) == 2
+    # abort after the fourth chunk has been handed out: None, every lane closed
+    lanes = [FakeLane(0, 0.001), FakeLane(1, 0.001)]
+    asked = [0]
+
+    def abort():
+        asked[0] += 1
+        return asked[0] > 4
+    assert localize._run_lanes(movie, chunks, lanes, abort_callback=abort) is None
+    assert all(lane.closed == 1 for lane in lanes) and sum(len(lane.ran) for lane in lanes) <= 5
+    # an error in one lane: raised in the caller, the other lane stopped and closed
+    lanes = [FakeLane(0, 0.001), FakeLane(1, 0.001, fail_at=30)]
+    with pytest.raises(RuntimeError, match="lane 1 failed"):
+        localize._run_lanes(movie, chunks, lanes)
+    assert all(lane.closed == 1 for lane in lanes)
+
+
+def test_install_fused_and_default_devices(monkeypatch):
+    """install(fused=True, devices=...): the reference module's `localize` becomes this package's (one PCIe crossing),
+    and the device list becomes the default of localize_streamed; PICASSO_AMD_DEVICES does the same for a process that
+    cannot pass arguments; an explicit `devices=` wins."""
+    import types
+    pl, pm = types.SimpleNamespace(localize="theirs"), types.SimpleNamespace()
+    monkeypatch.setattr(localize, "_default_devices", None)
+    localize.install(pl, pm, types.SimpleNamespace())
+    assert pl.localize == "theirs" and localize._resolve_devices(None) is None
+    localize.install(pl, pm, types.SimpleNamespace(), fused=True, devices=[1, 0])
+    assert pl.localize is localize.localize and localize._resolve_devices(None) == [1, 0]
+    assert localize._resolve_devices([3]) == [3]
+    localize.set_devices(None)
+    monkeypatch.setenv("PICASSO_AMD_DEVICES", "0, 2,3")
+    assert localize._resolve_devices(None) == [0, 2, 3]
+    monkeypatch.setenv("PICASSO_AMD_DEVICES", "all")
+    assert localize._resolve_devices(None) == "all"
+    monkeypatch.delenv("PICASSO_AMD_DEVICES")
+    assert localize._resolve_devices(None) is None
+
+
+def test_streamed_lanes_for_devices(monkeypatch):
+    """`devices=` of localize_streamed -> (device, scratch bank) lanes: None keeps the calling thread's device unbound, a
+    device named twice gets the two banks the library has per device, a third time / an absent device is refused."""
+    from picasso_amd import _lib
+    monkeypatch.setattr(_lib, "device_count", lambda: 4)
+    assert localize._lanes_for(None, 7) == [(None, 0)]
+    assert localize._lanes_for("all", 7) == [(0, 0), (1, 0), (2, 0), (3, 0)]
+    assert localize._lanes_for([2, 0, 2], 7) == [(2, 0), (0, 0), (2, 1)]
+    assert localize._lanes_for([0, 1, 2, 3], 2) == [(0, 0), (1, 0)]             # no more lanes than chunks
+    for bad in ([0, 0, 0], [4], [-1], [], "gpu"):
+        with pytest.raises(ValueError):
+            localize._lanes_for(bad, 7)
+
+
 def test_picks_and_locs_to_identifications_match_reference():
     """Host-side table constructors (picasso/localize.py:752-913) against the reference's output
     (tests/golden/make_goldens_surface.py); rows of one frame are compared as a set (the reference's

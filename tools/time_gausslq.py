@@ -46,3 +46,5 @@ for rep in range(3):
 nf = np.empty(N, np.int32)
 _lib.check(L.pmi_memcpy_d2h(_lib.ptr(nf), d_nf, N * 4), "d2h")
 print("mean nfev", nf.mean(), "max", nf.max())
+from picasso_amd import backend  # noqa: E402
+print("second pass:", backend.last_lq_refit_count(), "spots;", backend.last_lq_tie_reasons())

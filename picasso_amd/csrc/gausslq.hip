@@ -625,7 +625,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_finish_kerne
 }
 
 // strict mode, boxes up to 7x7: one image column per lane (gausslq_w.hip)
-int launch_jacobian_w(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count, dim3 grid, hipStream_t s);
+int launch_jacobian_w(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count, int cus, hipStream_t s);
 
 template <bool FROM_MOVIE, bool STRICT, bool CR = false>
 static int launch_jacobian(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count,
@@ -640,12 +640,11 @@ static int launch_jacobian(const Params &p, const LqState &st, const int32_t *li
     // strict mode: m doubles of LDS per group (the rows of one column at a time, summed in MINPACK's order)
     auto lds_for = [&](int spots_per_wave) { return STRICT ? (size_t)LQ_WAVES * spots_per_wave * lq_sbuf_doubles(m) * sizeof(double) : (size_t)0; };
     static const bool g16 = tuning_env("PMI_LQ_GROUP16") != nullptr;      // A/B: the 16-lane groups for boxes up to 7
-    static const bool old7 = tuning_env("PMI_LQ_OLD7") != nullptr;         // A/B: the lane = row % 8 kernel for the strict rounds of boxes up to 7
+    // strict mode, first pass: the image columns on the lanes (gausslq_w.hip), every box
     if constexpr (STRICT && !CR && !FROM_MOVIE) {
-        if (p.box <= 7 && !old7) {
-            return launch_jacobian_w(p, st, list, list_n, count, grid_for(8), s);
-        }
-    }
+        (void)g16; (void)lds_for; (void)block;
+        return launch_jacobian_w(p, st, list, list_n, count, cus, s);
+    } else {
     // (more than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel)
 #define LQ_JAC(GS, E, SPW) do { \
         if (lds_for(SPW) > 65536) { \
@@ -680,6 +679,7 @@ static int launch_jacobian(const Params &p, const LqState &st, const int32_t *li
     }
 #undef LQ_JAC
     return PMI_OK;
+    }
 }
 
 // Rounds of (Jacobian + QR, step) over the spots still running that are queued before the finishing kernel takes over (boxes

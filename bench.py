@@ -55,6 +55,9 @@ def parse():
                          "schedule: the scan of the second half beside the fit of the first; 1 = one range, as the profiled passes)")
     ap.add_argument("--allow-env", action="store_true",
                     help="run although PMI_* / PICASSO_AMD_LIB tuning variables are set (they are echoed in the line)")
+    ap.add_argument("--scaling", default="weak", choices=("weak", "strong"),
+                    help="N > 1: weak = every rank owns a --frames movie (the default, what BASELINE's metric scales); "
+                         "strong = --frames is the whole job, each rank takes frames / N of it")
     ap.add_argument("--serial-gather", action="store_true",
                     help="N > 1: wait for each step's all-gather before the next step computes (no overlap)")
     return ap.parse_args()
@@ -118,6 +121,13 @@ def main():
 
     _lib.check(L.pmi_localize_set_ranges(args.ranges), "pmi_localize_set_ranges")
     F, H, W, box = args.frames, args.size, args.size, args.box
+    if args.scaling == "strong":
+        # the whole job is --frames frames: this rank's contiguous share (picasso_amd.dist.shard_frames), its own movie
+        from picasso_amd.dist import shard_frames
+        f_lo, f_hi = shard_frames(args.frames, world, rank)
+        F = f_hi - f_lo
+        if F < 16:
+            raise SystemExit(f"bench.py --scaling strong: {args.frames} frames over {world} ranks leaves {F} per rank")
     cam = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
     movie = synth.simulate_movie(F, H, W, emitters_per_frame=args.emitters,
                                  seed=synth.DEFAULT_SEED + rank, device=dev)
@@ -162,13 +172,16 @@ def main():
     # The all-gather is the library's own (pmi_allgather_locs: RCCL called from C on a side stream of ours); if that
     # communicator cannot be made the step falls back to torch.distributed's collectives and says so in the line.
     gather_impl, comm, gstream = "none", None, None
+    rccl_seen, rccl_lib = None, None
     if grouped:
         try:
             if os.environ.get("PMI_BENCH_TORCH_GATHER"):
                 raise RuntimeError("PMI_BENCH_TORCH_GATHER set")
             from picasso_amd.dist import NativeComm
             comm = NativeComm.for_group(None, dev)
-            assert comm.info() == (world, rank), f"communicator {comm.info()} but the launch has world {world} rank {rank}"
+            rccl_seen = comm.info()          # ncclCommCount / ncclCommUserRank of the library's own communicator
+            assert rccl_seen == (world, rank), f"communicator {rccl_seen} but the launch has world {world} rank {rank}"
+            rccl_lib = NativeComm.library_path()
             gstream = torch.cuda.Stream(device=dev)
             gather_impl = "pmi_allgather_locs (RCCL from libpicasso_hip.so)"
         except Exception as exc:      # noqa: BLE001 - any failure to set up the native communicator
@@ -180,6 +193,7 @@ def main():
         if int(okt.item()) == 0 and comm is not None:
             comm.close()
             comm, gstream = None, None
+            rccl_seen = None
             gather_impl = "torch.distributed all_gather_into_tensor (native communicator unavailable on another rank)"
     g_stream_ptr = ctypes.c_void_p(gstream.cuda_stream) if gstream is not None else None
 
@@ -350,7 +364,7 @@ def main():
         result = {
             "metric": "localizations/sec (7x7 ROI, MLE)", "value": value, "unit": "localizations/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak",
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None,
             # every spot in the reference's arithmetic (pmi_mle_set_mode strict), the same step, after the timed ones (no all-gather)
             "ms_per_step_strict": strict_ms,
@@ -370,6 +384,11 @@ def main():
                        "mle_mode": mle_mode, "refit_margin": mle_margin, "refit_spots_rank0": refit,
                        "frame_ranges_in_flight": args.ranges,
                        "all_gather": gather_impl,
+                       # the collective's own evidence: world size and rank RCCL reports for the library's communicator on
+                       # rank 0 (ncclCommCount / ncclCommUserRank), and the librccl its entry points resolved to (dladdr)
+                       "rccl_world": rccl_seen[0] if rccl_seen else None,
+                       "rccl_rank0_sees": list(rccl_seen) if rccl_seen else None,
+                       "librccl": rccl_lib,
                        "sharding": f"frames x{world}", "per_rank": per_rank, "env_overrides": overrides},
             "roofline": roofline,
             "cpu_baseline": cpu,

@@ -381,7 +381,8 @@ int pmi_rcc_pair_list(const double *segments, int64_t n_seg, int64_t Y, int64_t 
 int pmi_comm_available(void);
 int pmi_comm_unique_id(void *id128);
 int pmi_comm_init(const void *id128, int world, int rank, void **comm);
-int pmi_comm_info(void *comm, int *world, int *rank);
+int pmi_comm_info(void *comm, int *world, int *rank);         /* as RCCL reports them (ncclCommCount / ncclCommUserRank) */
+int pmi_comm_library_path(char *path, size_t path_len);         /* the librccl the collectives resolved to (dladdr) */
 int pmi_comm_destroy(void *comm);
 int pmi_allgather_locs(void *comm, const void *d_table, int ncols, int64_t cap, const int64_t *d_n,
                        void *d_all_tables, int64_t *d_all_counts, void *stream);

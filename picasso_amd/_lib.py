@@ -98,6 +98,7 @@ SYMBOLS = {
     "pmi_comm_unique_id": (_i32, [_p]),
     "pmi_comm_init": (_i32, [_p, _i32, _i32, _p]),
     "pmi_comm_info": (_i32, [_p, _p, _p]),
+    "pmi_comm_library_path": (_i32, [_p, _sz]),
     "pmi_comm_destroy": (_i32, [_p]),
     "pmi_allgather_locs": (_i32, [_p, _p, _i32, _i64, _p, _p, _p, _p]),
     "pmi_compact_gathered_dev": (_i32, [_p, _p, _i32, _i32, _i64, _p, _i64, _p, _p]),

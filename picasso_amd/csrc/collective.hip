@@ -33,6 +33,8 @@ struct Rccl {
     int (*AllGather)(const void *, void *, size_t, int, Comm, hipStream_t);
     int (*GroupStart)();
     int (*GroupEnd)();
+    int (*CommCount)(Comm, int *);
+    int (*CommUserRank)(Comm, int *);
     const char *(*GetErrorString)(int);
     bool ok = false;
 };
@@ -53,6 +55,8 @@ int load_rccl()
     PMI_SYM(AllGather, "ncclAllGather")
     PMI_SYM(GroupStart, "ncclGroupStart")
     PMI_SYM(GroupEnd, "ncclGroupEnd")
+    PMI_SYM(CommCount, "ncclCommCount")
+    PMI_SYM(CommUserRank, "ncclCommUserRank")
     PMI_SYM(GetErrorString, "ncclGetErrorString")
 #undef PMI_SYM
     g_rccl.ok = true;
@@ -142,8 +146,28 @@ int pmi_comm_info(void *comm, int *world, int *rank)
 {
     if (!comm) { pmi::set_error("null communicator"); return PMI_ERR_ARG; }
     pmi::CommBox *box = static_cast<pmi::CommBox *>(comm);
-    if (world) *world = box->world;
-    if (rank) *rank = box->rank;
+    // what RCCL itself says about the communicator (not what pmi_comm_init was told)
+    using namespace pmi;
+    int w = -1, r = -1;
+    PMI_RCCL(g_rccl.CommCount(box->comm, &w));
+    PMI_RCCL(g_rccl.CommUserRank(box->comm, &r));
+    if (w != box->world || r != box->rank) { pmi::set_error("communicator reports world %d rank %d, made as %d / %d", w, r, box->world, box->rank); return PMI_ERR_HIP; }
+    if (world) *world = w;
+    if (rank) *rank = r;
+    return PMI_OK;
+}
+
+int pmi_comm_library_path(char *path, size_t path_len)
+{
+    // the shared object the collective entry points resolved to (torch bundles an RCCL of its own next to /opt/rocm's)
+    using namespace pmi;
+    int rc = load_rccl();
+    if (rc != PMI_OK) return rc;
+    Dl_info di;
+    if (!path || !path_len) { set_error("null pointer"); return PMI_ERR_ARG; }
+    if (!dladdr(reinterpret_cast<void *>(g_rccl.AllGather), &di) || !di.dli_fname) { set_error("dladdr cannot place ncclAllGather"); return PMI_ERR_HIP; }
+    strncpy(path, di.dli_fname, path_len - 1);
+    path[path_len - 1] = 0;
     return PMI_OK;
 }
 

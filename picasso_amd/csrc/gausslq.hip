@@ -525,7 +525,7 @@ __global__ __launch_bounds__(256) void lq_init_kernel(Params p, LqState st, int6
 
 // (lq_step_spot: lq_common.h; lq_step_kernel and its launcher: gausslq_step.hip)
 int launch_step(bool strict, const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count, int32_t *next_list,
-                unsigned *next_n, int32_t *tie_list, unsigned *tie_n, size_t step_lds, hipStream_t s);
+                unsigned *next_n, int32_t *tie_list, unsigned *tie_n, size_t step_lds, int64_t max_blocks, hipStream_t s);
 
 // ---- the fits the rounds have left, finished on the device ------------------------------------------------------
 // MINPACK's loop has no bound a host could queue ahead of (maxfev = 1400: up to 200 rounds), and asking the device how many
@@ -625,11 +625,11 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_finish_kerne
 }
 
 // strict mode, boxes up to 7x7: one image column per lane (gausslq_w.hip)
-int launch_jacobian_w(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count, int cus, hipStream_t s);
+int launch_jacobian_w(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count, int64_t max_blocks, hipStream_t s);
 
 template <bool FROM_MOVIE, bool STRICT, bool CR = false>
 static int launch_jacobian(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count,
-                            int cus, hipStream_t s)
+                            int cus, hipStream_t s, bool light = false)
 {
     const int m = p.box * p.box;
     dim3 block(LQ_WAVES * 64);
@@ -643,7 +643,7 @@ static int launch_jacobian(const Params &p, const LqState &st, const int32_t *li
     // strict mode, first pass: the image columns on the lanes (gausslq_w.hip), every box
     if constexpr (STRICT && !CR && !FROM_MOVIE) {
         (void)g16; (void)lds_for; (void)block;
-        return launch_jacobian_w(p, st, list, list_n, count, cus, s);
+        return launch_jacobian_w(p, st, list, list_n, count, (int64_t)cus * (light ? 4 : 16), s);
     } else {
     // (more than 64 KB of dynamic LDS per workgroup has to be asked for, once per kernel)
 #define LQ_JAC(GS, E, SPW) do { \
@@ -755,7 +755,7 @@ static int launch(Params p, hipStream_t s)
     int32_t *tie_list = st.i + (size_t)cap * (LQ_NSI + 2);
     unsigned *counters = (unsigned *)(tie_list + cap);           // one per round + the tie counter, zeroed per batch
     constexpr int NCTR = 64;
-    static_assert(LQ_ROUNDS >= 1 && LQ_ROUNDS + 7 <= NCTR, "one counter per round");
+    static_assert(LQ_ROUNDS >= 1 && LQ_ROUNDS + 7 + 36 <= NCTR, "one counter per round");
     unsigned *tie_n = counters + NCTR;
     const int mode = lq_mode_now();
     const bool no_strict = mode == PMI_LQ_FAST, all_strict = mode == PMI_LQ_STRICT;
@@ -776,7 +776,11 @@ static int launch(Params p, hipStream_t s)
     // rounds queued before the finishing kernel: a fit of an n x n box takes (nfev - 1) / 7 of them — 2 to 4 at 7x7 (none left
     // after five), up to ten at 13x13, where the finishing kernel's one spot per Jacobian would be the slower way for many
     // (3x3: nine residuals for six parameters — a third of the fits are still running after five rounds, and a round costs little)
-    const int rounds = p.box <= 3 ? LQ_ROUNDS + 7 : (p.box <= 7 ? LQ_ROUNDS : (p.box <= 9 ? LQ_ROUNDS + 1 : (p.box <= 13 ? LQ_ROUNDS + 4 : LQ_ROUNDS + 7)));
+    const int full_rounds = p.box <= 3 ? LQ_ROUNDS + 7 : (p.box <= 7 ? LQ_ROUNDS : (p.box <= 9 ? LQ_ROUNDS + 1 : (p.box <= 13 ? LQ_ROUNDS + 4 : LQ_ROUNDS + 7)));
+    // 3x3 (strict mode): a tenth of the fits is still running after the full rounds and the longest take another fifty —
+    // light rounds (small grids, 10 ... 20 us each when their list is empty) before the finishing kernel, which works a
+    // wavefront's 64 spots off eight Jacobians at a time
+    const int rounds = full_rounds + (all_strict && p.box <= 3 ? 36 : 0);
     for (int64_t first = 0; first < Ntotal; first += BATCH) {
         const int64_t count = std::min<int64_t>(BATCH, Ntotal - first);
         st.first = first;
@@ -795,9 +799,12 @@ static int launch(Params p, hipStream_t s)
         for (int round = 0; round < rounds; round++) {
             int32_t *nxt = lists[round & 1];
             unsigned *nxt_n = counters + round;
-            if ((rc = all_strict ? launch_jacobian<FROM_MOVIE, true>(p, st, cur, cur_n, count, cus, s)
-                                 : launch_jacobian<FROM_MOVIE, false>(p, st, cur, cur_n, count, cus, s)) != PMI_OK) return rc;
-            if ((rc = launch_step(all_strict, p, st, cur, cur_n, count, nxt, nxt_n, tie_list, tie_n, step_lds, s)) != PMI_OK) return rc;
+            // a round past the full ones runs on small grids: few spots are left, how many only the device knows
+            const bool light = round >= full_rounds;
+            if ((rc = all_strict ? launch_jacobian<FROM_MOVIE, true>(p, st, cur, cur_n, count, cus, s, light)
+                                 : launch_jacobian<FROM_MOVIE, false>(p, st, cur, cur_n, count, cus, s, light)) != PMI_OK) return rc;
+            if ((rc = launch_step(all_strict, p, st, cur, cur_n, count, nxt, nxt_n, tie_list, tie_n, step_lds,
+                                  light ? (int64_t)cus * 8 : (int64_t)1 << 40, s)) != PMI_OK) return rc;
             cur = nxt; cur_n = nxt_n;
         }
         if (all_strict) launch_finish<false, false, true>(fin_shape, fin_grid, fin_lds, s, p, st, cur, cur_n, tie_list, tie_n);

@@ -13,7 +13,7 @@ namespace lq {
 #include "lq_jacobian_w.inc"
 
 template <int W>
-static int launch_w(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count, int cus, hipStream_t s)
+static int launch_w(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count, int64_t max_blocks, hipStream_t s)
 {
     constexpr int NGRP = 64 / LqwBox<W>::GS;           // spots per wavefront
     const size_t lds = lqw_lds_bytes_of<W>();
@@ -27,25 +27,26 @@ static int launch_w(const Params &p, const LqState &st, const int32_t *list, con
         }
     }
     const int64_t waves = (count + NGRP - 1) / NGRP;
-    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + LQ_WAVES - 1) / LQ_WAVES, (int64_t)cus * 16)));
+    const dim3 grid((unsigned)std::max<int64_t>(1, std::min<int64_t>((waves + LQ_WAVES - 1) / LQ_WAVES, max_blocks)));
     hipLaunchKernelGGL((lq_jacobian_w_kernel<W>), grid, dim3(LQ_WAVES * 64), lds, s, p, st, list, list_n, count);
     return PMI_OK;
 }
 
+// max_blocks: at most that many workgroups (the kernel walks its list with a stride; a late round is launched small)
 // the Jacobian + QR of the spots of a round (list == nullptr: spots [st.first, st.first + count)), every odd box 3 .. 21
-int launch_jacobian_w(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count, int cus, hipStream_t s)
+int launch_jacobian_w(const Params &p, const LqState &st, const int32_t *list, const unsigned *list_n, int64_t count, int64_t max_blocks, hipStream_t s)
 {
     switch (p.box) {
-    case 3: return launch_w<3>(p, st, list, list_n, count, cus, s);
-    case 5: return launch_w<5>(p, st, list, list_n, count, cus, s);
-    case 7: return launch_w<7>(p, st, list, list_n, count, cus, s);
-    case 9: return launch_w<9>(p, st, list, list_n, count, cus, s);
-    case 11: return launch_w<11>(p, st, list, list_n, count, cus, s);
-    case 13: return launch_w<13>(p, st, list, list_n, count, cus, s);
-    case 15: return launch_w<15>(p, st, list, list_n, count, cus, s);
-    case 17: return launch_w<17>(p, st, list, list_n, count, cus, s);
-    case 19: return launch_w<19>(p, st, list, list_n, count, cus, s);
-    case 21: return launch_w<21>(p, st, list, list_n, count, cus, s);
+    case 3: return launch_w<3>(p, st, list, list_n, count, max_blocks, s);
+    case 5: return launch_w<5>(p, st, list, list_n, count, max_blocks, s);
+    case 7: return launch_w<7>(p, st, list, list_n, count, max_blocks, s);
+    case 9: return launch_w<9>(p, st, list, list_n, count, max_blocks, s);
+    case 11: return launch_w<11>(p, st, list, list_n, count, max_blocks, s);
+    case 13: return launch_w<13>(p, st, list, list_n, count, max_blocks, s);
+    case 15: return launch_w<15>(p, st, list, list_n, count, max_blocks, s);
+    case 17: return launch_w<17>(p, st, list, list_n, count, max_blocks, s);
+    case 19: return launch_w<19>(p, st, list, list_n, count, max_blocks, s);
+    case 21: return launch_w<21>(p, st, list, list_n, count, max_blocks, s);
     default: set_error("gausslq: no kernel for box %d", p.box); return PMI_ERR_ARG;
     }
 }

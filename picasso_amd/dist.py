@@ -140,6 +140,16 @@ class NativeComm:
         _lib.check(_lib.load().pmi_comm_info(self._h, ctypes.byref(w), ctypes.byref(r)), "pmi_comm_info")
         return w.value, r.value
 
+    @staticmethod
+    def library_path() -> str:
+        """The librccl shared object the library's collectives resolved to (dladdr of ncclAllGather)."""
+        import ctypes
+
+        from . import _lib
+        buf = ctypes.create_string_buffer(1024)
+        _lib.check(_lib.load().pmi_comm_library_path(buf, 1024), "pmi_comm_library_path")
+        return buf.value.decode()
+
     def allgather_table(self, table: torch.Tensor, d_n: torch.Tensor, stream=None):
         """table: (C, cap) int32 on the GPU, the same cap on every rank; d_n: its device row count (int64).
         Returns (gathered (world, C, cap), counts (world,) int64), both on the device; asynchronous."""

@@ -89,6 +89,22 @@ def test_bench_under_the_launcher_uses_the_native_all_gather(serial):
     assert per and len(per["compute_ms"]) == 1 and per["compute_ms"][0] > 0
     assert per["gather_ms"][0] is not None and per["gather_ms"][0] >= 0 and per["gather_bytes_received_per_step"] > 0
     assert ("double-buffered" in line["config"]["workload"]) == (not serial)
+    # the line proves its own collective: what RCCL reports for the library's communicator, and which librccl it called
+    assert line["config"]["rccl_world"] == 1 and line["config"]["rccl_rank0_sees"] == [1, 0]
+    assert os.path.basename(line["config"]["librccl"]).startswith("librccl.so") and os.path.exists(line["config"]["librccl"])
+    assert line["scaling"] == "weak"
+
+
+def test_bench_strong_scaling_shares_the_frames():
+    """`bench.py --scaling strong`: --frames is the whole job, each rank localizes frames / N of it (one rank here: all of
+    it), the line says "strong" and its localization count is the whole job's."""
+    small = ["--steps", "3", "--warmup", "1", "--frames", "300", "--cpu-seconds", "0", "--profile-steps", "0", "--strict-steps", "0"]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--scaling", "strong"] + small
+    out = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    line = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["config"]["frames"] == 300 and line["config"]["localizations_total"] > 20000
 
 
 def test_native_communicator_one_rank():

@@ -171,6 +171,38 @@ def test_config5_fused_pipeline_on_the_astigmatic_movie(be, orc):
     assert 0 < out["refit_spots"] < 0.05 * out["localizations_gpu"]
 
 
+def test_config5_lq3d_twin_on_the_astigmatic_movie(be, orc):
+    """Config 5 through the reference's 3-D DEFAULT route (picasso/zfit.py:300,472: fitting_method="gausslq"):
+    pmi_localize_lq_dev with box 13 on 3000 frames of the astigmatic movie, then the z fit, against the oracle's identify ->
+    get_spots -> lmdif -> table -> zfit on every row.  The strict mode is MINPACK's own arithmetic: theta is the oracle's bit
+    for bit, so the table columns are compared for equality, z to the tolerance of the Brent search."""
+    import torch
+    from picasso_amd import synth
+    g = golden("zfit_calib3d")
+    F = 3000
+    movie = synth.simulate_movie(F, 512, 512, emitters_per_frame=116, device="cuda", sigma=(1.1, 2.4), astigmatic=True,
+                                 photons=(3000.0, 9000.0), seed=synth.DEFAULT_SEED + 5)
+    torch.cuda.synchronize()
+    assert be.get_lq_mode() == "strict"
+    t = be.localize_lq_device(movie.data_ptr(), np.uint16, tuple(movie.shape), 13, 5000.0, CAM)
+    n = len(t["frame"])
+    assert n > 2.5e5
+    host = movie.cpu().numpy()
+    del movie
+    fr, y, x, ng = orc.identify(host, 5000.0, 13, threads=orc.max_threads())
+    assert n == len(fr) and np.array_equal(t["frame"], fr.astype(np.uint32)) and np.array_equal(t["net_gradient"], ng)
+    spots = orc.get_spots(host, fr, y, x, 13, CAM)
+    th = orc.gausslq(spots, threads=orc.max_threads())
+    same = lambda a, b: np.array_equal(a, b, equal_nan=True)      # noqa: E731
+    assert same(t["x"], (th[:, 0].astype(np.float64) + x).astype(np.float32)) and same(t["y"], (th[:, 1].astype(np.float64) + y).astype(np.float32))
+    assert same(t["photons"], th[:, 2]) and same(t["bg"], th[:, 3]) and same(t["sx"], th[:, 4]) and same(t["sy"], th[:, 5])
+    z, sq = be.zfit_arrays(t["sx"], t["sy"], g["cx"], g["cy"])
+    oz, osq = orc.zfit(th[:, 4], th[:, 5], g["cx"], g["cy"], threads=orc.max_threads())
+    ok = np.isfinite(oz)
+    assert np.array_equal(np.isfinite(z), ok) and np.max(np.abs(z[ok] - oz[ok])) < 5e-5
+    assert be.last_lq_refit_count() < 1e-3 * n
+
+
 def test_config4_geometry_shard_in_miniature(be, orc):
     """Config 4's frame geometry (2048 x 2048, ~1600 spots per frame) at a length the oracle can follow: the
     identification set and net gradients are the oracle's, the fit is within tolerance, frame ranges concatenate

@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--only", type=int, default=0, help="3 or 5: just that config")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--no-lq3d", action="store_true", help="config 5: skip the least-squares twin of the route")
     ap.add_argument("--defer", type=int, default=1, choices=(0, 1), help="A/B: 0 keeps identify's exact stage in the scan (pmi_localize_set_defer)")
     args = ap.parse_args()
     import torch
@@ -168,6 +169,34 @@ def config5(args, torch, orc, L, _lib, synth, cam, threads, timed, kernel_ms, ro
                                   ctypes.c_void_p(zout.data_ptr()), ctypes.c_void_p(zout.data_ptr() + cap * 8), None), "zfit")
 
     t_z = timed(zf)
+    # ---- the lq-3d twin: the reference's 3-D default is fitting_method="gausslq" (picasso/zfit.py:300,472) -> the same movie
+    # through identify(box 13) + fused cut + MINPACK lmdif (strict mode) + 11-column table, then the same z fit
+    lq_table = torch.empty((_lib.PMI_LQ_COLUMNS, cap), dtype=torch.int32, device="cuda")
+    lcol = lambda c: ctypes.c_void_p(lq_table.data_ptr() + c * cap * 4)      # noqa: E731
+
+    def lq13():
+        _lib.check(L.pmi_localize_lq_dev(ctypes.c_void_p(movie.data_ptr()), 0, F, H, W, 13, 5000.0, None, 0, F - 1,
+                                         cam["Baseline"], cam["Sensitivity"], cam["Gain"], 0, ctypes.c_void_p(lq_table.data_ptr()),
+                                         cap, ctypes.c_void_p(d_n.data_ptr()), None), "lq13")
+
+    lq_route = None
+    if not args.no_lq3d:
+        assert backend.get_lq_mode() == "strict"
+        t_l = timed(lq13)
+        n_l = int(d_n.item())
+        lq_scan_ms, lq_fit_ms = kernel_ms(lq13)
+
+        def zf_lq():
+            _lib.check(L.pmi_zfit_dev(lcol(4), lcol(5), n_l, None, ctypes.c_void_p(cx.data_ptr()), ctypes.c_void_p(cy.data_ptr()),
+                                      ctypes.c_void_p(zout.data_ptr()), ctypes.c_void_p(zout.data_ptr() + cap * 8), None), "zfit")
+        t_zl = timed(zf_lq)
+        lq_route = {"metric": "localizations/sec (13x13 ROI astigmatic gausslq + zfit)", "value": n_l / (t_l + t_zl),
+                    "ms_per_step": 1e3 * (t_l + t_zl), "localizations": n_l, "mode": "strict",
+                    "stages_ms": {"identify+gausslq+table": 1e3 * t_l, "zfit": 1e3 * t_zl},
+                    "kernels_ms": {"identify_scan": lq_scan_ms, "gausslq_fit": lq_fit_ms},
+                    "second_pass_spots": backend.last_lq_refit_count(), "over_mle_route": (t_l + t_zl) / (t_m + t_z)}
+        mle13(); torch.cuda.synchronize()          # (d_n and the statistics back to the MLE route's for the line below)
+    del lq_table
     cpu = None
     if args.cpu_seconds > 0:
         nf = min(F, 400)
@@ -191,6 +220,7 @@ def config5(args, torch, orc, L, _lib, synth, cam, threads, timed, kernel_ms, ro
                               "exact_stage_deferred_to_fit": False},
                       "roofline": roofline(movie.numel() * 2, scan_ms, fit_ms, n, "mle_fit_13x13 (g8 init/iterate/final + strict refit + crlb)",
                                            "fp32 valu issue; 406 B/spot algorithmic", 406.0),
+                      "lq3d_route": lq_route,
                       "cpu_baseline": cpu}), flush=True)
 
 

@@ -24,9 +24,10 @@
 // gives the same bits as evaluating it B^2 times.  (d + 1/2 of pixel k and d - 1/2 of pixel
 // k + 1 are the same float64 whenever k - mu is exact, i.e. |mu| > 3e-8.)
 //
-// Mapping: a group of GS lanes per spot (GS = 64: one wavefront per spot, the lowest
-// latency, used for the flagged-spot list; GS = 16 / 32: four / two spots per wavefront
-// for boxes <= 7 / <= 15 when every spot is fitted this way, PMI_MLE_STRICT).
+// Mapping: a group of GS lanes per spot — GS = 16 / 32 / 64 (four / two / one spot per
+// wavefront) for boxes <= 7 / <= 15 / larger, for the flagged-spot list and for PMI_MLE_STRICT
+// alike: the kernel is bound by instruction issue, and the list's launch by its longest fits
+// (launch_fit_strict: 64-lane groups for the list were measured slower, 0.45 against 0.30 ms).
 #include <algorithm>
 #include <cstdlib>
 

@@ -1159,7 +1159,10 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
     // (boxes up to 7: eight lanes per candidate in the start-value kernel.  With the 16-lane groups of boxes 9 ... 15 the stage
     // costs the fit more than it saves the scan — config 5, box 13: scan 7.0 -> 6.0 ms, fit 19.9 -> 22.0 ms — so those boxes
     // keep it in the scan, which is bound by instruction issue there, not by its memory requests)
-    const bool defer = g_localize_defer && !hand && box <= 7 && mle_mode_now() != PMI_MLE_STRICT &&
+    // (a tuning build's PMI_FIT_WAVE_PER_SPOT / PMI_MLE_NO_KEEP take the fit off the row-per-lane path that hosts the stage:
+    // the stage then stays in the scan — the predicate fit_impl checks)
+    static const bool off_g8 = tuning_env("PMI_FIT_WAVE_PER_SPOT") != nullptr || tuning_env("PMI_MLE_NO_KEEP") != nullptr;
+    const bool defer = g_localize_defer && !hand && !off_g8 && box <= 7 && mle_mode_now() != PMI_MLE_STRICT &&
                        (dtype == PMI_U16 || dtype == PMI_U8 || dtype == PMI_I16) && min_ng > 0.0 && std::isfinite(min_ng);
     const int64_t capc = defer ? cap + cap / 2 + 4096 : cap;         // rows of the identification / fit arrays
     int64_t cy0 = 0, cx0 = 0, cy1 = Y, cx1 = X;

@@ -500,6 +500,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
     // candidate, instead of sending the fit a group of lanes for every reject.
     int ex_seen = 0, ex_kept = 0;
     bool defer_now = false;
+    int defer_rounds = 0;
 
     // ---- results: buffered in registers, appended KBUF rounds at a time with ONE slot-allocating atomic per flush
     // per wave on the counter of this block's shard (a single hot counter costs ~11 ns per atomic)
@@ -608,6 +609,9 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
             pixbase = (unsigned)__builtin_amdgcn_readfirstlane((int)pixbase);
         }
         bool kept = false;
+        // a wave that defers still decides one round in sixteen itself: its accept rate follows the rows it is in (a wave that
+        // starts on dense spots and then crosses shot-noise rows would otherwise hand every reject to the fit)
+        const bool probe = defer_now && (++defer_rounds & 15) == 0;
         if (lane < n) {
             const int q = (head + lane) & (LIST - 1);
             const unsigned e = s_pos[q];
@@ -620,7 +624,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                 slot = (int)((unsigned)shard * p.pix_cap + pixbase + (unsigned)lane);
                 pixdst = p.pix + (size_t)slot * (size_t)(BOX * (H + 1));
             }
-            if (defer_now) {
+            if (defer_now && !probe) {
 #pragma unroll
                 for (int k = 0; k < KBUF; k++) if (k == nbuf) { buf_f[k] = fi; buf_i[k] = i; buf_j[k] = j; buf_ng[k] = __uint_as_float(NG_DEFERRED_BITS); buf_s[k] = -1; }
                 nbuf++;
@@ -634,7 +638,8 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                 kept = first_max && (double)ng > p.min_ng;
             }
         }
-        if (p.defer && !defer_now) {
+        if (p.defer && (!defer_now || probe)) {
+            if (probe) { ex_seen >>= 1; ex_kept >>= 1; }       // the history fades: two probes that reject most outweigh it
             ex_seen += n;
             ex_kept += (int)__popcll(__ballot(kept));
             defer_now = ex_seen >= 32 && ex_kept * 4 >= ex_seen * 3;

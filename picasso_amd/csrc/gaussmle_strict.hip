@@ -99,15 +99,24 @@ __global__ __launch_bounds__(FIT_NT) void mle_strict_kernel(FitParams p, const i
     // it is done with the last.  (Every wavefront asking the queue at its START was measured slower on short lists — 7 346
     // entries, config 2: 142 instead of 94 us — 3 072 atomics on one word from eight XCDs complete one after the other.)
     unsigned *qw = list ? p.strict_queue : nullptr;
+    // ... and takes several rounds' worth of entries per visit when the list is long: the queue is ONE word, and the atomics
+    // of three thousand wavefronts on it complete one after the other (~0.1 us each) — at eps 1e-4 config 2's list is
+    // 113 000 entries = 28 000 visits of four, 2.8 of the launch's 3.4 ms; config 5's two lists of 26 000 13x13 spots paid
+    // 1 ms each.  Up to eight rounds per visit, never more than half of what a wavefront's fair share would be.
+    const int64_t fair = items / (2 * total_groups);
+    const unsigned chunk = (unsigned)NSPW * (unsigned)(fair < 1 ? 1 : (fair > 8 ? 8 : fair));
     int64_t w0 = group0 - g;                                             // wave-uniform
-    for (bool first = true;; first = false) {
-        if (!first) {
+    int64_t w_lim = w0 + NSPW;                                           // end of the entries this wavefront holds
+    for (;; w0 += NSPW) {
+        if (w0 >= w_lim) {
             if (qw) {
                 unsigned t = 0;
-                if (lane == 0) t = atomicAdd(qw, (unsigned)NSPW);
+                if (lane == 0) t = atomicAdd(qw, chunk);
                 w0 = total_groups + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
+                w_lim = w0 + chunk;
             } else {
-                w0 += total_groups;
+                w0 += total_groups - NSPW;
+                w_lim = w0 + NSPW;
             }
         }
         if (w0 >= items) break;

@@ -354,7 +354,7 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_source,
                     "measured_on": f"{args.profile_steps} single-range passes over the whole movie after the timed steps (HIP events "
                                    "around the kernels on their launch stream, inside the library); the same launches as "
-                                   "`bench.py --ranges 1`, profiles/r04_bench_ranges1_kernel_stats.txt",
+                                   "`bench.py --ranges 1`, profiles/r05_bench_ranges1_kernel_stats.txt",
                     "scan_kernel": scan_kernel,
                     "kernels": kernels}
         kernels["mle_fit"]["bound"] = "fp32 valu (no MFMA shape); algorithmic bytes are 166 B/spot"
@@ -403,7 +403,7 @@ def main():
     return result
 
 
-PMC_TRAFFIC_FILE = "profiles/r04_identify_pmc.json"
+PMC_TRAFFIC_FILE = "profiles/r05_identify_pmc.json"
 
 
 def last_scan_kernel(L):

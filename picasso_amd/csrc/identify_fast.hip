@@ -105,6 +105,7 @@ struct FastParams {
     int rbu;                   // rows per unit (per sub-band when P > 1)
     int upf;                   // units per frame: ceil(cy / (rbu * P)) * segs
     long long units;           // nframes * upf
+    int pf;                    // P > 1: the P lane sets hold the same rows of P consecutive FRAMES (short frames: no halo inside a frame), not P row ranges of one
     int upw;                   // consecutive units per wavefront
     int lin_rows;              // > 0 (one row range per lane set, P == 1): a wave takes lin_rows consecutive rows of the
     long long lin_total;       //   sequence (segment, frame, row) of lin_total rows, cut into units only at frame boundaries
@@ -460,7 +461,10 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
     if (unit0 >= unit1) return;
     if (p.gate && *p.gate != p.gate_want) return;
     const int sub = P > 1 ? lane / NL : 0;                            // this lane's sub-band and its rows' offset
-    const int sub_rows = sub * p.rbu;
+    // Two ways to fill a wavefront with a narrow frame: P row ranges of ONE frame side by side (each pays its 2H + 2 halo rows:
+    // 8 for every 8 rows of a 64 x 64 frame at box 7), or the same rows of P consecutive frames (p.pf; round 5)
+    const bool fside = P > 1 && p.pf != 0;
+    const int sub_rows = fside ? 0 : sub * p.rbu;
 
     // The crop may start at any column: lanes work on 8-pixel chunks aligned in the FRAME (16-byte
     // loads), xoff pixels of the first chunk lie left of the crop.  Positions outside the crop are
@@ -659,6 +663,15 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
             unit_rows = (int)(unit1 - unit < (long long)(p.cy - b0) ? unit1 - unit : (long long)(p.cy - b0));
             bend = b0 + unit_rows;
             unit += unit_rows;
+        } else if (fside) {
+            const long long fg = unit / p.upf;             // a group of P consecutive frames, upf row ranges each
+            fi = (int)fg * P;                              // the frame of sub-band 0
+            seg = 0;
+            const int band = (int)(unit - fg * p.upf);
+            b0 = band * p.rbu;
+            unit_rows = min(p.rbu, p.cy - b0);
+            bend = b0 + p.rbu;
+            unit++;
         } else {
             fi = (int)(unit / p.upf);
             const int rem = (int)(unit - (long long)fi * p.upf);
@@ -672,7 +685,9 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
             unit++;
         }
         const int c8 = P > 1 ? lane % NL : seg * 64 + lane;
-        const bool lane_valid = c8 < nch;
+        // (frames side by side: a lane set past the last frame repeats the last one and marks nothing)
+        const int sub_f = fside ? min(sub, p.nframes - 1 - fi) : 0;
+        const bool lane_valid = c8 < nch && (!fside || fi + sub < p.nframes);
         const int cm = min(c8, nch - 1);
         const PX *src = frame_src(fi);
         const int col_m = cm * 8;
@@ -702,7 +717,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
         // Neighbour pixels come from the adjacent lanes' registers (DPP), not from memory: overlapping
         // 8-byte loads next to the 16-byte ones doubled the HBM-side traffic (requests to a line whose
         // fill is still in flight are not merged).  Only lanes 0 and 63 load the 4 pixels beyond the wave.
-        const unsigned off_m = (unsigned)col_m * (unsigned)PXB;
+        const unsigned off_m = (unsigned)col_m * (unsigned)PXB + (unsigned)sub_f * ((unsigned)p.Y * pitch);
         const unsigned off_e = (lane == 0 || lane == 63) ? (unsigned)(lane == 0 ? col_l : col_r) * (unsigned)PXB : 0x7ffffff0u;   // others: out of bounds
         // a sub-band's row lies wholly inside its lanes, and so does the row of a frame at most 512 pixels wide: the
         // pixels lanes 0 and 63 would take from beyond the wave then only feed masked positions
@@ -968,7 +983,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                                 // bit b: row slot (b >> 2) & 3, pixel 2 * (b & 3) + (b >> 4)
                                 const u32 e = ebase + (((b >> 2) & 3u) << 16) + ((b & 3u) << 1) + (b >> 4);
                                 const int slot = tail + (int)__builtin_amdgcn_mbcnt_hi((u32)(bal >> 32), __builtin_amdgcn_mbcnt_lo((u32)bal, 0u));
-                                if (slot - head < LIST) { s_pos[slot & (LIST - 1)] = e; s_fi[slot & (LIST - 1)] = (unsigned)fi; }
+                                if (slot - head < LIST) { s_pos[slot & (LIST - 1)] = e; s_fi[slot & (LIST - 1)] = (unsigned)(fi + sub_f); }
                             }
                             const int nb_ = __popcll(bal);
                             added += nb_;
@@ -1064,12 +1079,15 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                 tail = tail0;
                 const int wcols = P > 1 ? NL * 8 : 512;
                 for (int s = 0; s < P; s++) {
-                    const int r_lo = max(clo + s * p.rbu, H), r_hi = min(min(clo + dn, bend) + s * p.rbu, p.cy - H - 1);
+                    const int rofs = fside ? 0 : s * p.rbu, fs = fside ? fi + s : fi;       // the lane set's rows / frame
+                    if (fs >= p.nframes) break;
+                    const PX *ssrc = fside ? frame_src(fs) : src;
+                    const int r_lo = max(clo + rofs, H), r_hi = min(min(clo + dn, bend) + rofs, p.cy - H - 1);
                     for (int idx0 = 0; idx0 < dn * wcols; idx0 += 64) {
                         const int idx = idx0 + lane;
-                        const int i = clo + s * p.rbu + idx / wcols;
+                        const int i = clo + rofs + idx / wcols;
                         const int ja = (P > 1 ? 0 : seg * 512) + idx % wcols, j = ja - xoff;
-                        if (i >= r_lo && i < r_hi && ja < nch * 8 && j >= H && j < p.cx - H - 1) process_slow(src, fi, i, j, true);
+                        if (i >= r_lo && i < r_hi && ja < nch * 8 && j >= H && j < p.cx - H - 1) process_slow(ssrc, fs, i, j, true);
                         flush();
                     }
                 }
@@ -1103,6 +1121,7 @@ static int launch_fast(const FastParams &p, int pt, const float *d_tab, Record *
     const dim3 g((unsigned)blocks), b(64);
     snprintf(g_last_scan_kernel, sizeof(g_last_scan_kernel), "identify_scan_u16_fast_kernel<%d, %d, %d, %d, %s>%s", H, D, P, pt,
              (P == 1 && p.segs > 1) ? "true" : "false", p.defer ? " defer" : "");
+    if (P > 1 && p.pf) strncat(g_last_scan_kernel, " frames", sizeof(g_last_scan_kernel) - strlen(g_last_scan_kernel) - 1);
     if constexpr (P == 1) {
         if (p.segs > 1) {             // frames wider than a wave: the variant with the edge loads
             if (pt == PT_KEY) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_KEY, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
@@ -1200,6 +1219,29 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     p.rbu = best_rbu;
     p.upf = ((cy + p.rbu * pack - 1) / (p.rbu * pack)) * p.segs;
     p.units = (long long)p.upf * nframes;
+    p.pf = 0;
+    static const bool no_pf = tuning_env("PMI_IDENTIFY_NOPF") != nullptr;
+    if (pack > 1 && !no_pf && force_rbu <= 0 && nframes >= pack && (long long)pack * Y * X * pxb < (1LL << 31)) {
+        // the same rows of `pack` consecutive frames side by side instead of `pack` row ranges of one frame: no halo rows
+        // inside a frame.  Same cost model; taken when it is the cheaper one (short frames: 64 x 64 at box 7 pays 72 pipeline
+        // rows per frame group of eight instead of 16 per frame)
+        const long long groups = (nframes + pack - 1) / pack;
+        int pf_rbu = 0;
+        double pf_cost = 0.0;
+        const int cand_pf[] = {cy, 1024, 512, 256, 128, 64, 32, 16, 8};
+        for (int r : cand_pf) {
+            if (r > cy || r < 1 || (r < 8 && r != cy)) continue;
+            const long long units = (long long)((cy + r - 1) / r) * groups;
+            const double cost = (double)((units + waves - 1) / waves) * (r + 2 * h + 2);
+            if (!pf_rbu || cost < pf_cost) { pf_rbu = r; pf_cost = cost; }
+        }
+        if (pf_cost < best_cost) {
+            p.pf = 1;
+            p.rbu = pf_rbu;
+            p.upf = (cy + pf_rbu - 1) / pf_rbu;
+            p.units = (long long)p.upf * groups;
+        }
+    }
     const long long blocks = std::min<long long>(p.units, waves);
     p.upw = (int)((p.units + blocks - 1) / blocks);
     p.lin_rows = 0; p.lin_total = 0;

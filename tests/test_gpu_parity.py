@@ -323,6 +323,101 @@ def test_identify_narrow_frames_packed_bands(be, orc, shape, box):
     assert all(np.array_equal(p, q) for p, q in zip(a, b))
 
 
+@pytest.mark.parametrize("dtype", [np.uint16, np.uint8, np.int16])
+@pytest.mark.parametrize("shape,box", [((19, 64, 64), 7), ((9, 40, 34), 7), ((32, 64, 64), 7), ((13, 128, 128), 7), ((11, 97, 130), 5),
+                                       ((6, 150, 256), 9), ((21, 64, 64), 5), ((17, 33, 64), 7), ((10, 30, 200), 13), ((4, 64, 64), 7)])
+def test_identify_narrow_short_frames_side_by_side(be, orc, shape, box, dtype):
+    """Round 5: a narrow frame that is also SHORT fills the wavefront with the same rows of 2 / 4 / 8 consecutive frames
+    (identify_fast.hip, FastParams::pf) instead of row ranges of one frame, each of which pays its halo rows — taken when
+    the cost model says so (64 x 64 at box 7: 2.3 -> 4.1 TB/s).  Frame counts that are not a multiple of the lane sets
+    (the last group repeats its last frame and marks nothing), fewer frames than lane sets (the other form), maxima on
+    the first / last allowed rows and columns, ties, a saturated frame in the middle of a group (the rescan path walks
+    the group's frames), crops off the 8-pixel grid, frame bounds that start inside a group; bit-exact against the oracle
+    (picasso/localize.py:97-134, 202-244, 288).  These short movies exercise the dispatch around the new form;
+    test_identify_frames_side_by_side_on_long_movies runs the form itself."""
+    rng = np.random.default_rng(shape[0] * 7919 + shape[1] * 31 + shape[2] + box)
+    F, Y, X = shape
+    h = box // 2
+    top = 250 if dtype == np.uint8 else (30000 if dtype == np.int16 else 60000)
+    mov = (rng.poisson(12, size=shape) + (3 if dtype == np.uint8 else 90)).astype(np.int64)
+    for f in range(F):
+        for _ in range(max(3, Y * X // 700)):
+            y, x = int(rng.integers(1, Y - 1)), int(rng.integers(1, X - 1))
+            amp = int(rng.integers(30, 200)) if dtype == np.uint8 else int(rng.integers(150, 3000))
+            mov[f, max(0, y - 1):y + 2, max(0, x - 1):x + 2] += amp // 3
+            mov[f, y, x] += amp
+        for y in (h, h + 1, Y - h - 2, Y - h - 3):
+            for x in (h, X - h - 2, X // 2):
+                mov[f, y, x] += (60 if dtype == np.uint8 else 2500) + (7 * y + x + 3 * f) % 40
+    mov[:, ::11, ::3] = mov[:, ::11, ::3] // 4 * 4
+    if dtype == np.int16:
+        mov -= 400                                       # negative counts (a baseline set too high)
+    mov = np.clip(mov, np.iinfo(dtype).min, top).astype(dtype)
+    if F > 5:
+        mov[F // 2] = top                                # a saturated frame inside a group of frames
+        mov[F // 2, Y // 2, X // 2] = 1
+    lo_t = 40.0 if dtype == np.uint8 else 400.0
+    for min_ng in (-1e9, lo_t, 30 * lo_t):
+        a = be.identify_arrays(mov, min_ng, box)
+        b = orc.identify(mov, min_ng, box, threads=4)
+        assert len(a[0]) == len(b[0]) and (min_ng > 0 or len(b[0]) > 20), (min_ng, len(a[0]), len(b[0]))
+        assert all(np.array_equal(p, q) for p, q in zip(a, b)), min_ng
+    # which form ran: the library names the kernel instance it launched last (" frames" = frames side by side)
+    import ctypes
+    from picasso_amd import _lib
+    name = ctypes.create_string_buffer(128)
+    _lib.load().pmi_last_scan_kernel(name, 128)
+    # (a few frames: the cost model keeps the row ranges of one frame — its measure is the busiest wavefront, and there are
+    # more wavefronts than frames; the long movies below take the other form)
+    assert b" frames" not in name.value, name.value
+    if X >= 32:
+        for roi in (((0, 3), (Y, X - 1)), ((2, 5), (Y - 3, X - 6)), ((1, 9), (Y - 1, min(X, 9 + 40)))):
+            a = be.identify_arrays(mov, lo_t, box, roi=roi)
+            b = orc.identify(mov, lo_t, box, roi=roi, threads=4)
+            assert all(np.array_equal(p, q) for p, q in zip(a, b)), roi
+    for fb in ((3, F - 2), (1, 1), (F - 1, F - 1)):
+        if fb[0] <= fb[1] < F:
+            a = be.identify_arrays(mov, lo_t, box, frame_bounds=fb)
+            b = orc.identify(mov, lo_t, box, frame_bounds=fb, threads=4)
+            assert all(np.array_equal(p, q) for p, q in zip(a, b)), fb
+
+
+@pytest.mark.parametrize("shape,box,dtype", [((40003, 64, 64), 7, np.uint16), ((33001, 40, 50), 7, np.uint8), ((41003, 36, 100), 7, np.int16),
+                                             ((40001, 30, 120), 5, np.uint16), ((24001, 40, 250), 9, np.uint16)])
+def test_identify_frames_side_by_side_on_long_movies(be, orc, shape, box, dtype):
+    """The frames-side-by-side form of the packed scan on movies long enough for the cost model to take it (more groups
+    of frames than persistent wavefronts): 8 / 4 / 2 lane sets, a last group that is not full, every pixel type of the
+    packed scan, a saturated frame inside a group, frame bounds and a crop; the kernel instance that ran is asserted, the
+    identifications are the oracle's bit for bit."""
+    import ctypes
+    from picasso_amd import _lib
+    rng = np.random.default_rng(shape[0] + box)
+    F, Y, X = shape
+    top = 250 if dtype == np.uint8 else (30000 if dtype == np.int16 else 60000)
+    mov = (rng.poisson(10, size=shape) + (3 if dtype == np.uint8 else 90)).astype(np.int32)
+    n_spots = F * max(1, Y * X // 2000)
+    ff, yy, xx = rng.integers(0, F, n_spots), rng.integers(1, Y - 1, n_spots), rng.integers(1, X - 1, n_spots)
+    amp = rng.integers(40, 200, n_spots) if dtype == np.uint8 else rng.integers(300, 4000, n_spots)
+    np.add.at(mov, (ff, yy, xx), amp)
+    np.add.at(mov, (ff, yy - 1, xx), amp // 3)
+    np.add.at(mov, (ff, yy, xx + 1), amp // 3)
+    if dtype == np.int16:
+        mov -= 300
+    mov = np.clip(mov, np.iinfo(dtype).min, top).astype(dtype)
+    mov[F // 3] = top
+    mov[F // 3, Y // 2, X // 2] = 1
+    lo_t = 60.0 if dtype == np.uint8 else 800.0
+    name = ctypes.create_string_buffer(128)
+    for kw in ({}, {"frame_bounds": (5, F - 4)}, {"roi": ((1, 3), (Y - 2, X - 5))}):
+        for min_ng in ((lo_t, 25 * lo_t) if not kw else (lo_t,)):
+            a = be.identify_arrays(mov, min_ng, box, **kw)
+            _lib.load().pmi_last_scan_kernel(name, 128)
+            assert name.value.decode().endswith(" frames"), (kw, name.value)
+            b = orc.identify(mov, min_ng, box, threads=orc.max_threads(), **kw)
+            assert len(a[0]) == len(b[0]) and (min_ng > lo_t or len(b[0]) > F // 4), (kw, min_ng, len(a[0]), len(b[0]))
+            assert all(np.array_equal(p, q) for p, q in zip(a, b)), (kw, min_ng)
+
+
 def test_identify_fast_path_all_zero_and_all_saturated(be, orc):
     for val in (0, 65535, 777):
         mov = np.full((2, 80, 256), val, np.uint16)

@@ -72,7 +72,9 @@ __device__ __forceinline__ u32 pk_sub_sat(u32 a, u32 b)
 // (float32 / 32-bit integer movies compare as float32 in the reference, picasso/localize.py:332: generic kernel.)
 //   PT_KEY  float32 movies with any content: the scan works on 16-bit KEYS — the upper half of the order-preserving integer
 //           image of a float32 (key_of_float below: monotone, so every first maximum of the pixels is a maximum of the keys) —
-//           made by narrow_to_key_kernel (identify.hip); everything that is decided exactly — the first-argmax rule, the
+//           built in registers from the float32 rows as they are loaded (round 5: two 16-byte loads per lane and row, three
+//           integer operations per pixel, one v_perm per pair; round 4 scanned a 16-bit copy made by a kernel of its own:
+//           8 bytes moved per pixel instead of 4); everything that is decided exactly — the first-argmax rule, the
 //           net gradient, the threshold — reads the float32 pixels.  Equal keys do not mean equal pixels, so the neighbour
 //           rule that drops the right-hand / lower one of two equal candidates does not apply; the floor is computed from
 //           the lower edges of the keys' buckets and turned back into a key (conservative on both sides).
@@ -89,6 +91,13 @@ __device__ __forceinline__ float key_lower_edge(unsigned k)
 }
 template <int PT> struct Px { typedef uint16_t T; };
 template <> struct Px<PT_U8> { typedef uint8_t T; };
+template <> struct Px<PT_KEY> { typedef float T; };
+// the keys of two float32 pixels as one packed pair (low half: the first)
+__device__ __forceinline__ uint32_t key_pair(uint32_t a, uint32_t b)
+{
+    const uint32_t ka = a ^ ((uint32_t)((int32_t)a >> 31) | 0x80000000u), kb = b ^ ((uint32_t)((int32_t)b >> 31) | 0x80000000u);
+    return __builtin_amdgcn_perm(kb, ka, 0x07060302u);
+}
 template <int PT> __device__ __forceinline__ float px_float(typename Px<PT>::T raw)
 {
     if constexpr (PT == PT_I16) return (float)(int16_t)raw;
@@ -758,6 +767,11 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                     const u32x2_t m = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)soff, 0);
                     ro.m = make_uint4(__builtin_amdgcn_perm(0u, m.x, 0x0c010c00u), __builtin_amdgcn_perm(0u, m.x, 0x0c030c02u),
                                       __builtin_amdgcn_perm(0u, m.y, 0x0c010c00u), __builtin_amdgcn_perm(0u, m.y, 0x0c030c02u));
+                } else if constexpr (PT == PT_KEY) {
+                    // 8 float32 pixels = 32 bytes -> four packed pairs of keys
+                    const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
+                    const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + 16u), (int)soff, 0);
+                    ro.m = make_uint4(key_pair(a.x, a.y), key_pair(a.z, a.w), key_pair(b.x, b.y), key_pair(b.z, b.w));
                 } else {
                     const u32x4_t m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
                     ro.m = make_uint4(m.x, m.y, m.z, m.w);
@@ -775,6 +789,13 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                         } else {
                             const unsigned e = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off_e, (int)soff, 0);
                             ro.e.x = __builtin_amdgcn_perm(0u, e, 0x0c010c00u); ro.e.y = __builtin_amdgcn_perm(0u, e, 0x0c030c02u);
+                        }
+                    } else if constexpr (PT == PT_KEY) {
+                        const u32x4_t e = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_e, (int)soff, 0);
+                        ro.e.x = key_pair(e.x, e.y); ro.e.y = key_pair(e.z, e.w);
+                        if constexpr (WIDE) {
+                            const u32x4_t f = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off_e + 16u), (int)soff, 0);
+                            ro.e.z = key_pair(f.x, f.y); ro.e.w = key_pair(f.z, f.w);
                         }
                     } else if constexpr (WIDE) {
                         const u32x4_t e = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_e, (int)soff, 0);
@@ -1177,9 +1198,11 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     if (!unit_vectors_match()) return PMI_OK;          // never expected; the generic kernel uses the runtime table
     // uint16, uint8 and int16 movies (see Px); rows need no alignment beyond the pixel's own: gfx950 runs buffer and
     // global loads in unaligned mode, so odd widths only cost the loads that straddle a 64-byte boundary
-    const int pt = fmovie ? (dtype == PMI_U16 ? PT_KEY : -1) : (dtype == PMI_U16 ? PT_U16 : (dtype == PMI_U8 ? PT_U8 : (dtype == PMI_I16 ? PT_I16 : -1)));
+    // (fmovie: a float32 movie — d_movie and fmovie are the same frames — scanned through keys built in registers)
+    const int pt = fmovie ? (dtype == PMI_F32 && (const void *)fmovie == d_movie ? PT_KEY : -1)
+                          : (dtype == PMI_U16 ? PT_U16 : (dtype == PMI_U8 ? PT_U8 : (dtype == PMI_I16 ? PT_I16 : -1)));
     if (pt < 0) return PMI_OK;
-    const int pxb = pt == PT_U8 ? 1 : 2;
+    const int pxb = pt == PT_U8 ? 1 : (pt == PT_KEY ? 4 : 2);
     if (cx < 16 || ((uintptr_t)d_movie & (uintptr_t)(pxb - 1))) return PMI_OK;
     if (cy > 65535 || cx > 65520 || X > 65535 || Y * X * pxb >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets, 16-bit list columns
     const int g_fast_cus = device_cu_count();

@@ -72,6 +72,10 @@ enum pmi_mle_method { PMI_MLE_SIGMA = 0, PMI_MLE_SIGMAXY = 1 };
 int         pmi_version(void);
 const char *pmi_last_error(void);            /* gpufit_get_last_error analogue  */
 int         pmi_device_count(void);          /* gpufit_cuda_available analogue: 0 = no GPU */
+/* The device of the CALLING THREAD (HIP keeps it per thread).  Everything the library keeps on a device — scratch banks,
+ * unit-vector tables, FFT plans, side streams, the statistics of the last fit — is keyed by the device current in the thread
+ * that calls in, so one process may drive several GPUs from one host thread each (at most 16 devices).  A device that does
+ * not exist is refused (PMI_ERR_ARG) and the thread stays where it was.                                       */
 int         pmi_set_device(int device);
 int         pmi_get_device(int *device);     /* the calling thread's current device */
 int         pmi_device_info(char *name, size_t name_len, int *compute_units,

@@ -129,7 +129,7 @@ void release_fft_plans();   // xcorr.hip
 
 extern "C" {
 
-int pmi_version(void) { return 103; }   // 0.1.3: round 4 (pmi_gausslq_set_mode, pmi_localize_set_defer, pmi_get_device)
+int pmi_version(void) { return 104; }   // 0.1.4: round 5 (state keyed by device, pmi_comm_library_path, an eighth reason in pmi_gausslq_last_tie_reasons)
 
 const char *pmi_last_error(void) { return pmi::g_err; }
 

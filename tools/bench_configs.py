@@ -26,6 +26,7 @@ def main():
     ap.add_argument("--only", type=int, default=0, help="3 or 5: just that config")
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--cpu-seconds", type=float, default=8.0)
+    ap.add_argument("--handoff", type=int, default=0, choices=(0, 1), help="A/B: 1 lets the scan's exact stage leave the box rows for the fit (pmi_localize_set_handoff)")
     ap.add_argument("--no-lq3d", action="store_true", help="config 5: skip the least-squares twin of the route")
     ap.add_argument("--defer", type=int, default=1, choices=(0, 1), help="A/B: 0 keeps identify's exact stage in the scan (pmi_localize_set_defer)")
     args = ap.parse_args()
@@ -35,6 +36,7 @@ def main():
     L = _lib.load()
     _lib.require_gpu()
     _lib.check(L.pmi_localize_set_defer(args.defer), "pmi_localize_set_defer")
+    _lib.check(L.pmi_localize_set_handoff(args.handoff), "pmi_localize_set_handoff")
     F, H, W = args.frames, 512, 512
     cam = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
     threads = min(16, len(os.sched_getaffinity(0)))

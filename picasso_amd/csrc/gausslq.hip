@@ -479,7 +479,7 @@ __global__ __launch_bounds__(256) void lq_init_kernel(Params p, LqState st, int6
     const bool staged = m <= LQ_TILE_MAXPIX;
     s_idx[threadIdx.x] = mine ? s : -1;
     __syncthreads();
-    if (staged) { stage_spots<FROM_MOVIE, 256>(p, s_idx, s_tile, m, size); __syncthreads(); }
+    if (staged) { stage_spots<FROM_MOVIE, 256>(p, s_idx, s_tile, m, size, FROM_MOVIE ? 0 : st.first); __syncthreads(); }
     if (!mine) return;
     int64_t fr = 0, y0 = 0, x0 = 0;
     if (FROM_MOVIE) { fr = p.frame[s]; y0 = p.y[s] - hsz; x0 = p.x[s] - hsz; }
@@ -582,7 +582,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_finish_kerne
         __syncthreads();
         s_idx[tid] = info > 0 ? -1 : s_mine;
         __syncthreads();
-        if (staged) { stage_spots<FROM_MOVIE, LQ_STEP_NT>(p, s_idx, s_tile, m, size); __syncthreads(); }
+        if (staged) { stage_spots<FROM_MOVIE, LQ_STEP_NT>(p, s_idx, s_tile, m, size, st.first); __syncthreads(); }
         const float *mytile = s_tile + (size_t)tid * m;
         bool running = info <= 0;
         for (;;) {

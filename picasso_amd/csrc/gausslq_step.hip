@@ -39,7 +39,7 @@ __global__ __launch_bounds__(LQ_STEP_NT, LQ_STEP_MIN_WAVES) void lq_step_kernel(
         __syncthreads();                                        // the previous block's tile is no longer read
         s_idx[tid] = info > 0 ? -1 : s;
         __syncthreads();
-        if (staged) { stage_spots<FROM_MOVIE, LQ_STEP_NT>(p, s_idx, s_tile, m, size); __syncthreads(); }
+        if (staged) { stage_spots<FROM_MOVIE, LQ_STEP_NT, BOX * BOX>(p, s_idx, s_tile, m, size, st.first); __syncthreads(); }
         if (info > 0) continue;
         unsigned tie = 0u;
         info = lq_step_spot<FROM_MOVIE, FLAG, FRAG, CR, BOX>(p, st, s, info, tie_list != nullptr, mytile, s_px, tid, staged, tie);

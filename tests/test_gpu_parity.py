@@ -680,6 +680,41 @@ def test_gausslq_strict_mode_where_one_exp_decides_a_float32_rounding(be, orc):
         _lq_assert_identical(th, info, nfev, oth, oinfo, onfev)
 
 
+@pytest.mark.parametrize("box", [3, 5, 7, 9, 13, 17, 21])
+def test_gausslq_strict_mode_on_extreme_pixels_among_ordinary_spots(be, orc, box):
+    """Every third spot is one lmdif was not written for — pixels scaled to 1e-38 ... 3e33, a NaN or an infinity, flat,
+    empty, negative, one bright pixel / row / column, pure noise — and sits in a lane group with ordinary neighbours: the
+    range guards of the column-per-lane Jacobian (csrc/lq_jacobian_w.inc: columns outside (2^-64, 2^54) take the scaled
+    norm, non-finite or degenerate ones the second pass) leave theta, info and nfev of ALL spots the oracle's."""
+    n = 1536
+    spots = _lq_adversarial_spots(box, n, 77 + box)
+    rng = np.random.default_rng(box)
+    c = box // 2
+    for i in range(0, n, 3):
+        k = (i // 3) % 16
+        if k == 0: spots[i] *= np.float32(1e-30)
+        elif k == 1: spots[i] *= np.float32(1e25)
+        elif k == 2: spots[i, rng.integers(box), rng.integers(box)] = np.nan
+        elif k == 3: spots[i, rng.integers(box), rng.integers(box)] = np.inf
+        elif k == 4: spots[i] = 0
+        elif k == 5: spots[i] = 7.0
+        elif k == 6: spots[i] = 0; spots[i, c, c] = 1000.0
+        elif k == 7: spots[i] = -spots[i]
+        elif k == 8: spots[i] *= np.float32(1e-38)
+        elif k == 9: spots[i] *= np.float32(3e33)
+        elif k == 10: spots[i, 0, 0] = 1e30
+        elif k == 11: spots[i] = 0; spots[i, 0, :] = 500.0
+        elif k == 12: spots[i] = 0; spots[i, :, -1] = 500.0
+        elif k == 13: spots[i] = rng.normal(0, 1, (box, box)).astype(np.float32)
+        elif k == 14: spots[i, rng.integers(box), rng.integers(box)] = -np.inf
+        elif k == 15: spots[i] *= np.float32(1e-20)
+    with np.errstate(all="ignore"):
+        th, info, nfev = be.gausslq_arrays(spots, full_output=True)
+        oth, oinfo, onfev = orc.gausslq(spots, full=True, threads=4)
+    _lq_assert_identical(th, info, nfev, oth, oinfo, onfev)
+    assert be.last_lq_refit_count() < n // 3          # the ordinary spots were fitted once
+
+
 @pytest.mark.parametrize("box", [3, 7, 13])
 def test_gausslq_refit_mode_tree_sums_and_a_second_fit_of_the_flagged(be, orc, box):
     """The faster mode (pmi_gausslq_set_mode(refit)): tree sums over the rows, every spot with a decision of lmdif within

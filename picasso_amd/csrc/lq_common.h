@@ -583,7 +583,7 @@ __device__ __forceinline__ int lq_step_spot(const Params &p, const LqState &st, 
         iter = LQI(st, 6, ls); nfev = LQI(st, 7, ls);
     }
 #pragma unroll
-    for (int k = 0; k < 36; k++) R[k] = LQD(st, 16 + k, ls);
+    for (int k = 0; k < 36; k++) R[k] = (k / 6 <= k % 6) ? LQD(st, 16 + k, ls) : 0.0;       // (below the diagonal: qrsolv's workspace, never read before it is written — not stored)
 #pragma unroll
     for (int j = 0; j < 6; j++) { qtf[j] = LQD(st, 52 + j, ls); wa2[j] = LQD(st, 58 + j, ls); ipvt[j] = LQI(st, j, ls); }
     nfev += 6;                                                 // the forward differences of this round

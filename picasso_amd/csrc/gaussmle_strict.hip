@@ -28,6 +28,8 @@
 // wavefront) for boxes <= 7 / <= 15 / larger, for the flagged-spot list and for PMI_MLE_STRICT
 // alike: the kernel is bound by instruction issue, and the list's launch by its longest fits
 // (launch_fit_strict: 64-lane groups for the list were measured slower, 0.45 against 0.30 ms).
+// PMI_MLE_STRICT (the whole batch) runs mle_strict_start_kernel (start values, the groups side by side) and then the Newton
+// loop with every group taking its next spot as soon as its fit has ended (REFILL); a list keeps its groups in lockstep.
 #include <algorithm>
 #include <cstdlib>
 
@@ -70,8 +72,121 @@ template <int GS> struct SLds {
 }  // namespace
 
 // list: spot indices to fit (entries [0, *list_n)), or nullptr = every spot of [p.first, min(p.N, *p.d_n)).
+// ---- the spot, in photons (localize.py:917-931, 1101-1112), into the group's LDS ----
+template <int GS, bool FROM_MOVIE>
+__device__ __forceinline__ void strict_load_spot(const FitParams &p, int64_t sidx, bool have, int j, float *spot)
+{
+    const int B = p.box, npix = B * B, H = B / 2;
+    for (int q = j; q < npix; q += GS) {
+        float v = 0.f;
+        if (have) {
+            if (FROM_MOVIE) {
+                const int a = q / B, c = q - a * B;
+                const int64_t fr = p.frame[sidx], yy = p.y[sidx], xx = p.x[sidx];
+                const float raw = load_movie_px(p.movie, p.dtype, (fr * p.Y + (yy - H + a)) * p.X + (xx - H + c));
+                v = div_const((raw - p.baseline) * p.sensitivity, p.gdiv);
+            } else {
+                v = p.spots[sidx * npix + q];
+            }
+        }
+        spot[q] = v;
+    }
+    lds_sync();
+}
+
+// ---- initial parameters (gaussmle.py:28-168) of the spot in the group's LDS; fscr: GS floats of the group ----
+template <int NP, int GS>
+__device__ __forceinline__ void strict_start_values(int B, int j, const float *spot, float *fscr, float (&th)[6])
+{
+    const int npix = B * B, H = B / 2;
+    // 3x3 edge-clipped mean filter, float64 sum in (m, n) order, float32 store (:61-91); its minimum (:135)
+    float best = INFINITY;
+    for (int q = j; q < npix; q += GS) {
+        const int k = q / B, l = q - k * B;
+        const int m0 = k - 1 > 0 ? k - 1 : 0, m1 = k + 2 < B ? k + 2 : B;
+        const int n0 = l - 1 > 0 ? l - 1 : 0, n1 = l + 2 < B ? l + 2 : B;
+        double nsum = 0.0;
+        for (int m = m0; m < m1; m++)
+            for (int c = n0; c < n1; c++) nsum += (double)spot[m * B + c];
+        const float f = (float)(nsum / (double)((m1 - m0) * (n1 - n0)));
+        best = (best != best) ? best : ((f != f) ? f : (f < best ? f : best));        // np.min: NaN propagates
+    }
+    fscr[j] = best;
+    lds_sync();
+    float bg0 = INFINITY;
+    for (int r = 0; r < GS; r++) {
+        const float f = fscr[r];
+        bg0 = (bg0 != bg0) ? bg0 : ((f != f) ? f : (f < bg0 ? f : bg0));
+    }
+    // sum and centre of mass, sequential float64 like the reference (:28-48); every lane does the same
+    double s_ = 0.0, sy_ = 0.0, sx_ = 0.0;
+    for (int a = 0; a < B; a++)
+        for (int c = 0; c < B; c++) {
+            const double v = (double)spot[a * B + c];
+            sy_ += v * (double)a;
+            sx_ += v * (double)c;
+            s_ += v;
+        }
+    double com_y, com_x;
+    if (s_ <= 0.0) { s_ = 0.01; com_y = (B - 1) / 2.0; com_x = (B - 1) / 2.0; }
+    else { com_y = sy_ / s_; com_x = sx_ / s_; }
+    const double photons0 = np_max_d(1.0, s_ - (double)(B * B) * (double)bg0);
+    double sdy = 0.0, sdx = 0.0, sum_y = 0.0, sum_x = 0.0;
+    for (int a = 0; a < B; a++) {
+        const double d2 = (double)((a - H) * (a - H));
+        const float vy = spot[a * B + H] - bg0;        // spot - bg is a float32 array (:105)
+        const float vx = spot[H * B + a] - bg0;
+        sdy += (double)vy * d2;
+        sdx += (double)vx * d2;
+        sum_y += (double)vy;
+        sum_x += (double)vx;
+    }
+    double isy = sqrt(sdy / sum_y), isx = sqrt(sdx / sum_x);
+    if (!isfinite(isy)) isy = 0.01;
+    if (!isfinite(isx)) isx = 0.01;
+    if (isx == 0) isx = 0.01;
+    if (isy == 0) isy = 0.01;
+
+    th[0] = (float)com_x; th[1] = (float)com_y; th[2] = (float)photons0; th[3] = bg0;
+    if (NP == 6) { th[4] = (float)isx; th[5] = (float)isy; }
+    else { th[4] = (float)((isx + isy) / 2); th[5] = 0.f; }                  // float64 mean, float32 store (:153)
+    lds_sync();             // (fscr may be written again)
+}
+
+// The start values of every spot of the batch, NSPW spots per wavefront side by side, into p.thetas (slot 5 of the `sigma`
+// method: a copy of slot 4, as in the fitted rows) — for mle_strict_kernel<.., REFILL = true>.
 template <int NP, int GS, bool FROM_MOVIE>
-__global__ __launch_bounds__(FIT_NT) void mle_strict_kernel(FitParams p, const int32_t *__restrict__ list,
+__global__ __launch_bounds__(FIT_NT) void mle_strict_start_kernel(FitParams p)
+{
+    constexpr int NSPW = 64 / GS;
+    __shared__ __attribute__((aligned(16))) float s_spot[FIT_WAVES][NSPW][PMI_MAX_BOX * PMI_MAX_BOX + GS];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int g = lane / GS, j = lane & (GS - 1);
+    float *spot = &s_spot[wid][g][0];
+    float *fscr = spot + PMI_MAX_BOX * PMI_MAX_BOX;
+    int64_t n = p.N;
+    if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
+    const int64_t items = n - p.first;
+    const int64_t total_groups = (int64_t)gridDim.x * FIT_WAVES * NSPW;
+    for (int64_t w0 = ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW; w0 < items; w0 += total_groups) {
+        const int64_t w = w0 + g;
+        const bool have = w < items;
+        const int64_t sidx = p.first + (have ? w : 0);
+        strict_load_spot<GS, FROM_MOVIE>(p, sidx, have, j, spot);
+        float th[6];
+        strict_start_values<NP, GS>(p.box, j, spot, fscr, th);
+        if (have && j == 0) {
+            float *to = p.thetas + sidx * 6;
+#pragma unroll
+            for (int l = 0; l < 5; l++) to[l] = th[l];
+            to[5] = NP == 6 ? th[5] : th[4];
+        }
+        lds_sync();
+    }
+}
+
+template <int NP, int GS, bool FROM_MOVIE, bool REFILL>
+__global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, const int32_t *__restrict__ list,
                                                             const unsigned *__restrict__ list_n)
 {
     constexpr int NSPW = 64 / GS;
@@ -85,125 +200,110 @@ __global__ __launch_bounds__(FIT_NT) void mle_strict_kernel(FitParams p, const i
     double *term = reinterpret_cast<double *>(mem + SLds<GS>::SPOT + SLds<GS>::BND + SLds<GS>::COL);
     float *accs = reinterpret_cast<float *>(mem + SLds<GS>::SPOT + SLds<GS>::BND + SLds<GS>::COL + SLds<GS>::TERM);
 
-    const int B = p.box, npix = B * B, H = B / 2;
+    const int B = p.box, npix = B * B;
     int64_t n = p.N;
     if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
     int64_t items = list ? (int64_t)*list_n : n - p.first;
     if (list && items > n - p.first) items = n - p.first;
-    const int64_t total_groups = (int64_t)gridDim.x * FIT_WAVES * NSPW;
-    const int64_t group0 = ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW + g;
-
-    // A list (the flagged spots) holds fits of 10 and of 100 iterations: dealt round robin, the groups with one entry more
+    // REFILL (the whole batch, PMI_MLE_STRICT): every group of GS lanes works through spots of its own — when its fit has
+    // converged it stores the result and takes the next spot while the other groups of the wavefront go on iterating (the
+    // instruction stream of an iteration costs the same with one group active as with four: groups in lockstep ran
+    // max-of-four iterations per spot, 1.5x the mean on config 2: 13.1 -> 10.9 ms).  A workgroup owns a contiguous share of
+    // the batch and its groups take the spots of the share one at a time from a counter in LDS.
+    // !REFILL (a list of flagged spots): the wavefront takes NSPW new entries when the LAST of its fits has ended.  The flagged
+    // fits are long and alike, and a refill runs the start values for one group with the others masked — measured on one box:
+    // config 2 2.74 (lockstep) against 2.81 ms, eps 1e-4 6.17 against 6.30, config 5 24.6 against 24.8.
+    // A list holds fits of 10 and of 100 iterations: dealt round robin, the groups with one entry more
     // than the others, or with two long fits, end the launch long after the rest (13x13, 26 000 entries over 6 144 groups:
     // 2.9 ms).  So only the first round is dealt; after it a wavefront takes its next NSPW entries from a queue word when
     // it is done with the last.  (Every wavefront asking the queue at its START was measured slower on short lists — 7 346
     // entries, config 2: 142 instead of 94 us — 3 072 atomics on one word from eight XCDs complete one after the other.)
-    unsigned *qw = list ? p.strict_queue : nullptr;
     // ... and takes several rounds' worth of entries per visit when the list is long: the queue is ONE word, and the atomics
     // of three thousand wavefronts on it complete one after the other (~0.1 us each) — at eps 1e-4 config 2's list is
     // 113 000 entries = 28 000 visits of four, 2.8 of the launch's 3.4 ms; config 5's two lists of 26 000 13x13 spots paid
     // 1 ms each.  Up to eight rounds per visit, never more than half of what a wavefront's fair share would be.
+    __shared__ unsigned s_next;
+    if (threadIdx.x == 0) s_next = 0u;
+    __syncthreads();
+    const int64_t blk_lo = items * (int64_t)blockIdx.x / (int64_t)gridDim.x;
+    const int64_t blk_hi = items * ((int64_t)blockIdx.x + 1) / (int64_t)gridDim.x;
+    const int64_t total_groups = (int64_t)gridDim.x * FIT_WAVES * NSPW;
+    unsigned *qw = list ? p.strict_queue : nullptr;
     const int64_t fair = items / (2 * total_groups);
     const unsigned chunk = (unsigned)NSPW * (unsigned)(fair < 1 ? 1 : (fair > 8 ? 8 : fair));
-    int64_t w0 = group0 - g;                                             // wave-uniform
-    int64_t w_lim = w0 + NSPW;                                           // end of the entries this wavefront holds
-    for (;; w0 += NSPW) {
-        if (w0 >= w_lim) {
-            if (qw) {
-                unsigned t = 0;
-                if (lane == 0) t = atomicAdd(qw, chunk);
-                w0 = total_groups + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
-                w_lim = w0 + chunk;
-            } else {
-                w0 += total_groups - NSPW;
-                w_lim = w0 + NSPW;
-            }
-        }
-        if (w0 >= items) break;
-        const int64_t w = w0 + g;
-        const bool have = w < items;
-        const int64_t sidx = have ? (list ? (int64_t)list[w] : p.first + w) : 0;
+    int64_t w0 = ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW - NSPW;  // wave-uniform: the entries before the first round's
+    int64_t w_lim = w0 + 2 * NSPW;                                       // end of the entries this wavefront holds
 
-        // ---- the spot, in photons (localize.py:917-931, 1101-1112) --------------------
-        for (int q = j; q < npix; q += GS) {
-            float v = 0.f;
-            if (have) {
-                if (FROM_MOVIE) {
-                    const int a = q / B, c = q - a * B;
-                    const int64_t fr = p.frame[sidx], yy = p.y[sidx], xx = p.x[sidx];
-                    const float raw = load_movie_px(p.movie, p.dtype, (fr * p.Y + (yy - H + a)) * p.X + (xx - H + c));
-                    v = div_const((raw - p.baseline) * p.sensitivity, p.gdiv);
+    const int nb = B + 1;
+    const int j0_ii = j / B, j0_jj = j - j0_ii * B, gs_ii = GS / B, gs_jj = GS - gs_ii * B;
+    bool have = false, active = false, exhausted = false;
+    int64_t sidx = 0;
+    int kk = 0;
+    float th[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, ms[6] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    auto store_fit = [&]() {
+        if (j == 0) {
+            float *to = p.thetas + sidx * 6;
+#pragma unroll
+            for (int l = 0; l < 5; l++) to[l] = th[l];
+            to[5] = NP == 6 ? th[5] : th[4];
+            p.iterations[sidx] = kk;
+            if (p.refit_mark) p.refit_mark[sidx - p.first] = 1;
+        }
+    };
+    for (;;) {
+        // ---- groups without a running fit take entries until one has iterations to do (max_it <= 0: none has) ----
+        while ((REFILL ? !active : !__any(active)) && !exhausted) {
+        int64_t w;
+        if (REFILL) {
+            unsigned tk = 0u;
+            if (j == 0) tk = atomicAdd(&s_next, 1u);
+            tk = (unsigned)__shfl((int)tk, lane & ~(GS - 1));
+            w = blk_lo + (int64_t)tk;
+            have = w < blk_hi;
+            if (!have) { exhausted = true; break; }
+        } else {
+            w0 += NSPW;
+            if (w0 >= w_lim) {
+                if (qw) {
+                    unsigned t = 0;
+                    if (lane == 0) t = atomicAdd(qw, chunk);
+                    w0 = total_groups + (int64_t)(unsigned)__builtin_amdgcn_readfirstlane((int)t);
+                    w_lim = w0 + chunk;
                 } else {
-                    v = p.spots[sidx * npix + q];
+                    w0 += total_groups - NSPW;
+                    w_lim = w0 + NSPW;
                 }
             }
-            spot[q] = v;
+            if (w0 >= items) { exhausted = true; break; }
+            w = w0 + g;
+            have = w < items;
         }
-        lds_sync();
+        if (have) {
+        sidx = list ? (int64_t)list[w] : p.first + w;
 
-        // ---- initial parameters (gaussmle.py:28-168) -----------------------------------
-        // 3x3 edge-clipped mean filter, float64 sum in (m, n) order, float32 store (:61-91); its minimum (:135)
-        float best = INFINITY;
-        for (int q = j; q < npix; q += GS) {
-            const int k = q / B, l = q - k * B;
-            const int m0 = k - 1 > 0 ? k - 1 : 0, m1 = k + 2 < B ? k + 2 : B;
-            const int n0 = l - 1 > 0 ? l - 1 : 0, n1 = l + 2 < B ? l + 2 : B;
-            double nsum = 0.0;
-            for (int m = m0; m < m1; m++)
-                for (int c = n0; c < n1; c++) nsum += (double)spot[m * B + c];
-            const float f = (float)(nsum / (double)((m1 - m0) * (n1 - n0)));
-            best = (best != best) ? best : ((f != f) ? f : (f < best ? f : best));        // np.min: NaN propagates
+        strict_load_spot<GS, FROM_MOVIE>(p, sidx, true, j, spot);
+        if (REFILL) {
+            // (the start values of the batch were computed by mle_strict_start_kernel, four spots per wavefront side by side:
+            // here they would run for this group alone with the rest of the wavefront masked)
+            const float *from = p.thetas + sidx * 6;
+#pragma unroll
+            for (int l = 0; l < 5; l++) th[l] = from[l];
+            th[5] = NP == 6 ? from[5] : 0.f;
+        } else {
+            strict_start_values<NP, GS>(p.box, j, spot, reinterpret_cast<float *>(term), th);
         }
-        float *fscr = reinterpret_cast<float *>(term);
-        fscr[j] = best;
-        lds_sync();
-        float bg0 = INFINITY;
-        for (int r = 0; r < GS; r++) {
-            const float f = fscr[r];
-            bg0 = (bg0 != bg0) ? bg0 : ((f != f) ? f : (f < bg0 ? f : bg0));
-        }
-        // sum and centre of mass, sequential float64 like the reference (:28-48); every lane does the same
-        double s_ = 0.0, sy_ = 0.0, sx_ = 0.0;
-        for (int a = 0; a < B; a++)
-            for (int c = 0; c < B; c++) {
-                const double v = (double)spot[a * B + c];
-                sy_ += v * (double)a;
-                sx_ += v * (double)c;
-                s_ += v;
-            }
-        double com_y, com_x;
-        if (s_ <= 0.0) { s_ = 0.01; com_y = (B - 1) / 2.0; com_x = (B - 1) / 2.0; }
-        else { com_y = sy_ / s_; com_x = sx_ / s_; }
-        const double photons0 = np_max_d(1.0, s_ - (double)(B * B) * (double)bg0);
-        double sdy = 0.0, sdx = 0.0, sum_y = 0.0, sum_x = 0.0;
-        for (int a = 0; a < B; a++) {
-            const double d2 = (double)((a - H) * (a - H));
-            const float vy = spot[a * B + H] - bg0;        // spot - bg is a float32 array (:105)
-            const float vx = spot[H * B + a] - bg0;
-            sdy += (double)vy * d2;
-            sdx += (double)vx * d2;
-            sum_y += (double)vy;
-            sum_x += (double)vx;
-        }
-        double isy = sqrt(sdy / sum_y), isx = sqrt(sdx / sum_x);
-        if (!isfinite(isy)) isy = 0.01;
-        if (!isfinite(isx)) isx = 0.01;
-        if (isx == 0) isx = 0.01;
-        if (isy == 0) isy = 0.01;
-
-        float th[6], ms[6];
-        th[0] = (float)com_x; th[1] = (float)com_y; th[2] = (float)photons0; th[3] = bg0;
-        if (NP == 6) { th[4] = (float)isx; th[5] = (float)isy; }
-        else { th[4] = (float)((isx + isy) / 2); th[5] = 0.f; }                  // float64 mean, float32 store (:153)
         ms[0] = th[4]; ms[1] = th[4];
         ms[2] = (float)(0.1 * (double)th[2]); ms[3] = (float)(0.1 * (double)th[3]);
         ms[4] = (float)(0.2 * (double)th[4]); ms[5] = (float)(0.2 * (double)th[5]);
 
-        // ---- Newton iterations (:533-670 sigma, :745-884 sigmaxy) -----------------------
-        int kk = 0;
-        bool active = have && p.max_it > 0;
-        const int nb = B + 1;
-        while (__any(active)) {
+        kk = 0;
+        active = p.max_it > 0;
+        if (!active) store_fit();
+        }
+        }
+        if (!__any(active)) break;
+        // ---- one Newton iteration of every group with a running fit (:533-670 sigma, :745-884 sigmaxy) -----------------
+        {
             const float sgy = NP == 6 ? th[5] : th[4];
             // phase A: lane -> (axis, boundary k)
             if (j < 2 * nb) {
@@ -270,10 +370,11 @@ __global__ __launch_bounds__(FIT_NT) void mle_strict_kernel(FitParams p, const i
             const float sgx = th[4];
             const double cx = K_SQRT_2PI * (double)sgx, cy = K_SQRT_2PI * (double)sgy;
             const double c3x = K_SQRT_2PI * (double)(sgx * (sgx * sgx)), c3y = K_SQRT_2PI * (double)(sgy * (sgy * sgy));
-            for (int r0 = 0; r0 < npix; r0 += GS) {
+            int ii = j0_ii, jj = j0_jj;                    // (ii, jj) of pixel r0 + j of the sequence, stepped without a division
+            for (int r0 = 0; r0 < npix; r0 += GS, ii += gs_ii, jj += gs_jj) {
                 const int seq = r0 + j;
+                if (jj >= B) { jj -= B; ii++; }
                 if (seq < npix) {
-                    const int ii = seq / B, jj = seq - ii * B;
                     const double *X = col + ii * 5, *Yc = col + (B + jj) * 5;
                     const double PSFx = X[0], PSFy = Yc[0];
                     float du[6], d2[6];
@@ -357,17 +458,9 @@ __global__ __launch_bounds__(FIT_NT) void mle_strict_kernel(FitParams p, const i
                 kk++;
                 if (conv || kk >= p.max_it) active = false;
             }
+            if (have && !active) { store_fit(); have = false; }
             lds_sync();
         }
-        if (have && j == 0) {
-            float *to = p.thetas + sidx * 6;
-#pragma unroll
-            for (int l = 0; l < 5; l++) to[l] = th[l];
-            to[5] = NP == 6 ? th[5] : th[4];
-            p.iterations[sidx] = kk;
-            if (p.refit_mark) p.refit_mark[sidx - p.first] = 1;
-        }
-        lds_sync();
     }
 }
 
@@ -379,8 +472,19 @@ static void launch_strict_gs(const FitParams &p, bool from_movie, const int32_t 
     const int64_t groups_per_block = (int64_t)FIT_WAVES * NSPW;
     int64_t blocks = (max_items + groups_per_block - 1) / groups_per_block;
     blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)cu_count * 3));
-    if (from_movie) hipLaunchKernelGGL((mle_strict_kernel<NP, GS, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
-    else hipLaunchKernelGGL((mle_strict_kernel<NP, GS, false>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
+    if (list) {
+        if (from_movie) hipLaunchKernelGGL((mle_strict_kernel<NP, GS, true, false>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
+        else hipLaunchKernelGGL((mle_strict_kernel<NP, GS, false, false>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
+    } else {
+        const int64_t sblocks = std::max<int64_t>(1, std::min<int64_t>((max_items + groups_per_block - 1) / groups_per_block, (int64_t)cu_count * 8));
+        if (from_movie) {
+            hipLaunchKernelGGL((mle_strict_start_kernel<NP, GS, true>), dim3((unsigned)sblocks), dim3(FIT_NT), 0, s, p);
+            hipLaunchKernelGGL((mle_strict_kernel<NP, GS, true, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
+        } else {
+            hipLaunchKernelGGL((mle_strict_start_kernel<NP, GS, false>), dim3((unsigned)sblocks), dim3(FIT_NT), 0, s, p);
+            hipLaunchKernelGGL((mle_strict_kernel<NP, GS, false, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
+        }
+    }
 }
 
 // Newton loop in the reference's arithmetic for the spots of `list` (device indices, *list_n of them, at most

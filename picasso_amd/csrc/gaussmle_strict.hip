@@ -71,25 +71,34 @@ template <int GS> struct SLds {
 
 }  // namespace
 
-// list: spot indices to fit (entries [0, *list_n)), or nullptr = every spot of [p.first, min(p.N, *p.d_n)).
 // ---- the spot, in photons (localize.py:917-931, 1101-1112), into the group's LDS ----
 template <int GS, bool FROM_MOVIE>
 __device__ __forceinline__ void strict_load_spot(const FitParams &p, int64_t sidx, bool have, int j, float *spot)
 {
     const int B = p.box, npix = B * B, H = B / 2;
-    for (int q = j; q < npix; q += GS) {
-        float v = 0.f;
-        if (have) {
-            if (FROM_MOVIE) {
-                const int a = q / B, c = q - a * B;
-                const int64_t fr = p.frame[sidx], yy = p.y[sidx], xx = p.x[sidx];
-                const float raw = load_movie_px(p.movie, p.dtype, (fr * p.Y + (yy - H + a)) * p.X + (xx - H + c));
-                v = div_const((raw - p.baseline) * p.sensitivity, p.gdiv);
-            } else {
-                v = p.spots[sidx * npix + q];
+    int64_t base = 0;
+    if (FROM_MOVIE && have) base = (p.frame[sidx] * p.Y + (p.y[sidx] - H)) * p.X + (p.x[sidx] - H);
+    // (eight loads in flight per lane: one per trip to memory made the one-lane-per-spot start kernel wait 49 times in a row)
+    for (int q0 = j; q0 < npix; q0 += 8 * GS) {
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = q0 + u * GS;
+            v[u] = 0.f;
+            if (have && q < npix) {
+                if (FROM_MOVIE) {
+                    const int a = q / B, c = q - a * B;
+                    v[u] = load_movie_px(p.movie, p.dtype, base + (int64_t)a * p.X + c);
+                } else {
+                    v[u] = p.spots[sidx * npix + q];
+                }
             }
         }
-        spot[q] = v;
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int q = q0 + u * GS;
+            if (q < npix) spot[q] = (FROM_MOVIE && have) ? div_const((v[u] - p.baseline) * p.sensitivity, p.gdiv) : v[u];
+        }
     }
     lds_sync();
 }
@@ -153,17 +162,21 @@ __device__ __forceinline__ void strict_start_values(int B, int j, const float *s
     lds_sync();             // (fscr may be written again)
 }
 
-// The start values of every spot of the batch, NSPW spots per wavefront side by side, into p.thetas (slot 5 of the `sigma`
-// method: a copy of slot 4, as in the fitted rows) — for mle_strict_kernel<.., REFILL = true>.
+// The start values of every spot of the batch into p.thetas (slot 5 of the `sigma` method: a copy of slot 4, as in the fitted
+// rows) — for mle_strict_kernel<.., REFILL = true>.  The sums of the start values are sequential (every lane of a group
+// repeats them), so the groups are as small as the LDS allows: one LANE per spot for boxes up to 7x7 (64 spots per
+// wavefront: 0.53 ms for config 2's million spots against 0.75 with 16-lane groups — what is left is the gather of seven
+// movie rows per spot; building the kernel for the box bought 5 %), 4 lanes up to 15x15, 16 above.
 template <int NP, int GS, bool FROM_MOVIE>
 __global__ __launch_bounds__(FIT_NT) void mle_strict_start_kernel(FitParams p)
 {
     constexpr int NSPW = 64 / GS;
-    __shared__ __attribute__((aligned(16))) float s_spot[FIT_WAVES][NSPW][PMI_MAX_BOX * PMI_MAX_BOX + GS];
+    extern __shared__ __attribute__((aligned(16))) float s_start[];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = lane / GS, j = lane & (GS - 1);
-    float *spot = &s_spot[wid][g][0];
-    float *fscr = spot + PMI_MAX_BOX * PMI_MAX_BOX;
+    const int npix = p.box * p.box, stride = (npix + GS) | 1;           // (odd: the lanes of a wavefront on different banks)
+    float *spot = s_start + (size_t)(wid * NSPW + g) * stride;
+    float *fscr = spot + npix;
     int64_t n = p.N;
     if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
     const int64_t items = n - p.first;
@@ -185,6 +198,18 @@ __global__ __launch_bounds__(FIT_NT) void mle_strict_start_kernel(FitParams p)
     }
 }
 
+template <int NP, int GS>
+static void launch_strict_start(const FitParams &p, bool from_movie, int64_t max_items, int cu_count, hipStream_t s)
+{
+    constexpr int NSPW = 64 / GS;
+    const int64_t groups_per_block = (int64_t)FIT_WAVES * NSPW;
+    const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((max_items + groups_per_block - 1) / groups_per_block, (int64_t)cu_count * 8));
+    const size_t lds = (size_t)groups_per_block * (size_t)((p.box * p.box + GS) | 1) * sizeof(float);
+    if (from_movie) hipLaunchKernelGGL((mle_strict_start_kernel<NP, GS, true>), dim3((unsigned)blocks), dim3(FIT_NT), lds, s, p);
+    else hipLaunchKernelGGL((mle_strict_start_kernel<NP, GS, false>), dim3((unsigned)blocks), dim3(FIT_NT), lds, s, p);
+}
+
+// list: spot indices to fit (entries [0, *list_n)), or nullptr = every spot of [p.first, min(p.N, *p.d_n)).
 template <int NP, int GS, bool FROM_MOVIE, bool REFILL>
 __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, const int32_t *__restrict__ list,
                                                             const unsigned *__restrict__ list_n)
@@ -282,7 +307,7 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
         sidx = list ? (int64_t)list[w] : p.first + w;
 
         strict_load_spot<GS, FROM_MOVIE>(p, sidx, true, j, spot);
-        if (REFILL) {
+        if (REFILL && !list) {
             // (the start values of the batch were computed by mle_strict_start_kernel, four spots per wavefront side by side:
             // here they would run for this group alone with the rest of the wavefront masked)
             const float *from = p.thetas + sidx * 6;
@@ -472,18 +497,19 @@ static void launch_strict_gs(const FitParams &p, bool from_movie, const int32_t 
     const int64_t groups_per_block = (int64_t)FIT_WAVES * NSPW;
     int64_t blocks = (max_items + groups_per_block - 1) / groups_per_block;
     blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)cu_count * 3));
-    if (list) {
+    static const char *renv = tuning_env("PMI_STRICT_LIST_REFILL");      // tuning: the list's groups refill one by one too
+    if (list && renv && atoi(renv)) {
+        if (from_movie) hipLaunchKernelGGL((mle_strict_kernel<NP, GS, true, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
+        else hipLaunchKernelGGL((mle_strict_kernel<NP, GS, false, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
+    } else if (list) {
         if (from_movie) hipLaunchKernelGGL((mle_strict_kernel<NP, GS, true, false>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
         else hipLaunchKernelGGL((mle_strict_kernel<NP, GS, false, false>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
     } else {
-        const int64_t sblocks = std::max<int64_t>(1, std::min<int64_t>((max_items + groups_per_block - 1) / groups_per_block, (int64_t)cu_count * 8));
-        if (from_movie) {
-            hipLaunchKernelGGL((mle_strict_start_kernel<NP, GS, true>), dim3((unsigned)sblocks), dim3(FIT_NT), 0, s, p);
-            hipLaunchKernelGGL((mle_strict_kernel<NP, GS, true, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
-        } else {
-            hipLaunchKernelGGL((mle_strict_start_kernel<NP, GS, false>), dim3((unsigned)sblocks), dim3(FIT_NT), 0, s, p);
-            hipLaunchKernelGGL((mle_strict_kernel<NP, GS, false, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
-        }
+        if (p.box <= 7) launch_strict_start<NP, 1>(p, from_movie, max_items, cu_count, s);
+        else if (p.box <= 15) launch_strict_start<NP, 4>(p, from_movie, max_items, cu_count, s);
+        else launch_strict_start<NP, 16>(p, from_movie, max_items, cu_count, s);
+        if (from_movie) hipLaunchKernelGGL((mle_strict_kernel<NP, GS, true, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
+        else hipLaunchKernelGGL((mle_strict_kernel<NP, GS, false, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
     }
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B on one box: pmi_localize_mle_dev with identify's exact stage in the scan (defer 0) and in the fit's start-value
 kernel (defer 1): the two tables must be equal bit for bit; time per pass for one and two ranges in flight.
-usage: python tools/ab_defer.py [frames] [box] [reps]"""
+usage: python tools/ab_defer.py [frames] [box] [reps] [only] [eps]"""
 import ctypes, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -11,6 +11,7 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 box = int(sys.argv[2]) if len(sys.argv) > 2 else 7
 reps = int(sys.argv[3]) if len(sys.argv) > 3 else 3
 only = int(sys.argv[4]) if len(sys.argv) > 4 else -1          # profile one mode: 0 / 1 (one range in flight, 10 passes)
+EPS = float(sys.argv[5]) if len(sys.argv) > 5 else 1e-3
 L = _lib.load()
 movie = synth.simulate_movie(F, 512, 512, emitters_per_frame=116, device="cuda")
 torch.cuda.synchronize()
@@ -20,7 +21,7 @@ dn = torch.zeros(1, dtype=torch.int64, device="cuda")
 
 
 def run(defer):
-    rc = L.pmi_localize_mle_dev(ctypes.c_void_p(movie.data_ptr()), 0, F, 512, 512, box, 5000.0, None, 0, F - 1, 100.0, 1.0, 1.0, 1e-3, 100,
+    rc = L.pmi_localize_mle_dev(ctypes.c_void_p(movie.data_ptr()), 0, F, 512, 512, box, 5000.0, None, 0, F - 1, 100.0, 1.0, 1.0, EPS, 100,
                                 _lib.MLE_METHODS["sigmaxy"], ctypes.c_void_p(tabs[defer].data_ptr()), cap, ctypes.c_void_p(dn.data_ptr()), None)
     _lib.check(rc, "localize")
 

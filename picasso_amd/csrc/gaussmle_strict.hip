@@ -236,8 +236,8 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
     // max-of-four iterations per spot, 1.5x the mean on config 2: 13.1 -> 10.9 ms).  A workgroup owns a contiguous share of
     // the batch and its groups take the spots of the share one at a time from a counter in LDS.
     // !REFILL (a list of flagged spots): the wavefront takes NSPW new entries when the LAST of its fits has ended.  The flagged
-    // fits are long and alike, and a refill runs the start values for one group with the others masked — measured on one box:
-    // config 2 2.74 (lockstep) against 2.81 ms, eps 1e-4 6.17 against 6.30, config 5 24.6 against 24.8.
+    // fits are long and alike, and a refill runs the start values for one group with the others masked — measured on one box
+    // (tuning build, PMI_STRICT_LIST_REFILL): config 2 2.66 - 2.73 (lockstep) against 2.77 - 2.79 ms, eps 1e-4 and config 5 the same.
     // A list holds fits of 10 and of 100 iterations: dealt round robin, the groups with one entry more
     // than the others, or with two long fits, end the launch long after the rest (13x13, 26 000 entries over 6 144 groups:
     // 2.9 ms).  So only the first round is dealt; after it a wavefront takes its next NSPW entries from a queue word when
@@ -331,8 +331,8 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
         {
             const float sgy = NP == 6 ? th[5] : th[4];
             // phase A: lane -> (axis, boundary k)
-            if (j < 2 * nb) {
-                const int a = j >= nb ? 1 : 0, k = j - a * nb;
+            for (int ja = j; ja < 2 * nb; ja += GS) {            // (one pass unless the group is narrower than 2 (B + 1) lanes)
+                const int a = ja >= nb ? 1 : 0, k = ja - a * nb;
                 const double dmu = (double)(a ? th[1] : th[0]);
                 const float sgf = a ? sgy : th[4];
                 const double ds = (double)sgf;
@@ -358,8 +358,8 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
             }
             lds_sync();
             // phase B: lane -> (axis, pixel index i): PSF, b - a, (d-.5) b - (d+.5) a, sigma terms
-            if (j < 2 * B) {
-                const int a = j >= B ? 1 : 0, i = j - a * B;
+            for (int jb = j; jb < 2 * B; jb += GS) {
+                const int a = jb >= B ? 1 : 0, i = jb - a * B;
                 const double dmu = (double)(a ? th[1] : th[0]);
                 const float sgf = a ? sgy : th[4];
                 const double ds = (double)sgf;
@@ -519,7 +519,8 @@ void launch_fit_strict(const FitParams &p, int method, bool from_movie, const in
                        int64_t max_items, int cu_count, hipStream_t s)
 {
     // four / two / one spot per wavefront: the kernel is bound by instruction issue, not by the latency of one fit
-    // (measured on config 2's 6 500 flagged spots: 16-lane groups 0.30 ms, 64-lane groups 0.45 ms)
+    // (measured on config 2's 6 500 flagged spots: 16-lane groups 0.30 ms, 64-lane groups 0.45 ms; 13x13 on 16-lane groups —
+    // four spots per wavefront but two wavefronts per SIMD instead of three for the LDS: 1.23 against 0.95 ms per list of config 5)
     static const char *genv = tuning_env("PMI_STRICT_LIST_GS");      // tuning: group size for the flagged-spot list
     const int packed = p.box <= 7 ? 16 : (p.box <= 15 ? 32 : 64);
     const int gs = list ? std::max(packed, genv ? atoi(genv) : packed) : packed;

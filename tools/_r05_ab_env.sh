@@ -1,5 +1,7 @@
 #!/bin/bash
-# same-box A/B of a tuning variable: usage tools/_r05_ab_env.sh VAR VALUE
+# same-box A/B of a tuning variable on the tuning build (picasso_amd/libpicasso_hip_tuning.so: make TUNING=1 objects): usage
+# tools/_r05_ab_env.sh VAR VALUE
+export PICASSO_AMD_LIB=$PWD/picasso_amd/libpicasso_hip_tuning.so
 for i in 1 2; do
 for v in off on; do
   if [ $v = on ]; then export $1=$2; else unset $1; fi

@@ -4,9 +4,17 @@
 // scipy.optimize.curve_fit(p0=[max,0,0,1,min], bounds=([0,-inf,-inf,0,0], inf)), i.e. least_squares(method='trf',
 // jac='2-point', x_scale=1, ftol=xtol=gtol=1e-8, max_nfev=500, tr_solver='exact') — third-party arithmetic (scipy
 // 1.15.3: _lsq/trf.py trf_bounds, _lsq/common.py, _numdiff.py), restated from the published Trust Region Reflective
-// algorithm (Branch, Coleman & Li 1999; More 1977) with a one-sided Jacobi SVD in place of LAPACK's.  One thread per
-// pair of segment images: RCC has n(n-1)/2 of these 25-number fits (300 for config 4's 25 segments), 13 ms each as a
-// scipy call on the host and the bulk of the reference's undrift time.
+// algorithm (Branch, Coleman & Li 1999; More 1977) with a one-sided Jacobi SVD in place of LAPACK's.  RCC has n(n-1)/2 of
+// these 25-number fits (300 for config 4's 25 segments, 4 950 for 100), 13 ms each as a scipy call on the host and the bulk of
+// the reference's undrift time.
+//
+// One WAVEFRONT per pair of segment images (round 5; rounds 2 - 4: one lane per pair with the residuals, the Jacobian and its
+// SVD copy in 35 KB of scratch memory per lane).  The m = box^2 residual rows (<= 225) and the five rows the bounds add to
+// the Jacobian sit on the lanes, row r on lane r % 64 as element r / 64 (PK_E = 4 per lane): the model evaluation, the
+// forward differences and the column rotations of the Jacobi SVD are row-parallel; the m-long sums (J^T f, the rotation
+// angles, the quadratic model) are per-lane partial sums + a butterfly over the wavefront, which leaves every lane the SAME
+// bits (both partners of a stage add the same two numbers) — so the five-parameter trust-region logic is computed by
+// every lane alike and the control flow never diverges.  No scratch, no LDS.
 #include <math.h>
 
 #include <vector>
@@ -19,30 +27,55 @@ namespace pmi {
 namespace pk {
 
 #define PK_N 5
-#define PK_MAXM (15 * 15)
+#define PK_E 4                      // rows per lane: (15 * 15 + 5 + 63) / 64
 #define PK_EPS 2.220446049250313e-16
 
-__device__ static void pk_fun(const double *x, const double *data, int box, double *f)
+__device__ __forceinline__ double wsum(double v)
 {
-    const int h = box / 2;
-    for (int i = 0; i < box; i++)
-        for (int j = 0; j < box; j++) {
-            const double xx = (double)(j - h) - x[1], yy = (double)(i - h) - x[2];
-            const double e = -0.5 * (xx * xx + yy * yy) / (x[3] * x[3]);
-            f[i * box + j] = (x[0] * exp(e) + x[4]) - data[i * box + j];
-        }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+__device__ __forceinline__ double wmax(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    return v;
+}
+__device__ __forceinline__ double wmin(double v)
+{
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v = fmin(v, __shfl_xor(v, off));
+    return v;
 }
 
-__device__ static double pk_norm(const double *v, int n) { double s = 0; for (int i = 0; i < n; i++) s += v[i] * v[i]; return sqrt(s); }
-__device__ static double pk_dot(const double *a, const double *b, int n) { double s = 0; for (int i = 0; i < n; i++) s += a[i] * b[i]; return s; }
-
-/* approx_derivative(method='2-point', rel_step=None, bounds): J is m x n row-major */
-__device__ static void pk_jac(const double *x0, const double *f0, const double *data, int box, const double *lb, const double *ub,
-                   double *J, int *nfev)
+// the residuals of this lane's rows (rows >= m: 0)
+__device__ __forceinline__ void pk_fun(const double (&x)[PK_N], const double (&data)[PK_E], int box, int m, int lane, double (&f)[PK_E])
 {
-    const int m = box * box;
-    double x1[PK_N], f1[PK_MAXM];
+    const int h = box / 2;
+#pragma unroll
+    for (int e = 0; e < PK_E; e++) {
+        const int r = lane + 64 * e;
+        double v = 0.0;
+        if (r < m) {
+            const int i = r / box, j = r - i * box;
+            const double xx = (double)(j - h) - x[1], yy = (double)(i - h) - x[2];
+            const double ex = -0.5 * (xx * xx + yy * yy) / (x[3] * x[3]);
+            v = (x[0] * exp(ex) + x[4]) - data[e];
+        }
+        f[e] = v;
+    }
+}
+
+__device__ __forceinline__ double pk_norm5(const double (&v)[PK_N]) { double s = 0; for (int i = 0; i < PK_N; i++) s += v[i] * v[i]; return sqrt(s); }
+__device__ __forceinline__ double pk_dot5(const double (&a)[PK_N], const double (&b)[PK_N]) { double s = 0; for (int i = 0; i < PK_N; i++) s += a[i] * b[i]; return s; }
+
+/* approx_derivative(method='2-point', rel_step=None, bounds): J[e][k], this lane's rows */
+__device__ __forceinline__ void pk_jac(const double (&x0)[PK_N], const double (&f0)[PK_E], const double (&data)[PK_E], int box, int m, int lane,
+                                       const double (&lb)[PK_N], const double (&ub)[PK_N], double (&J)[PK_E][PK_N])
+{
     const double rstep = sqrt(PK_EPS);
+#pragma unroll
     for (int i = 0; i < PK_N; i++) {
         const double sign_x0 = x0[i] >= 0 ? 1.0 : -1.0;
         double h = rstep * sign_x0 * fmax(1.0, fabs(x0[i]));
@@ -53,55 +86,69 @@ __device__ static void pk_jac(const double *x0, const double *f0, const double *
         const int fitting = fabs(h) <= fmax(lower_dist, upper_dist);
         if (violated && fitting) h = -h;
         if (!fitting) h = upper_dist >= lower_dist ? upper_dist : -lower_dist;
+        double x1[PK_N], f1[PK_E];
+#pragma unroll
         for (int k = 0; k < PK_N; k++) x1[k] = x0[k];
         x1[i] += h;
         const double dx = x1[i] - x0[i];
-        pk_fun(x1, data, box, f1);
-        (*nfev)++;          /* (counted by scipy's jac wrapper separately from nfev; kept for information) */
-        for (int r = 0; r < m; r++) J[r * PK_N + i] = (f1[r] - f0[r]) / dx;
+        pk_fun(x1, data, box, m, lane, f1);
+#pragma unroll
+        for (int e = 0; e < PK_E; e++) J[e][i] = (lane + 64 * e < m) ? (f1[e] - f0[e]) / dx : 0.0;
     }
 }
 
-/* one-sided Jacobi SVD of A (M x 5, row-major, overwritten by U*S); V (5x5 row-major) */
-__device__ static void pk_svd(double *A, int M, double *V, double *s)
+/* one-sided Jacobi SVD of A (this lane's rows of an M x 5 matrix, overwritten by U*S); V (5 x 5, every lane the same) */
+__device__ __forceinline__ void pk_svd(double (&A)[PK_E][PK_N], double (&V)[PK_N][PK_N], double (&s)[PK_N])
 {
-    for (int i = 0; i < PK_N; i++) for (int j = 0; j < PK_N; j++) V[i * PK_N + j] = (i == j);
+#pragma unroll
+    for (int i = 0; i < PK_N; i++)
+#pragma unroll
+        for (int j = 0; j < PK_N; j++) V[i][j] = (i == j);
     for (int sweep = 0; sweep < 60; sweep++) {
         int rotated = 0;
+#pragma unroll
         for (int p = 0; p < PK_N - 1; p++)
+#pragma unroll
             for (int q = p + 1; q < PK_N; q++) {
                 double alpha = 0, beta = 0, gamma = 0;
-                for (int r = 0; r < M; r++) {
-                    const double ap = A[r * PK_N + p], aq = A[r * PK_N + q];
+#pragma unroll
+                for (int e = 0; e < PK_E; e++) {
+                    const double ap = A[e][p], aq = A[e][q];
                     alpha += ap * ap; beta += aq * aq; gamma += ap * aq;
                 }
+                alpha = wsum(alpha); beta = wsum(beta); gamma = wsum(gamma);
                 if (gamma == 0.0 || fabs(gamma) <= PK_EPS * sqrt(alpha * beta)) continue;
                 rotated = 1;
                 const double zeta = (beta - alpha) / (2.0 * gamma);
                 const double t = (zeta >= 0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
                 const double c = 1.0 / sqrt(1.0 + t * t), sn = c * t;
-                for (int r = 0; r < M; r++) {
-                    const double ap = A[r * PK_N + p], aq = A[r * PK_N + q];
-                    A[r * PK_N + p] = c * ap - sn * aq;
-                    A[r * PK_N + q] = sn * ap + c * aq;
+#pragma unroll
+                for (int e = 0; e < PK_E; e++) {
+                    const double ap = A[e][p], aq = A[e][q];
+                    A[e][p] = c * ap - sn * aq;
+                    A[e][q] = sn * ap + c * aq;
                 }
+#pragma unroll
                 for (int r = 0; r < PK_N; r++) {
-                    const double vp = V[r * PK_N + p], vq = V[r * PK_N + q];
-                    V[r * PK_N + p] = c * vp - sn * vq;
-                    V[r * PK_N + q] = sn * vp + c * vq;
+                    const double vp = V[r][p], vq = V[r][q];
+                    V[r][p] = c * vp - sn * vq;
+                    V[r][q] = sn * vp + c * vq;
                 }
             }
         if (!rotated) break;
     }
+#pragma unroll
     for (int i = 0; i < PK_N; i++) {
         double n2 = 0;
-        for (int r = 0; r < M; r++) n2 += A[r * PK_N + i] * A[r * PK_N + i];
-        s[i] = sqrt(n2);
+#pragma unroll
+        for (int e = 0; e < PK_E; e++) n2 += A[e][i] * A[e][i];
+        s[i] = sqrt(wsum(n2));
     }
 }
 
 /* common.py solve_lsq_trust_region: suf[i] = s[i] * (U^T f)[i] */
-__device__ static void pk_solve_tr(int m, const double *suf, const double *s, const double *V, double Delta, double *alpha_io, double *p)
+__device__ __forceinline__ void pk_solve_tr(int m, const double (&suf)[PK_N], const double (&s)[PK_N], const double (&V)[PK_N][PK_N], double Delta,
+                                            double *alpha_io, double (&p)[PK_N])
 {
     double smax = 0, smin = INFINITY;
     for (int i = 0; i < PK_N; i++) { if (s[i] > smax) smax = s[i]; if (s[i] < smin) smin = s[i]; }
@@ -109,10 +156,10 @@ __device__ static void pk_solve_tr(int m, const double *suf, const double *s, co
     double t[PK_N];
     if (full_rank) {
         for (int i = 0; i < PK_N; i++) t[i] = (suf[i] / s[i]) / s[i];        /* uf / s */
-        for (int i = 0; i < PK_N; i++) { double a = 0; for (int k = 0; k < PK_N; k++) a += V[i * PK_N + k] * t[k]; p[i] = -a; }
-        if (pk_norm(p, PK_N) <= Delta) { *alpha_io = 0.0; return; }
+        for (int i = 0; i < PK_N; i++) { double a = 0; for (int k = 0; k < PK_N; k++) a += V[i][k] * t[k]; p[i] = -a; }
+        if (pk_norm5(p) <= Delta) { *alpha_io = 0.0; return; }
     }
-    double alpha_upper = pk_norm(suf, PK_N) / Delta, alpha_lower = 0.0;
+    double alpha_upper = pk_norm5(suf) / Delta, alpha_lower = 0.0;
     if (full_rank) {
         double pn2 = 0, dsum = 0;
         for (int i = 0; i < PK_N; i++) { const double den = s[i] * s[i]; const double q = suf[i] / den; pn2 += q * q; dsum += suf[i] * suf[i] / (den * den * den); }
@@ -133,13 +180,13 @@ __device__ static void pk_solve_tr(int m, const double *suf, const double *s, co
         if (fabs(phi) < 0.01 * Delta) break;
     }
     for (int i = 0; i < PK_N; i++) t[i] = suf[i] / (s[i] * s[i] + alpha);
-    for (int i = 0; i < PK_N; i++) { double a = 0; for (int k = 0; k < PK_N; k++) a += V[i * PK_N + k] * t[k]; p[i] = -a; }
-    const double pn = pk_norm(p, PK_N);
+    for (int i = 0; i < PK_N; i++) { double a = 0; for (int k = 0; k < PK_N; k++) a += V[i][k] * t[k]; p[i] = -a; }
+    const double pn = pk_norm5(p);
     for (int i = 0; i < PK_N; i++) p[i] *= Delta / pn;
     *alpha_io = alpha;
 }
 
-__device__ static double pk_step_to_bound(const double *x, const double *sv, const double *lb, const double *ub, int *hits)
+__device__ __forceinline__ double pk_step_to_bound(const double (&x)[PK_N], const double (&sv)[PK_N], const double (&lb)[PK_N], const double (&ub)[PK_N], int *hits)
 {
     double steps[PK_N], mn = INFINITY;
     for (int i = 0; i < PK_N; i++) {
@@ -151,33 +198,41 @@ __device__ static double pk_step_to_bound(const double *x, const double *sv, con
     return mn;
 }
 
-/* 0.5 * s^T (J_h^T J_h + diag) s + g^T s */
-__device__ static double pk_quad(const double *Jh, int m, const double *diag, const double *g, const double *sv)
+/* 0.5 * s^T (J_h^T J_h + diag) s + g^T s; J_h = J d, this lane's rows */
+__device__ __forceinline__ double pk_quad(const double (&J)[PK_E][PK_N], const double (&d)[PK_N], const double (&diag)[PK_N], const double (&g)[PK_N],
+                                          const double (&sv)[PK_N])
 {
     double q = 0;
-    for (int r = 0; r < m; r++) { double a = 0; for (int k = 0; k < PK_N; k++) a += Jh[r * PK_N + k] * sv[k]; q += a * a; }
+#pragma unroll
+    for (int e = 0; e < PK_E; e++) { double a = 0; for (int k = 0; k < PK_N; k++) a += (J[e][k] * d[k]) * sv[k]; q += a * a; }
+    q = wsum(q);
     for (int k = 0; k < PK_N; k++) q += sv[k] * diag[k] * sv[k];
-    return 0.5 * q + pk_dot(sv, g, PK_N);
+    return 0.5 * q + pk_dot5(sv, g);
 }
-__device__ static void pk_quad_1d(const double *Jh, int m, const double *diag, const double *g, const double *sv, const double *s0,
-                       double *a, double *b, double *c)
+__device__ __forceinline__ void pk_quad_1d(const double (&J)[PK_E][PK_N], const double (&d)[PK_N], const double (&diag)[PK_N], const double (&g)[PK_N],
+                                           const double (&sv)[PK_N], const double *s0, double *a, double *b, double *c)
 {
-    double aa = 0, bb = pk_dot(g, sv, PK_N), cc = 0, uu = 0, uv = 0;
-    for (int r = 0; r < m; r++) {
+    double aa = 0, bb = pk_dot5(g, sv), cc = 0, uu = 0, uv = 0;
+#pragma unroll
+    for (int e = 0; e < PK_E; e++) {
         double v = 0, u = 0;
-        for (int k = 0; k < PK_N; k++) { v += Jh[r * PK_N + k] * sv[k]; if (s0) u += Jh[r * PK_N + k] * s0[k]; }
+        for (int k = 0; k < PK_N; k++) { const double jh = J[e][k] * d[k]; v += jh * sv[k]; if (s0) u += jh * s0[k]; }
         aa += v * v; uu += u * u; uv += u * v;
     }
+    aa = wsum(aa);
+    if (s0) { uu = wsum(uu); uv = wsum(uv); }
     for (int k = 0; k < PK_N; k++) aa += sv[k] * diag[k] * sv[k];
     aa *= 0.5;
     if (s0) {
         bb += uv;
-        cc = 0.5 * uu + pk_dot(g, s0, PK_N);
+        double gs0 = 0;
+        for (int k = 0; k < PK_N; k++) gs0 += g[k] * s0[k];
+        cc = 0.5 * uu + gs0;
         for (int k = 0; k < PK_N; k++) { bb += s0[k] * diag[k] * sv[k]; cc += 0.5 * s0[k] * diag[k] * s0[k]; }
     }
     *a = aa; *b = bb; if (c) *c = cc;
 }
-__device__ static double pk_min_quad_1d(double a, double b, double lo, double hi, double c, double *tmin)
+__device__ __forceinline__ double pk_min_quad_1d(double a, double b, double lo, double hi, double c, double *tmin)
 {
     double tt[3] = {lo, hi, 0}; int nt = 2;
     if (a != 0) { const double ex = -0.5 * b / a; if (lo < ex && ex < hi) tt[nt++] = ex; }
@@ -187,16 +242,16 @@ __device__ static double pk_min_quad_1d(double a, double b, double lo, double hi
 }
 
 /* trf.py select_step; p, p_h are modified like the numpy arrays are */
-__device__ static double pk_select_step(const double *x, const double *Jh, int m, const double *diag_h, const double *g_h, double *p, double *p_h,
-                             const double *d, double Delta, const double *lb, const double *ub, double theta,
-                             double *step, double *step_h)
+__device__ __forceinline__ double pk_select_step(const double (&x)[PK_N], const double (&J)[PK_E][PK_N], const double (&diag_h)[PK_N], const double (&g_h)[PK_N],
+                                                 double (&p)[PK_N], double (&p_h)[PK_N], const double (&d)[PK_N], double Delta, const double (&lb)[PK_N],
+                                                 const double (&ub)[PK_N], double theta, double (&step)[PK_N], double (&step_h)[PK_N])
 {
     double xp[PK_N];
     int inb = 1;
     for (int i = 0; i < PK_N; i++) { xp[i] = x[i] + p[i]; if (!(xp[i] >= lb[i] && xp[i] <= ub[i])) inb = 0; }
     if (inb) {
         for (int i = 0; i < PK_N; i++) { step[i] = p[i]; step_h[i] = p_h[i]; }
-        return -pk_quad(Jh, m, diag_h, g_h, p_h);
+        return -pk_quad(J, d, diag_h, g_h, p_h);
     }
     int hits[PK_N];
     const double p_stride = pk_step_to_bound(x, p, lb, ub, hits);
@@ -206,7 +261,7 @@ __device__ static double pk_select_step(const double *x, const double *Jh, int m
     /* intersect_trust_region(p_h, r_h, Delta): positive root */
     double to_tr;
     {
-        const double a = pk_dot(r_h, r_h, PK_N), b = pk_dot(p_h, r_h, PK_N), c = pk_dot(p_h, p_h, PK_N) - Delta * Delta;
+        const double a = pk_dot5(r_h, r_h), b = pk_dot5(p_h, r_h), c = pk_dot5(p_h, p_h) - Delta * Delta;
         const double dd = sqrt(b * b - a * c), q = -(b + copysign(dd, b));
         const double t1 = q / a, t2 = c / q;
         to_tr = t1 < t2 ? t2 : t1;
@@ -218,52 +273,52 @@ __device__ static double pk_select_step(const double *x, const double *Jh, int m
     double r_value = INFINITY;
     if (r_stride_l <= r_stride_u) {
         double a, b, c;
-        pk_quad_1d(Jh, m, diag_h, g_h, r_h, p_h, &a, &b, &c);
+        pk_quad_1d(J, d, diag_h, g_h, r_h, p_h, &a, &b, &c);
         r_value = pk_min_quad_1d(a, b, r_stride_l, r_stride_u, c, &r_stride);
         for (int i = 0; i < PK_N; i++) { r_h[i] = r_h[i] * r_stride + p_h[i]; r[i] = r_h[i] * d[i]; }
     }
     for (int i = 0; i < PK_N; i++) { p[i] *= theta; p_h[i] *= theta; }
-    const double p_value = pk_quad(Jh, m, diag_h, g_h, p_h);
+    const double p_value = pk_quad(J, d, diag_h, g_h, p_h);
     double ag_h[PK_N], ag[PK_N];
     for (int i = 0; i < PK_N; i++) { ag_h[i] = -g_h[i]; ag[i] = d[i] * ag_h[i]; }
-    const double to_tr2 = Delta / pk_norm(ag_h, PK_N);
+    const double to_tr2 = Delta / pk_norm5(ag_h);
     const double to_bound2 = pk_step_to_bound(x, ag, lb, ub, 0);
     double ag_stride = to_bound2 < to_tr2 ? theta * to_bound2 : to_tr2;
     double a, b;
-    pk_quad_1d(Jh, m, diag_h, g_h, ag_h, 0, &a, &b, 0);
+    pk_quad_1d(J, d, diag_h, g_h, ag_h, nullptr, &a, &b, nullptr);
     const double ag_value = pk_min_quad_1d(a, b, 0, ag_stride, 0, &ag_stride);
     for (int i = 0; i < PK_N; i++) { ag_h[i] *= ag_stride; ag[i] *= ag_stride; }
-    const double *ss, *sh; double val;
-    if (p_value < r_value && p_value < ag_value) { ss = p; sh = p_h; val = p_value; }
-    else if (r_value < p_value && r_value < ag_value) { ss = r; sh = r_h; val = r_value; }
-    else { ss = ag; sh = ag_h; val = ag_value; }
-    for (int i = 0; i < PK_N; i++) { step[i] = ss[i]; step_h[i] = sh[i]; }
+    double val;
+    if (p_value < r_value && p_value < ag_value) { for (int i = 0; i < PK_N; i++) { step[i] = p[i]; step_h[i] = p_h[i]; } val = p_value; }
+    else if (r_value < p_value && r_value < ag_value) { for (int i = 0; i < PK_N; i++) { step[i] = r[i]; step_h[i] = r_h[i]; } val = r_value; }
+    else { for (int i = 0; i < PK_N; i++) { step[i] = ag[i]; step_h[i] = ag_h[i]; } val = ag_value; }
     return -val;
 }
 
-// roi: box x box float64 window (row-major, rows = y).  popt = a, xc, yc, s, b.  Returns scipy's status
-// (0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 both).
-__device__ static int peak_fit(const double *roi, int box, double *popt, int *nfev_out)
+// data: this lane's rows of the box x box float64 window (row-major, rows = y).  popt = a, xc, yc, s, b (every lane the same).
+// Returns scipy's status (0 max_nfev, 1 gtol, 2 ftol, 3 xtol, 4 both).
+__device__ __forceinline__ int peak_fit(const double (&data)[PK_E], int box, int lane, double mx, double mn, double (&popt)[PK_N], int *nfev_out)
 {
-    const int m = box * box, M = m + PK_N;
+    const int m = box * box;
     const double lb[PK_N] = {0, -INFINITY, -INFINITY, 0, 0}, ub[PK_N] = {INFINITY, INFINITY, INFINITY, INFINITY, INFINITY};
     const double ftol = 1e-8, xtol = 1e-8, gtol = 1e-8;
     const int max_nfev = 100 * PK_N;
-    double x[PK_N], mx = roi[0], mn = roi[0];
-    for (int i = 1; i < m; i++) { if (roi[i] > mx) mx = roi[i]; if (roi[i] < mn) mn = roi[i]; }
+    double x[PK_N];
     x[0] = mx; x[1] = 0; x[2] = 0; x[3] = 1; x[4] = mn;
     /* make_strictly_feasible(x0, lb, ub, rstep=1e-10) */
     for (int i = 0; i < PK_N; i++) {
         if (isfinite(lb[i]) && x[i] - lb[i] <= 1e-10 * fmax(1.0, fabs(lb[i]))) x[i] = lb[i] + 1e-10 * fmax(1.0, fabs(lb[i]));
         if (x[i] < lb[i] || x[i] > ub[i]) x[i] = 0.5 * (lb[i] + ub[i]);
     }
-    double f[PK_MAXM], f_new[PK_MAXM], J[PK_MAXM * PK_N], Jaug[(PK_MAXM + PK_N) * PK_N], Jh[PK_MAXM * PK_N];
-    double g[PK_N], v[PK_N], dv[PK_N], d[PK_N], diag_h[PK_N], g_h[PK_N], V[PK_N * PK_N], s[PK_N], suf[PK_N];
-    int nfev = 1, njac = 0;
-    pk_fun(x, roi, box, f);
-    pk_jac(x, f, roi, box, lb, ub, J, &njac);
-    double cost = 0.5 * pk_dot(f, f, m);
-    for (int k = 0; k < PK_N; k++) { double a = 0; for (int r = 0; r < m; r++) a += J[r * PK_N + k] * f[r]; g[k] = a; }
+    double f[PK_E], f_new[PK_E], J[PK_E][PK_N], A[PK_E][PK_N];
+    double g[PK_N], v[PK_N], dv[PK_N], d[PK_N], diag_h[PK_N], g_h[PK_N], V[PK_N][PK_N], s[PK_N], suf[PK_N];
+    int nfev = 1;
+    pk_fun(x, data, box, m, lane, f);
+    pk_jac(x, f, data, box, m, lane, lb, ub, J);
+    auto dot_ff = [&](const double (&a)[PK_E]) { double t = 0; for (int e = 0; e < PK_E; e++) t += a[e] * a[e]; return wsum(t); };
+    auto grad = [&]() { for (int k = 0; k < PK_N; k++) { double a = 0; for (int e = 0; e < PK_E; e++) a += J[e][k] * f[e]; g[k] = wsum(a); } };
+    double cost = 0.5 * dot_ff(f);
+    grad();
     /* CL_scaling_vector */
 #define PK_CL()                                                                                   \
     for (int i = 0; i < PK_N; i++) {                                                              \
@@ -273,7 +328,7 @@ __device__ static int peak_fit(const double *roi, int box, double *popt, int *nf
     }
     PK_CL();
     double Delta;
-    { double t[PK_N]; for (int i = 0; i < PK_N; i++) t[i] = x[i] / sqrt(v[i]); Delta = pk_norm(t, PK_N); if (Delta == 0) Delta = 1.0; }
+    { double t[PK_N]; for (int i = 0; i < PK_N; i++) t[i] = x[i] / sqrt(v[i]); Delta = pk_norm5(t); if (Delta == 0) Delta = 1.0; }
     double alpha = 0.0;
     int status = -1;
     for (;;) {
@@ -283,31 +338,36 @@ __device__ static int peak_fit(const double *roi, int box, double *popt, int *nf
         if (g_norm < gtol) status = 1;
         if (status != -1 || nfev == max_nfev) break;
         for (int i = 0; i < PK_N; i++) { d[i] = sqrt(v[i]); diag_h[i] = g[i] * dv[i]; g_h[i] = d[i] * g[i]; }
-        for (int r = 0; r < m; r++) for (int k = 0; k < PK_N; k++) { Jh[r * PK_N + k] = J[r * PK_N + k] * d[k]; Jaug[r * PK_N + k] = Jh[r * PK_N + k]; }
-        for (int r = 0; r < PK_N; r++) for (int k = 0; k < PK_N; k++) Jaug[(m + r) * PK_N + k] = (r == k) ? sqrt(diag_h[k]) : 0.0;
-        pk_svd(Jaug, M, V, s);
+        // J_h = J d, and below it the five rows diag(sqrt(diag_h)) (rows m .. m + 4, on the lanes like the others)
+#pragma unroll
+        for (int e = 0; e < PK_E; e++) {
+            const int r = lane + 64 * e;
+#pragma unroll
+            for (int k = 0; k < PK_N; k++) A[e][k] = r < m ? J[e][k] * d[k] : (r - m == k ? sqrt(diag_h[k]) : 0.0);
+        }
+        pk_svd(A, V, s);
         /* suf = s * (U^T f_aug) = (U S)^T f_aug; f_aug = (f, 0) */
-        for (int k = 0; k < PK_N; k++) { double a = 0; for (int r = 0; r < m; r++) a += Jaug[r * PK_N + k] * f[r]; suf[k] = a; }
+        for (int k = 0; k < PK_N; k++) { double a = 0; for (int e = 0; e < PK_E; e++) a += A[e][k] * f[e]; suf[k] = wsum(a); }
         const double theta = fmax(0.995, 1 - g_norm);
         double actual_reduction = -1, cost_new = cost, x_new[PK_N], step[PK_N], step_h[PK_N];
         while (actual_reduction <= 0 && nfev < max_nfev) {
             double p_h[PK_N], p[PK_N];
             pk_solve_tr(m, suf, s, V, Delta, &alpha, p_h);
             for (int i = 0; i < PK_N; i++) p[i] = d[i] * p_h[i];
-            const double predicted = pk_select_step(x, Jh, m, diag_h, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h);
+            const double predicted = pk_select_step(x, J, diag_h, g_h, p, p_h, d, Delta, lb, ub, theta, step, step_h);
             /* make_strictly_feasible(x + step, rstep=0) */
             for (int i = 0; i < PK_N; i++) {
                 x_new[i] = x[i] + step[i];
                 if (x_new[i] <= lb[i]) x_new[i] = nextafter(lb[i], ub[i]);
                 if (x_new[i] >= ub[i]) x_new[i] = nextafter(ub[i], lb[i]);
             }
-            pk_fun(x_new, roi, box, f_new);
+            pk_fun(x_new, data, box, m, lane, f_new);
             nfev++;
-            const double step_h_norm = pk_norm(step_h, PK_N);
-            int finite = 1;
-            for (int r = 0; r < m; r++) if (!isfinite(f_new[r])) finite = 0;
-            if (!finite) { Delta = 0.25 * step_h_norm; continue; }
-            cost_new = 0.5 * pk_dot(f_new, f_new, m);
+            const double step_h_norm = pk_norm5(step_h);
+            bool bad = false;
+            for (int e = 0; e < PK_E; e++) bad = bad || !isfinite(f_new[e]);
+            if (__builtin_amdgcn_ballot_w64(bad) != 0ull) { Delta = 0.25 * step_h_norm; continue; }
+            cost_new = 0.5 * dot_ff(f_new);
             actual_reduction = cost - cost_new;
             /* update_tr_radius */
             double ratio, Delta_new = Delta;
@@ -316,7 +376,7 @@ __device__ static int peak_fit(const double *roi, int box, double *popt, int *nf
             else ratio = 0;
             if (ratio < 0.25) Delta_new = 0.25 * step_h_norm;
             else if (ratio > 0.75 && step_h_norm > 0.95 * Delta) Delta_new = Delta * 2.0;
-            const double step_norm = pk_norm(step, PK_N), x_norm = pk_norm(x, PK_N);
+            const double step_norm = pk_norm5(step), x_norm = pk_norm5(x);
             const int ftol_ok = actual_reduction < ftol * cost && ratio > 0.25;
             const int xtol_ok = step_norm < xtol * (xtol + x_norm);
             if (ftol_ok && xtol_ok) status = 4; else if (ftol_ok) status = 2; else if (xtol_ok) status = 3;
@@ -326,10 +386,10 @@ __device__ static int peak_fit(const double *roi, int box, double *popt, int *nf
         }
         if (actual_reduction > 0) {
             for (int i = 0; i < PK_N; i++) x[i] = x_new[i];
-            for (int r = 0; r < m; r++) f[r] = f_new[r];
+            for (int e = 0; e < PK_E; e++) f[e] = f_new[e];
             cost = cost_new;
-            pk_jac(x, f, roi, box, lb, ub, J, &njac);
-            for (int k = 0; k < PK_N; k++) { double a = 0; for (int r = 0; r < m; r++) a += J[r * PK_N + k] * f[r]; g[k] = a; }
+            pk_jac(x, f, data, box, m, lane, lb, ub, J);
+            grad();
         }
     }
     if (status == -1) status = 0;
@@ -340,28 +400,39 @@ __device__ static int peak_fit(const double *roi, int box, double *popt, int *nf
 
 struct PairIn { int32_t y_max, x_max, valid; };
 
+constexpr int PK_WAVES = 4;           // wavefronts (pairs) per workgroup
+
 // shift_yx[2p], [2p+1] = (-yc, -xc) of imageprocess.py:155-159; status: scipy's termination code, -1 no fit
 // (empty image or truncated window: shift (0, 0)), -2 the window minimum is negative (curve_fit raises: p0 infeasible),
 // -3 the window holds a NaN or an infinity (curve_fit(check_finite=True) raises ValueError); 0 = the fit ran into
 // max_nfev, where curve_fit raises RuntimeError("Optimal parameters not found") — the host mirror raises both
-__global__ void peak_fit_kernel(const double *__restrict__ rois, const int32_t *__restrict__ peaks /* y, x, valid */,
+__global__ __launch_bounds__(PK_WAVES * 64, 1) void peak_fit_kernel(const double *__restrict__ rois, const int32_t *__restrict__ peaks /* y, x, valid */,
                                 int64_t n_pairs, int box, int64_t Y, int64_t X, int64_t Y_, int64_t X_,
                                 double *__restrict__ shift_yx, double *__restrict__ popt_out, int32_t *__restrict__ status)
 {
-    const int64_t p = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int64_t p = (int64_t)blockIdx.x * PK_WAVES + (threadIdx.x >> 6);       // one wavefront per pair
     if (p >= n_pairs) return;
     double sy = 0.0, sx = 0.0, popt[PK_N] = {0, 0, 0, 0, 0};
     int st = -1;
     if (peaks[3 * p + 2] == 1) {
-        const double *roi = rois + p * box * box;
-        double mn = roi[0];
-        bool finite = isfinite(roi[0]);
-        for (int k = 1; k < box * box; k++) { mn = fmin(mn, roi[k]); finite = finite && isfinite(roi[k]); }      // fmin drops a NaN: test it
-        if (!finite) st = -3;
+        const int m = box * box;
+        const double *roi = rois + p * m;
+        double data[PK_E];
+        double mn = INFINITY, mx = -INFINITY;
+        bool finite = true;
+#pragma unroll
+        for (int e = 0; e < PK_E; e++) {
+            const int r = lane + 64 * e;
+            data[e] = r < m ? roi[r] : 0.0;
+            if (r < m) { mn = fmin(mn, data[e]); mx = fmax(mx, data[e]); finite = finite && isfinite(data[e]); }      // fmin drops a NaN: test it
+        }
+        mn = wmin(mn); mx = wmax(mx);
+        if (__builtin_amdgcn_ballot_w64(!finite) != 0ull) st = -3;
         else if (mn < 0.0) st = -2;
         else {
             int nfev = 0;
-            st = peak_fit(roi, box, popt, &nfev);
+            st = peak_fit(data, box, lane, mx, mn, popt, &nfev);
             double xc = popt[1] + (double)X_ + (double)peaks[3 * p + 1];
             double yc = popt[2] + (double)Y_ + (double)peaks[3 * p];
             xc -= floor((double)X / 2.0);
@@ -369,9 +440,11 @@ __global__ void peak_fit_kernel(const double *__restrict__ rois, const int32_t *
             sy = -yc; sx = -xc;
         }
     }
-    shift_yx[2 * p] = sy; shift_yx[2 * p + 1] = sx;
-    if (popt_out) for (int k = 0; k < PK_N; k++) popt_out[p * PK_N + k] = popt[k];
-    status[p] = st;
+    if (lane == 0) {
+        shift_yx[2 * p] = sy; shift_yx[2 * p + 1] = sx;
+        if (popt_out) for (int k = 0; k < PK_N; k++) popt_out[p * PK_N + k] = popt[k];
+        status[p] = st;
+    }
 }
 
 }  // namespace pk
@@ -387,7 +460,7 @@ int rcc_fit_peaks(const double *d_rois, const int32_t *h_peaks3, int64_t n_pairs
     double *d_shift = (double *)ptr;
     int32_t *d_peaks = (int32_t *)(d_shift + 2 * n_pairs), *d_status = d_peaks + 3 * n_pairs;
     PMI_HIP(hipMemcpy(d_peaks, h_peaks3, (size_t)n_pairs * 12, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(pk::peak_fit_kernel, dim3((unsigned)((n_pairs + 63) / 64)), dim3(64), 0, 0, d_rois, d_peaks, n_pairs, box,
+    hipLaunchKernelGGL(pk::peak_fit_kernel, dim3((unsigned)((n_pairs + pk::PK_WAVES - 1) / pk::PK_WAVES)), dim3(pk::PK_WAVES * 64), 0, 0, d_rois, d_peaks, n_pairs, box,
                        Y, X, Y_, X_, d_shift, (double *)nullptr, d_status);
     PMI_HIP(hipGetLastError());
     PMI_HIP(hipMemcpy(h_shift_yx, d_shift, (size_t)n_pairs * 16, hipMemcpyDeviceToHost));
@@ -416,7 +489,7 @@ int pmi_peak_fit(const double *rois, int64_t n, int box, double *popt, int32_t *
     for (int64_t i = 0; i < n; i++) pk3[(size_t)i * 3 + 2] = 1;
     PMI_HIP(hipMemcpy(d_rois, rois, rb, hipMemcpyHostToDevice));
     PMI_HIP(hipMemcpy(d_peaks, pk3.data(), (size_t)n * 12, hipMemcpyHostToDevice));
-    hipLaunchKernelGGL(pk::peak_fit_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, 0, d_rois, d_peaks, n, box, (int64_t)0,
+    hipLaunchKernelGGL(pk::peak_fit_kernel, dim3((unsigned)((n + pk::PK_WAVES - 1) / pk::PK_WAVES)), dim3(pk::PK_WAVES * 64), 0, 0, d_rois, d_peaks, n, box, (int64_t)0,
                        (int64_t)0, (int64_t)0, (int64_t)0, d_shift, d_popt, d_status);
     PMI_HIP(hipGetLastError());
     PMI_HIP(hipMemcpy(popt, d_popt, (size_t)n * 40, hipMemcpyDeviceToHost));

@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of a tuning variable on the tuning build (picasso_amd/libpicasso_hip_tuning.so: make TUNING=1 objects): usage
-# tools/_r05_ab_env.sh VAR VALUE
+# tools/ab_env.sh VAR VALUE
 export PICASSO_AMD_LIB=$PWD/picasso_amd/libpicasso_hip_tuning.so
 for i in 1 2; do
 for v in off on; do

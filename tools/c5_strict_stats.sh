@@ -1,5 +1,5 @@
 #!/bin/bash
-# config 5: kernel stats of the strict re-fit with and without a tuning variable.  usage: tools/_r05_c5_strict.sh VAR VALUE
+# config 5: kernel stats of the strict re-fit with and without a tuning variable.  usage: tools/c5_strict_stats.sh VAR VALUE
 export TMPDIR=/tmp; export PICASSO_AMD_LIB=$PWD/picasso_amd/libpicasso_hip_tuning.so
 for v in off on; do
   if [ $v = on ]; then export $1=$2; else unset $1; fi

@@ -158,7 +158,7 @@ def test_config5_astigmatic_13x13_and_zfit(be, orc):
 def test_config5_fused_pipeline_on_the_astigmatic_movie(be, orc):
     """Config 5 through the path the benchmark times — pmi_localize_mle_dev with box 13 on the astigmatic movie, then
     zfit — against the oracle on every row, at 3000 frames (~3e5 spots; tools/parity_config5.py runs the same comparison
-    at the full 50 000 frames, profiles/r03_parity_config5.json)."""
+    at the full 50 000 frames, profiles/r03_parity_config5.json, r05_parity_config5.json)."""
     import os
     import sys
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))

@@ -115,10 +115,15 @@ def test_config3_gausslq_and_render(be, orc):
     oth = orc.gausslq(spots, threads=orc.max_threads())
     ref = gausslq.locs_from_fits(pd.DataFrame({"frame": fr, "x": x, "y": y, "net_gradient": ng}), oth, 7, em=False)
     ref = ref.sort_index()          # the reference's quicksort by frame is not stable; undo it (identification order)
-    same = t["x"] == ref["x"].to_numpy()
-    assert same.mean() > 0.98
-    assert np.max(np.abs(t["x"] - ref["x"].to_numpy())) < 1e-3 and np.max(np.abs(t["y"] - ref["y"].to_numpy())) < 1e-3
-    assert np.max(np.abs(t["photons"] - ref["photons"].to_numpy()) / ref["photons"].to_numpy()) < 1e-2
+    # the strict mode (the default) is MINPACK's own arithmetic: every fitted column of every one of the 1e6 rows is the
+    # oracle's bit for bit (the refit mode of round 3 was held to 98 % identical rows and 1e-3 px here)
+    assert be.get_lq_mode() == "strict"
+    for c in ("x", "y", "photons", "bg", "sx", "sy"):
+        want = ref[c].to_numpy()
+        assert np.array_equal(t[c], want, equal_nan=True), (c, int((t[c] != want).sum()))
+    for c in ("lpx", "lpy"):          # Mortensen's precision from those columns (float32 expression order of the kernel): 1e-6 relative
+        want = ref[c].to_numpy()
+        assert np.allclose(t[c], want, rtol=1e-6, atol=0, equal_nan=True), c
     # render what the GPU localized, against the oracle render of the same table
     n, img = be.render_arrays(t["x"], t["y"], 10.0, 0, 0, 512, 512, t["lpx"], t["lpy"], 0.0)
     on, oimg = orc.render(t["x"], t["y"], 10.0, [(0, 0), (512, 512)], t["lpx"], t["lpy"], "gaussian", 0.0)

@@ -461,3 +461,32 @@ def test_bench_refuses_tuning_variables():
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--steps", "1"], env=env, capture_output=True, text=True, timeout=120)
     assert r.returncode != 0 and "tuning variables are set" in (r.stderr + r.stdout) and "PMI_MLE_MODE" in (r.stderr + r.stdout)
     assert r.stdout.strip() == ""          # no JSON line
+
+
+def test_lq_chain_scratch_layouts_are_free_of_bank_conflicts():
+    """The LDS layout of the strict least-squares Jacobian's chain scratch (csrc/lq_jacobian_w.inc: LqwBox<W> and
+    lqw_coff<W>) through the bank model of tools/emul/lds_chain_layout.py (lane groups and bank functions of gfx950's
+    ds_read_b128 / ds_write_b64; the model reproduced SQ_LDS_BANK_CONFLICT of the 7x7 kernel before and after its
+    layout changed): no chain read conflicts for any box, no write conflicts up to 9x9 — and the table the tool carries is
+    the one the kernel is built with."""
+    import importlib.util
+    import os
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("lds_chain_layout", os.path.join(root, "tools", "emul", "lds_chain_layout.py"))
+    sim = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(sim)
+    src = open(os.path.join(root, "picasso_amd", "csrc", "lq_jacobian_w.inc")).read()
+    boxes = {}
+    for w, gs, h, s_expr, g_expr in re.findall(r"LqwBox<(\d+)>\s*\{ static constexpr int GS = (\d+),\s*H = (\d+), S = ([^,]+),\s*G = ([^;]+); \};", src):
+        boxes[int(w)] = (int(gs), int(h), int(eval(s_expr)), int(eval(g_expr)))
+    assert sorted(boxes) == [3, 5, 7, 9, 11, 13, 15, 17, 19, 21]
+    assert boxes == sim.BOX
+    # lqw_coff<7>: 50 c + (0, 0, 2, 6, 10, 12)
+    assert "c < 2 ? 0 : (c == 2 ? 2 : (c == 3 ? 6 : (c == 4 ? 10 : 12)))" in src and sim.COFF7 == [50 * c + e for c, e in enumerate((0, 0, 2, 6, 10, 12))]
+    for w, (gs, h, s, g) in boxes.items():
+        rd_extra, wr_extra = sim.score(w, gs, h, s, g)
+        assert rd_extra == 0, (w, rd_extra)
+        if w <= 9:
+            assert wr_extra == 0, (w, wr_extra)
+        assert 6 * s <= g or w == 7          # the columns of a spot fit its share (7x7: its own offsets, 262 + 50 = 312)

@@ -36,8 +36,9 @@ FIT_BYTES_PER_SPOT_7 = 166.0   # 98 px + 12 id + 56 result
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    # (defaults: half a second of timed steps — long enough for an outside sampler of GPU activity to see the run)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=10000)
     ap.add_argument("--size", type=int, default=512)
     ap.add_argument("--emitters", type=int, default=116, help="emitters per frame (~86%% pass min_ng 5000)")

@@ -182,6 +182,25 @@ def test_gaussmle_strict_mode_is_the_oracle_bit_for_bit(be, orc, box, method):
     assert np.array_equal(g[0].view(np.uint32), o[0].view(np.uint32))
 
 
+@pytest.mark.parametrize("n", [1, 5, 67, 1031])
+@pytest.mark.parametrize("max_it,eps", [(0, 1e-3), (1, 1e-3), (3, 1e-5), (100, 1e-1), (250, 1e-6)])
+def test_gaussmle_strict_mode_at_the_knobs(be, orc, n, max_it, eps):
+    """The all-strict launch (start-value kernel, then lane groups that take their next spot when their fit ends,
+    csrc/gaussmle_strict.hip) at the edges of its bookkeeping: batches smaller than a wavefront's four groups and not a
+    multiple of them, max_it 0 (the start values are the result: no group ever iterates), fits that stop after one step and
+    fits that run long — theta and iteration count of every spot are the oracle's bit for bit, both methods, two boxes."""
+    for box, method in ((7, "sigmaxy"), (13, "sigma")):
+        spots = _adversarial_spots(box, n, 4000 + 7 * n + max_it)
+        o = orc.gaussmle(spots, eps, max_it, method, threads=4)
+        be.set_mle_mode("strict")
+        try:
+            g = be.gaussmle_arrays(spots, eps, max_it, method)
+        finally:
+            be.set_mle_mode("refit")
+        assert np.array_equal(g[3], o[3]), (box, method)
+        assert np.array_equal(g[0].view(np.uint32), o[0].view(np.uint32)), (box, method)
+
+
 @pytest.mark.parametrize("box,method", [(7, "sigmaxy"), (7, "sigma"), (5, "sigmaxy"), (13, "sigmaxy"), (17, "sigma")])
 def test_gaussmle_default_mode_every_row_on_adversarial_spots(be, orc, box, method):
     """The default mode (float32 loop + re-fit of flagged spots) on ill-conditioned input: no row is exempt — equal

@@ -98,6 +98,33 @@ def test_config2_full_size_properties(be, orc):
     del movie
 
 
+def test_fused_pipeline_with_every_spot_in_the_reference_arithmetic(be, orc):
+    """`value_strict` of the bench line: pmi_localize_mle_dev in MLE mode `strict` — identify, then the start-value kernel and
+    the refilling Newton kernel of csrc/gaussmle_strict.hip reading the MOVIE, then the table — on 1500 frames: the
+    identifications are the oracle's and photons / bg / sx / sy / iterations of every row its bits (x and y: theta + the
+    pixel position in float32)."""
+    import torch
+    from picasso_amd import synth
+    F = 1500
+    movie = synth.simulate_movie(F, 512, 512, emitters_per_frame=116, device="cuda", seed=4242)
+    torch.cuda.synchronize()
+    be.set_mle_mode("strict")
+    try:
+        t = _localize_resident(be, movie)
+    finally:
+        be.set_mle_mode("refit")
+    host = movie.cpu().numpy()
+    fr, y, x, ng = orc.identify(host, 5000.0, 7, threads=orc.max_threads())
+    assert len(t["frame"]) == len(fr) > 1.2e5 and np.array_equal(t["frame"], fr.astype(np.uint32)) and np.array_equal(t["net_gradient"], ng)
+    spots = orc.get_spots(host, fr, y, x, 7, CAM)
+    th, cr, ll, it = orc.gaussmle(spots, 1e-3, 100, "sigmaxy", threads=orc.max_threads())
+    assert np.array_equal(t["iterations"], it.astype(np.uint32))
+    for c, k in (("photons", 2), ("bg", 3), ("sx", 4), ("sy", 5)):
+        assert np.array_equal(t[c].view(np.uint32), th[:, k].view(np.uint32)), c
+    assert np.array_equal(t["x"], (th[:, 0] + x - 3).astype(np.float32)) or np.max(np.abs(t["x"] - (th[:, 0] + x - 3))) < 1e-5
+    assert np.array_equal(t["y"], (th[:, 1] + y - 3).astype(np.float32)) or np.max(np.abs(t["y"] - (th[:, 1] + y - 3))) < 1e-5
+
+
 def test_config3_gausslq_and_render(be, orc):
     """gausslq path + Gaussian render at oversampling 10 (BASELINE.json configs[2]) at its FULL size — 10 000
     frames, 1e6 spots — vs the oracle composition (the C restatement of MINPACK lmdif fits them in ~10 s on the

@@ -776,32 +776,33 @@ def test_gausslq_edge_cases(be, orc):
     assert np.array_equal(th[[0, 2]], good)
 
 
-def test_localize_lq_pipeline_on_resident_movie(be, orc, testdata_movie):
-    """identify -> fused cut + lmdif -> 11-column table on device vs oracle fit + host table."""
+@pytest.mark.parametrize("box", [5, 7, 9])
+def test_localize_lq_pipeline_on_resident_movie(be, orc, testdata_movie, box):
+    """identify -> fused cut + lmdif -> 11-column table on device vs oracle fit + host table, on the reference's own test
+    movie: in the strict mode (the default) every fitted column of every row is the oracle's bit for bit (the refit mode
+    of round 3 was held to 98 % identical rows here), the precision columns to float32 rounding."""
     import pandas as pd
     from picasso_amd import gausslq
+    assert be.get_lq_mode() == "strict"
     for gain in (1.0, 2.0):
         cam = {"Baseline": 100.0, "Sensitivity": 0.5, "Gain": gain}
         dm = be.DeviceMovie(testdata_movie)
         try:
-            t = be.localize_lq_device(dm.ptr, dm.dtype, dm.shape, 7, 1500, cam)
+            t = be.localize_lq_device(dm.ptr, dm.dtype, dm.shape, box, 1500, cam)
         finally:
             dm.free()
-        fr, y, x, ng = orc.identify(testdata_movie, 1500, 7)
-        spots = orc.get_spots(testdata_movie, fr, y, x, 7, cam)
+        fr, y, x, ng = orc.identify(testdata_movie, 1500, box)
+        spots = orc.get_spots(testdata_movie, fr, y, x, box, cam)
         oth = orc.gausslq(spots, threads=4)
         ids = pd.DataFrame({"frame": fr, "x": x, "y": y, "net_gradient": ng})
-        ref = gausslq.locs_from_fits(ids, oth, 7, em=gain > 1)
+        ref = gausslq.locs_from_fits(ids, oth, box, em=gain > 1)
         assert list(t) == list(ref.columns)
         assert np.array_equal(t["frame"], ref["frame"].to_numpy())
         assert np.array_equal(t["net_gradient"], ref["net_gradient"].to_numpy())
-        same = np.all(np.stack([t[c] == ref[c].to_numpy() for c in ("x", "y", "photons", "sx", "sy", "bg")]), axis=0)
-        assert same.mean() > 0.98
+        for c in ("x", "y", "photons", "sx", "sy", "bg"):
+            assert np.array_equal(t[c], ref[c].to_numpy(), equal_nan=True), (c, gain)
         for c in ("lpx", "lpy", "ellipticity"):
-            a, b = t[c][same], ref[c].to_numpy()[same]
-            assert np.allclose(a, b, rtol=3e-7, atol=0, equal_nan=True), c
-        assert np.max(np.abs(t["x"] - ref["x"].to_numpy())) < 1e-3
-        assert np.max(np.abs(t["y"] - ref["y"].to_numpy())) < 1e-3
+            assert np.allclose(t[c], ref[c].to_numpy(), rtol=3e-7, atol=0, equal_nan=True), c
 
 
 # ---------------------------------------------------------------------------

@@ -267,8 +267,9 @@ int pmi_gausslq(const float *spots, int64_t N, int box, float *thetas, int32_t *
  *                  test of the fit sees;
  *   PMI_LQ_STRICT  (default) every sum over the residual rows — enorm, qrfac's Householder products, Q^T fvec — in
  *                  MINPACK's sequential order from the first Jacobian on (one chain per column, side by side in the lanes
- *                  of a spot's group): theta, info and nfev are lmdif's on EVERY spot, bit for bit.  1.2x the time of
- *                  REFIT on 7x7 boxes, 1.3x on 5x5, 1.5x on 13x13.
+ *                  of a spot's group): theta, info and nfev are lmdif's on EVERY spot, bit for bit.  Since round 5
+ *                  (the image columns on the lanes, csrc/gausslq_w.hip) also the faster mode up to 9x9 boxes (7x7: 0.8x
+ *                  the time of REFIT); 1.1x REFIT's time at 11x11 and 13x13, 1.8x at 15x15, 2.4x at 21x21.
  * Process-wide; the environment variable PMI_LQ_MODE = fast | refit | strict overrides the mode.                 */
 enum pmi_lq_mode { PMI_LQ_FAST = 0, PMI_LQ_REFIT = 1, PMI_LQ_STRICT = 2 };
 int pmi_gausslq_set_mode(int mode);

@@ -25,12 +25,22 @@ def _env():
     return env
 
 
+def _launch(args, tries=3):
+    """`python -m torch.distributed.run --nproc-per-node=1 ... <args>` on a free port of the loopback; a port that was free
+    when it was picked can be taken by the time the rendezvous store binds it (EADDRINUSE): another port, again."""
+    for attempt in range(tries):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
+               "127.0.0.1", "--master-port", str(_free_port())] + list(args)
+        out = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+        if out.returncode == 0 or "EADDRINUSE" not in out.stderr:
+            break
+    return out
+
+
 def test_rccl_probe_one_rank():
     """tools/rccl_probe.py: nccl (= RCCL) process group, the table all-gather of picasso_amd/dist.py, the
     all-reduce of the sharded undrift, the pipelined shard path — on one rank."""
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tools", "rccl_probe.py")]
-    out = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    out = _launch([os.path.join(ROOT, "tools", "rccl_probe.py")])
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "rccl probe ok: world 1" in out.stdout
 
@@ -76,11 +86,7 @@ def test_bench_under_the_launcher_uses_the_native_all_gather(serial):
     torch.distributed's RCCL in the same process — double-buffered on a side stream, and unoverlapped (--serial-gather).
     bench.py checks the gathered table against the local one; the line carries the per-rank compute / gather split."""
     small = ["--steps", "50", "--warmup", "2", "--frames", "400", "--cpu-seconds", "0", "--profile-steps", "0", "--strict-steps", "0"]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small
-    if serial:
-        cmd.append("--serial-gather")
-    out = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    out = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "1"] + small + (["--serial-gather"] if serial else []))
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert line["steps"] == 50 and line["n_gpus"] == 1
@@ -99,9 +105,7 @@ def test_bench_strong_scaling_shares_the_frames():
     """`bench.py --scaling strong`: --frames is the whole job, each rank localizes frames / N of it (one rank here: all of
     it), the line says "strong" and its localization count is the whole job's."""
     small = ["--steps", "3", "--warmup", "1", "--frames", "300", "--cpu-seconds", "0", "--profile-steps", "0", "--strict-steps", "0"]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr",
-           "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--scaling", "strong"] + small
-    out = subprocess.run(cmd, cwd=ROOT, env=_env(), capture_output=True, text=True, timeout=600)
+    out = _launch([os.path.join(ROOT, "bench.py"), "--gpus", "1", "--scaling", "strong"] + small)
     assert out.returncode == 0, out.stderr[-2000:]
     line = json.loads([ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")][-1])
     assert line["scaling"] == "strong" and line["config"]["frames"] == 300 and line["config"]["localizations_total"] > 20000

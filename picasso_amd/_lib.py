@@ -189,8 +189,25 @@ def bound_to():
     return getattr(_tls, "key", None)
 
 
-def lock():
+def current_key():
+    """(device, bank) the calling thread's library calls use: what it bound itself to, else HIP's current device of
+    the thread and bank 0 (None when no device can be asked, e.g. on a box without a GPU)."""
     key = getattr(_tls, "key", None)
+    if key is not None:
+        return key
+    dev = ctypes.c_int(0)
+    try:
+        if load().pmi_get_device(ctypes.byref(dev)) != PMI_OK:
+            return None
+    except (ImportError, OSError):
+        return None
+    return (int(dev.value), 0)
+
+
+def lock():
+    """One lock per (device, scratch bank): a thread that never bound itself takes the lock of the device it really
+    runs on (bank 0), i.e. the same lock as a lane bound to that device and bank — the two write the same scratch."""
+    key = current_key()
     if key is None:
         return _lock
     with _bound_locks_mu:

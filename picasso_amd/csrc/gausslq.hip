@@ -707,8 +707,9 @@ static int lq_mode_now()
 // statistics of the calling thread's last fit: a device buffer of its own ([0] spots fitted again, [1..7] why), read when asked for
 static thread_local const unsigned *g_lq_stats[2] = {nullptr, nullptr};          // [1]: the second frame range of a fused call
 static thread_local unsigned g_lq_stats_generation = 0;
-static thread_local hipEvent_t g_lq_stats_done[PMI_MAX_DEVICES][2] = {};       // recorded after the statistics kernel of the fit: the caller's stream may be gone when they are read
+static thread_local hipEvent_t g_lq_stats_done[2] = {nullptr, nullptr};       // recorded after the statistics kernel of the fit (the caller's stream may be gone when they are read); the events belong to the device's side lane (runtime.hip), not to this thread
 static thread_local int g_lq_stats_device = 0;
+static thread_local int g_lq_stats_bank = 0;      // and the scratch bank they were taken from
 static thread_local bool g_lq_stats_second = false;                               // the fit being queued is that second range
 static thread_local int g_lq_rounds[2] = {0, 0};
 
@@ -820,12 +821,14 @@ static int launch(Params p, hipStream_t s)
         PMI_HIP(hipGetLastError());
     }
     g_lq_stats_device = current_device();
-    hipEvent_t &done = g_lq_stats_done[g_lq_stats_device][g_lq_stats_second ? 1 : 0];
-    if (!done) PMI_HIP(hipEventCreateWithFlags(&done, hipEventDisableTiming));
+    g_lq_stats_bank = scratch_user_bank();
+    SideLane *lane = nullptr;
+    { const int rc_lane = side_lane(1, &lane); if (rc_lane != PMI_OK) return rc_lane; }
+    hipEvent_t done = g_lq_stats_done[g_lq_stats_second ? 1 : 0] = lane->stats_done[g_lq_stats_second ? 1 : 0];
     PMI_HIP(hipEventRecord(done, s));
     g_lq_stats[g_lq_stats_second ? 1 : 0] = stats;
     if (!g_lq_stats_second) g_lq_stats[1] = nullptr;
-    g_lq_stats_generation = scratch_generation_of(g_lq_stats_device, SCR_LQ_STATS);
+    g_lq_stats_generation = scratch_generation_of(g_lq_stats_device, g_lq_stats_bank, SCR_LQ_STATS);
     g_lq_rounds[0] = rounds; g_lq_rounds[1] = no_strict ? 0 : 1;
     return PMI_OK;
 }
@@ -833,11 +836,11 @@ static int launch(Params p, hipStream_t s)
 static int read_lq_stats(unsigned (&h)[16])
 {
     for (unsigned &v : h) v = 0;
-    if (!g_lq_stats[0] || g_lq_stats_generation != scratch_generation_of(g_lq_stats_device, SCR_LQ_STATS)) return PMI_OK;      // no fit yet, or its buffers are gone
+    if (!g_lq_stats[0] || g_lq_stats_generation != scratch_generation_of(g_lq_stats_device, g_lq_stats_bank, SCR_LQ_STATS)) return PMI_OK;      // no fit yet, or its buffers are gone
     for (int k = 0; k < 2; k++) {
         if (!g_lq_stats[k]) continue;
         unsigned part[16];
-        PMI_HIP(hipEventSynchronize(g_lq_stats_done[g_lq_stats_device][k]));
+        PMI_HIP(hipEventSynchronize(g_lq_stats_done[k]));
         PMI_HIP(hipMemcpy(part, g_lq_stats[k], 64, hipMemcpyDeviceToHost));
         for (int i = 0; i < 16; i++) h[i] += part[i];
     }
@@ -1016,8 +1019,6 @@ int pmi_locs_from_fits_lq_dev(const int32_t *d_frame, const int32_t *d_y, const 
 
 namespace pmi {
 namespace lq {
-struct SideLane { hipStream_t s2 = nullptr; hipEvent_t ev_start = nullptr, ev_scan_a = nullptr, ev_b = nullptr; };
-static thread_local SideLane g_lq_side_of[PMI_MAX_DEVICES];      // per device the thread has used (streams and events belong to a device)
 // rows: [0] rows of A to fit, [1] rows of B to fit, [2] rows of A for the table, [3] rows of B for the table, [4] row offset of B
 __global__ void lq_rows_a_kernel(const int64_t *__restrict__ n_a, int64_t cap, int64_t *__restrict__ rows) { rows[0] = *n_a > cap ? 0 : *n_a; }
 __global__ void lq_rows_b_kernel(const int64_t *__restrict__ n_a, const int64_t *__restrict__ n_b, int64_t cap, int64_t *__restrict__ rows,
@@ -1078,20 +1079,16 @@ int pmi_localize_lq_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, in
         PMI_HIP(hipGetLastError());
         return PMI_OK;
     }
-    lq::SideLane &side = lq::g_lq_side_of[current_device()];
-    if (!side.s2) {
-        PMI_HIP(hipStreamCreateWithFlags(&side.s2, hipStreamNonBlocking));
-        PMI_HIP(hipEventCreateWithFlags(&side.ev_start, hipEventDisableTiming));
-        PMI_HIP(hipEventCreateWithFlags(&side.ev_scan_a, hipEventDisableTiming));
-        PMI_HIP(hipEventCreateWithFlags(&side.ev_b, hipEventDisableTiming));
-    }
+    SideLane *side_p = nullptr;
+    if ((rc = side_lane(1, &side_p)) != PMI_OK) return rc;
+    SideLane &side = *side_p;
     const int64_t mid = lo + nf / 2 - 1;                      // A = [lo, mid], B = [mid + 1, hi]
     if ((rc = scratch(SCR_IDS, ids_bytes, &ptr)) != PMI_OK) return rc;
     const Ids a = carve(ptr);
     PMI_HIP(hipEventRecord(side.ev_start, s));
     PMI_HIP(hipStreamWaitEvent(side.s2, side.ev_start, 0));
     struct Join {       // whatever happens, the caller's stream is ordered after the side stream before this call returns
-        lq::SideLane &sd; hipStream_t st; bool done = false;
+        SideLane &sd; hipStream_t st; bool done = false;
         ~Join() { if (!done) { (void)hipEventRecord(sd.ev_b, sd.s2); (void)hipStreamWaitEvent(st, sd.ev_b, 0); } }
     } join{side, s};
     // ---- range A on the caller's stream

@@ -615,6 +615,7 @@ static double g_mle_margin = 0.001;
 static thread_local const unsigned *g_last_stats[2] = {nullptr, nullptr};      // [1]: the second frame range of a fused call
 static thread_local unsigned g_last_stats_generation = 0;
 static thread_local int g_last_stats_device = 0;                                  // the device those buffers live on
+static thread_local int g_last_stats_bank = 0;      // and the scratch bank they were taken from
 static thread_local bool g_stats_second = false;                                  // the fit being queued is that second range
 
 __global__ void zero_words_kernel(unsigned *__restrict__ a, int na, unsigned *__restrict__ b, int nb)
@@ -806,7 +807,8 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     g_last_stats[g_stats_second ? 1 : 0] = stats;
     if (!g_stats_second) g_last_stats[1] = nullptr;
     g_last_stats_device = current_device();
-    g_last_stats_generation = scratch_generation_of(g_last_stats_device, SCR_STATS);
+    g_last_stats_bank = scratch_user_bank();
+    g_last_stats_generation = scratch_generation_of(g_last_stats_device, g_last_stats_bank, SCR_STATS);
     tm.stop();
     return PMI_OK;
 }
@@ -814,7 +816,7 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
 static int read_last_stats(unsigned (&h)[16], hipStream_t s)
 {
     for (unsigned &v : h) v = 0;
-    if (!g_last_stats[0] || g_last_stats_generation != scratch_generation_of(g_last_stats_device, SCR_STATS)) return PMI_OK;      // no fit yet, or its buffers are gone
+    if (!g_last_stats[0] || g_last_stats_generation != scratch_generation_of(g_last_stats_device, g_last_stats_bank, SCR_STATS)) return PMI_OK;      // no fit yet, or its buffers are gone
     PMI_HIP(hipStreamSynchronize(s));
     for (const unsigned *src : g_last_stats) {
         if (!src) continue;
@@ -1082,8 +1084,6 @@ int pmi_locs_from_fits_dev(const int32_t *d_frame, const int32_t *d_y, const int
 namespace pmi {
 static bool g_localize_handoff = false;
 static bool g_localize_defer = true;
-struct SideLane { hipStream_t s2 = nullptr; hipEvent_t ev_start = nullptr, ev_scan_a = nullptr, ev_b = nullptr; };
-static thread_local SideLane g_side_of[PMI_MAX_DEVICES];       // streams and events belong to a device: one lane per device the thread has used
 
 // rows: [0] rows of A to fit, [1] rows of B to fit, [2] rows of A for the table, [3] rows of B for the table, [4] row offset of B
 __global__ void range_rows_a_kernel(const int64_t *__restrict__ n_a, int64_t cap, int64_t *__restrict__ rows)
@@ -1255,13 +1255,9 @@ int pmi_localize_mle_dev(const void *d_movie, int dtype, int64_t F, int64_t Y, i
         PMI_HIP(hipGetLastError());
         return PMI_OK;
     }
-    SideLane &side = g_side_of[current_device()];
-    if (!side.s2) {
-        PMI_HIP(hipStreamCreateWithFlags(&side.s2, hipStreamNonBlocking));
-        PMI_HIP(hipEventCreateWithFlags(&side.ev_start, hipEventDisableTiming));
-        PMI_HIP(hipEventCreateWithFlags(&side.ev_scan_a, hipEventDisableTiming));
-        PMI_HIP(hipEventCreateWithFlags(&side.ev_b, hipEventDisableTiming));
-    }
+    SideLane *side_p = nullptr;
+    if ((rc = side_lane(0, &side_p)) != PMI_OK) return rc;
+    SideLane &side = *side_p;
     const int64_t mid = lo + nf / 2 - 1;                      // A = [lo, mid], B = [mid + 1, hi]
     // counts of the two ranges and the row bookkeeping live in the OUTER bank (both streams read them)
     if ((rc = scratch(SCR_IDS, ids_bytes, &ptr)) != PMI_OK) return rc;

@@ -36,6 +36,7 @@ int hip_fail(hipError_t e, const char *what, const char *file, int line);
 // INTEGRATION.md).  Settings (the modes, the number of frame ranges) stay process-wide.
 constexpr int PMI_MAX_DEVICES = 16;
 int current_device();                 // the calling thread's device, 0 if it cannot be asked; pmi_set_device refuses >= PMI_MAX_DEVICES
+int checked_device(int *device);      // the same with a status: PMI_ERR_HIP / PMI_ERR_ARG (a device the library keeps no state for) instead of device 0
 int device_cu_count();                // compute units of that device (cached per device)
 
 // Grow-only scratch arena per device.  slot = purpose id.
@@ -62,8 +63,16 @@ int scratch(int slot, size_t bytes, void **ptr);
 int scratch_release_all();
 int scratch_enter_inner();           // -> the bank to hand back to scratch_leave_inner
 void scratch_leave_inner(int was);
-unsigned scratch_generation(int slot);      // of the current device; bumped whenever a buffer of that slot (any bank) is released: pointers into it taken before are stale
-unsigned scratch_generation_of(int device, int slot);
+unsigned scratch_generation(int slot);      // of the current device and the calling thread's bank; bumped whenever a buffer of that slot (the bank or its inner bank) is released: pointers into it taken before are stale
+unsigned scratch_generation_of(int device, int user_bank, int slot);
+int scratch_user_bank();                    // the bank pmi_scratch_bank selected for the calling thread (its inner bank counts as the same)
+// The side stream a fused call runs its second frame range on, with the events that join it to the caller's stream, and the
+// events recorded behind the statistics kernels of a fit.  Process-wide, one per device, user bank and pipeline
+// (0: MLE, 1: least squares), created on first use with that device current and kept for the life of the process: host
+// threads come and go (localize_streamed starts lane threads per call), what belongs to a device does not.  Two threads on
+// one device and bank are serialised by the caller (picasso_amd/_lib.py lock()), as for the scratch buffers.
+struct SideLane { hipStream_t s2 = nullptr; hipEvent_t ev_start = nullptr, ev_scan_a = nullptr, ev_b = nullptr, stats_done[2] = {nullptr, nullptr}; };
+int side_lane(int pipeline, SideLane **lane);
 // Fused pipelines: *d_rows = *d_total if it fits the caller's capacity, else 0 (the identification columns were not
 // written; the caller sees *d_total > cap and resubmits), so that the fit stages never follow stale rows.
 int rows_to_fit(const int64_t *d_total, int64_t cap, const int64_t **d_rows, hipStream_t s);

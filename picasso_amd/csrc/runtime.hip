@@ -38,16 +38,36 @@ static ScratchBuf g_scratch_banks[PMI_MAX_DEVICES][SCR_BANKS][SCR_NUM];      // 
 // the bank is a property of the calling thread: two host threads that drive two streams select a bank each
 // (pmi_scratch_bank) and never see each other's records or fit state
 static thread_local int g_scratch_bank = 0;
-static std::mutex g_scratch_mu;
-static unsigned g_scratch_generation[PMI_MAX_DEVICES][SCR_NUM] = {};       // per device and slot: a record in one slot outlives the growth of another
-unsigned scratch_generation_of(int device, int slot) { std::lock_guard<std::mutex> lk(g_scratch_mu); return g_scratch_generation[device][slot]; }
-unsigned scratch_generation(int slot) { return scratch_generation_of(current_device(), slot); }
+static std::mutex g_scratch_mu[PMI_MAX_DEVICES];      // one per device: growth on one device (a device-wide synchronise) does not stall the others' lanes
+// per device, USER bank (a bank and its inner bank count as one) and slot: a record in one slot outlives the growth of
+// another, and the statistics of a lane on bank 0 outlive growth in the other lane of the same device
+static unsigned g_scratch_generation[PMI_MAX_DEVICES][SCR_USER_BANKS][SCR_NUM] = {};
+int scratch_user_bank() { return g_scratch_bank % SCR_USER_BANKS; }
+unsigned scratch_generation_of(int device, int user_bank, int slot)
+{
+    std::lock_guard<std::mutex> lk(g_scratch_mu[device]);
+    return g_scratch_generation[device][user_bank % SCR_USER_BANKS][slot];
+}
+unsigned scratch_generation(int slot) { return scratch_generation_of(current_device(), scratch_user_bank(), slot); }
 
 int current_device()
 {
+    // pmi_set_device refuses devices >= PMI_MAX_DEVICES; a thread put on one behind the library's back (hipSetDevice, torch)
+    // is refused by checked_device() at the head of every scratch() call instead of being aliased to device 0's state
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= PMI_MAX_DEVICES) return 0;
     return dev;
+}
+int checked_device(int *device)
+{
+    int dev = 0;
+    PMI_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev >= PMI_MAX_DEVICES) {
+        set_error("the calling thread is on device %d: the library keeps state for devices 0 ... %d", dev, PMI_MAX_DEVICES - 1);
+        return PMI_ERR_ARG;
+    }
+    *device = dev;
+    return PMI_OK;
 }
 int device_cu_count()
 {
@@ -63,11 +83,13 @@ int device_cu_count()
 
 int scratch(int slot, size_t bytes, void **ptr)
 {
-    const int dev = current_device();
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
+    int dev = 0;
+    const int rc = checked_device(&dev);
+    if (rc != PMI_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_scratch_mu[dev]);
     ScratchBuf &b = g_scratch_banks[dev][g_scratch_bank][slot];
     if (b.bytes < bytes) {
-        if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; g_scratch_generation[dev][slot]++; }
+        if (b.p) { PMI_HIP(hipDeviceSynchronize()); PMI_HIP(hipFree(b.p)); b.p = nullptr; b.bytes = 0; g_scratch_generation[dev][scratch_user_bank()][slot]++; }
         size_t want = bytes + bytes / 4 + 4096;   // headroom so repeated calls stop reallocating
         PMI_HIP(hipMalloc(&b.p, want));
         b.bytes = want;
@@ -80,13 +102,14 @@ int scratch_release_all()
 {
     // every device's buffers: each is synchronised and freed with its own device current, the caller's device is restored
     const int was = current_device();
-    std::lock_guard<std::mutex> lk(g_scratch_mu);
     int rc = PMI_OK;
     for (int dev = 0; dev < PMI_MAX_DEVICES; dev++) {
+        std::lock_guard<std::mutex> lk(g_scratch_mu[dev]);
         bool any = false;
         for (auto &bank : g_scratch_banks[dev])
             for (auto &b : bank) any = any || b.p;
-        for (unsigned &g : g_scratch_generation[dev]) g++;
+        for (auto &bank : g_scratch_generation[dev])
+            for (unsigned &g : bank) g++;
         if (!any) continue;
         if (hipSetDevice(dev) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { rc = PMI_ERR_HIP; set_error("pmi_release_scratch: device %d cannot be synchronised", dev); continue; }
         for (auto &bank : g_scratch_banks[dev])
@@ -105,6 +128,29 @@ int scratch_select_bank(int bank)
 // the inner bank of the calling thread's bank (and back): scratch of the second frame range of a fused call
 int scratch_enter_inner() { const int was = g_scratch_bank; g_scratch_bank = was % SCR_USER_BANKS + SCR_USER_BANKS; return was; }
 void scratch_leave_inner(int was) { g_scratch_bank = was; }
+
+static SideLane g_side_lanes[PMI_MAX_DEVICES][SCR_USER_BANKS][2];
+static std::mutex g_side_mu;
+int side_lane(int pipeline, SideLane **lane)
+{
+    int dev = 0;
+    const int rc = checked_device(&dev);
+    if (rc != PMI_OK) return rc;
+    std::lock_guard<std::mutex> lk(g_side_mu);
+    SideLane &sd = g_side_lanes[dev][scratch_user_bank()][pipeline ? 1 : 0];
+    if (!sd.s2) {
+        hipStream_t s2 = nullptr;
+        PMI_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        PMI_HIP(hipEventCreateWithFlags(&sd.ev_start, hipEventDisableTiming));
+        PMI_HIP(hipEventCreateWithFlags(&sd.ev_scan_a, hipEventDisableTiming));
+        PMI_HIP(hipEventCreateWithFlags(&sd.ev_b, hipEventDisableTiming));
+        PMI_HIP(hipEventCreateWithFlags(&sd.stats_done[0], hipEventDisableTiming));
+        PMI_HIP(hipEventCreateWithFlags(&sd.stats_done[1], hipEventDisableTiming));
+        sd.s2 = s2;                        // last: a lane with a stream is complete
+    }
+    *lane = &sd;
+    return PMI_OK;
+}
 
 __global__ void rows_to_fit_kernel(const int64_t *__restrict__ total, int64_t cap, int64_t *__restrict__ rows)
 {

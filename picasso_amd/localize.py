@@ -547,8 +547,7 @@ class _DeviceLane:
         self.work = None
 
     def bind(self):
-        if self.device is not None:
-            _lib.bind_thread(self.device, self.bank)
+        _lib.bind_thread(self.device, self.bank)
 
     def open(self):
         self.stream = backend.DeviceStream()
@@ -577,7 +576,7 @@ class _DeviceLane:
 
 def _run_lanes(movie, chunks, lanes, progress_callback=None, abort_callback=None, frames=None):
     """The scheduler of `localize_streamed`: chunk i = frames [c0, c1) goes to lane i % len(lanes).  Every lane has one
-    host thread (the calling thread when there is one lane) that uploads the lane's next chunk — a blocking copy, the GIL
+    host thread that uploads the lane's next chunk — a blocking copy, the GIL
     released — while a worker thread of the lane runs identify -> cut + fit -> table on the previous one in the lane's other
     staging allocation.  Tables come back in frame order whatever order the lanes finish in (what the reference's worker
     threads give, picasso/localize.py:424-454 + the sort at :478).  `progress_callback(n)`: frames handed to a device so
@@ -625,14 +624,13 @@ def _run_lanes(movie, chunks, lanes, progress_callback=None, abort_callback=None
             if opened:
                 lane.close()
 
-    if len(lanes) == 1:
-        lane_loop(0, lanes[0])
-    else:
-        threads = [threading.Thread(target=lane_loop, args=(li, lane), name=f"pmi-lane-{li}") for li, lane in enumerate(lanes)]
-        for t in threads:
-            t.start()
-        for t in threads:
-            t.join()
+    # every lane on a thread of its own, one lane too: binding a thread to a device and bank is sticky, and the calling
+    # thread's device, bank and lock key must be what they were when this returns
+    threads = [threading.Thread(target=lane_loop, args=(li, lane), name=f"pmi-lane-{li}") for li, lane in enumerate(lanes)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
     if errors:
         raise errors[0]
     if stop.is_set():
@@ -711,11 +709,16 @@ def _resolve_devices(devices):
 
 
 def _lanes_for(devices, n_chunks: int):
-    """(device, scratch bank) of every lane.  None -> one lane on the calling thread's device (no binding: (None, 0));
+    """(device, scratch bank) of every lane.  None -> one lane on the calling thread's device and bank (what it bound
+    itself to, else HIP's current device of the thread, bank 0) — named explicitly, so the lane's threads bind to it;
     "all" -> every visible device; a list -> as given, a device named twice on banks 0 and 1 (a third time is an error:
     the library has two banks per device)."""
     if devices is None:
-        return [(None, 0)]
+        key = _lib.current_key()
+        if key is None:
+            _lib.require_gpu()
+            key = (0, 0)
+        return [key]
     if isinstance(devices, str):
         if devices != "all":
             raise ValueError("devices must be None, 'all' or a list of device indices")

@@ -130,6 +130,34 @@ def test_gaussmle_vs_goldens_and_oracle(be, orc, name, method):
         assert np.array_equal(th[:, 4], th[:, 5])
 
 
+NBP_VARIANTS = [("", 1e-3, 100), ("_it3", 1e-3, 3), ("_eps5", 1e-5, 100)]
+
+
+@pytest.mark.parametrize("name", MLE_DATASETS)
+@pytest.mark.parametrize("method", ["sigmaxy", "sigma"])
+def test_gaussmle_vs_numba_promotion_goldens(be, name, method):
+    """The device against the reference ITSELF under numba's typing (tests/golden/*_nbp.npz: the reference's gaussmle.py
+    executed with its jitted arithmetic typed by numba's rules, tests/golden/_nbemu.py) — no oracle in between and no loose
+    row: `strict` = theta and iterations bit for bit on every row (degenerate7 included), the default mode = the same
+    iteration count on every row and the north-star tolerance wherever the reference converged."""
+    d, g = golden("gaussmle_" + name), golden("gaussmle_" + name + "_nbp")
+    for tag, eps, max_it in NBP_VARIANTS:
+        key = method + tag
+        if key + "_theta" not in g.files:
+            continue
+        gth, git = g[key + "_theta"], g[key + "_iterations"]
+        be.set_mle_mode("strict")
+        try:
+            th, cr, ll, it = be.gaussmle_arrays(d["spots"], eps, max_it, method)
+        finally:
+            be.set_mle_mode("refit")
+        assert np.array_equal(it, git), (name, key)
+        same = np.array([np.array_equal(a, b, equal_nan=True) for a, b in zip(th, gth)])
+        assert same.all(), (name, key, np.flatnonzero(~same)[:8])
+        th, cr, ll, it = be.gaussmle_arrays(d["spots"], eps, max_it, method)
+        _check_fit(th, cr, ll, it, gth, g[key + "_crlb"], g[key + "_loglik"], git, (), max_it)
+
+
 @pytest.mark.parametrize("box", [5, 7, 9, 11, 13, 15, 17, 19, 21])
 def test_gaussmle_all_boxes_vs_oracle(be, orc, box):
     from math import erf, sqrt
@@ -606,6 +634,17 @@ def test_gausslq_vs_oracle_and_goldens(be, orc, name):
     assert np.max(np.abs(th[:, :2] - g["theta"][:, :2])) < 5e-3
     assert np.max(np.abs(th[:, 4:] - g["theta"][:, 4:])) < 5e-3
     assert np.max(np.abs(th[:, 2] - g["theta"][:, 2]) / g["theta"][:, 2]) < 5e-3
+
+
+@pytest.mark.parametrize("name", ["conftest_clean", "conftest_noisy", "testdata_real", "poisson7", "poisson13"])
+def test_gausslq_vs_numba_promotion_goldens(be, name):
+    """The device (strict, the default) against the reference's own gausslq.fit_spot under numba's typing — start values
+    from float64 moment sums, scipy's MINPACK over the numba-typed residual function (tests/golden/*_nbp.npz): the
+    float32 theta the reference stores (gausslq.py:275) is EQUAL on every row, no oracle in between."""
+    s, g = golden("gausslq_" + name), golden("gausslq_" + name + "_nbp")
+    assert be.get_lq_mode() == "strict"
+    th = be.gausslq_arrays(s["spots"])
+    assert np.array_equal(th, g["theta"].astype(np.float32))
 
 
 @pytest.mark.parametrize("box", [3, 5, 7, 9, 11, 13, 15, 17, 19, 21])

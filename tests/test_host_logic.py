@@ -256,10 +256,14 @@ def test_localize_streamed_chunking_logic(monkeypatch, testdata_movie):
         def destroy(self): pass
         def free(self): pass
 
+    from picasso_amd import _lib
+    bound = []
     monkeypatch.setattr(backend, "DeviceMovie", FakeStage)
     monkeypatch.setattr(backend, "DeviceStream", Dummy)
     monkeypatch.setattr(backend, "DeviceWorkspace", Dummy)
     monkeypatch.setattr(backend, "localize_mle_device", fake_device)
+    monkeypatch.setattr(_lib, "current_key", lambda: (0, 0))            # devices=None: the caller's device and bank ...
+    monkeypatch.setattr(_lib, "bind_thread", lambda dev, bank=0: bound.append((dev, bank)))   # ... bound in the lane's threads
     mov = np.ascontiguousarray(testdata_movie)
     cam = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
     params = {"Min. Net Gradient": 3000, "Box Size": 7}
@@ -348,11 +352,11 @@ def test_streamed_scheduler_deals_chunks_over_lanes_in_frame_order():
         assert lane.ran == [c0 for i, (c0, _) in enumerate(chunks) if i % 3 == li]
         assert [k for k, _ in lane.uploads] == [n & 1 for n in range(len(lane.uploads))]
     assert len({t for lane in lanes for t in lane.bound}) == 6                 # no thread shared between lanes
-    # one lane: everything in the calling thread + one worker
+    # one lane: a lane thread + one worker as well — binding is sticky, so never the calling thread
     solo = FakeLane(9)
     parts = localize._run_lanes(movie, chunks, [solo])
     assert pd.concat(parts, ignore_index=True)["frame"].tolist() == list(range(F))
-    assert threading.get_ident() in solo.bound and len(solo.bound) == 2
+    assert threading.get_ident() not in solo.bound and len(solo.bound) == 2
     # abort after the fourth chunk has been handed out: None, every lane closed
     lanes = [FakeLane(0, 0.001), FakeLane(1, 0.001)]
     asked = [0]
@@ -391,17 +395,64 @@ def test_install_fused_and_default_devices(monkeypatch):
 
 
 def test_streamed_lanes_for_devices(monkeypatch):
-    """`devices=` of localize_streamed -> (device, scratch bank) lanes: None keeps the calling thread's device unbound, a
+    """`devices=` of localize_streamed -> (device, scratch bank) lanes: None names the calling thread's own device and bank
+    (what it bound itself to, else the thread's current device, bank 0) so that the lane's threads bind to it, a
     device named twice gets the two banks the library has per device, a third time / an absent device is refused."""
     from picasso_amd import _lib
     monkeypatch.setattr(_lib, "device_count", lambda: 4)
-    assert localize._lanes_for(None, 7) == [(None, 0)]
+    monkeypatch.setattr(_lib, "current_key", lambda: (2, 1))
+    assert localize._lanes_for(None, 7) == [(2, 1)]
     assert localize._lanes_for("all", 7) == [(0, 0), (1, 0), (2, 0), (3, 0)]
     assert localize._lanes_for([2, 0, 2], 7) == [(2, 0), (0, 0), (2, 1)]
     assert localize._lanes_for([0, 1, 2, 3], 2) == [(0, 0), (1, 0)]             # no more lanes than chunks
     for bad in ([0, 0, 0], [4], [-1], [], "gpu"):
         with pytest.raises(ValueError):
             localize._lanes_for(bad, 7)
+
+
+def test_lock_is_keyed_by_device_and_bank(monkeypatch):
+    """One lock per (device, scratch bank) whether the thread bound itself or not: an unbound thread on device 0 and a
+    lane bound to (0, 0) write the same scratch buffers and must serialise; (0, 1) and (1, 0) run beside them."""
+    import threading
+    from picasso_amd import _lib
+    monkeypatch.setattr(_lib, "_tls", threading.local())
+    monkeypatch.setattr(_lib, "_bound_locks", {})
+
+    class L:
+        @staticmethod
+        def pmi_get_device(ref):
+            ref._obj.value = 0
+            return 0
+    monkeypatch.setattr(_lib, "load", lambda: L)
+    unbound = _lib.lock()
+    assert _lib.current_key() == (0, 0)
+    got = {}
+
+    def bound(key):
+        _lib._tls.key = key
+        got[key] = _lib.lock()
+    for key in ((0, 0), (0, 1), (1, 0)):
+        t = threading.Thread(target=bound, args=(key,)); t.start(); t.join()
+    assert got[(0, 0)] is unbound and got[(0, 1)] is not unbound and got[(1, 0)] is not unbound
+    assert _lib.bound_to() is None                      # the lane threads' binding did not leak into this thread
+
+
+def test_run_lanes_leaves_the_calling_thread_unbound():
+    """A single lane runs on a thread of its own too: bind() is sticky per thread, and the caller's device / bank / lock
+    key must be what they were."""
+    import threading
+    main = threading.get_ident()
+    seen = []
+
+    class Lane:
+        def bind(self): seen.append(threading.get_ident())
+        def open(self): pass
+        def upload(self, k, chunk): pass
+        def run(self, k, c0): return pd.DataFrame({"frame": np.array([c0], np.uint32)})
+        def close(self): pass
+    parts = localize._run_lanes(np.zeros((6, 4, 4), np.uint16), [(0, 3), (3, 6)], [Lane()])
+    assert [int(p["frame"][0]) for p in parts] == [0, 3]
+    assert seen and main not in seen
 
 
 def test_picks_and_locs_to_identifications_match_reference():

@@ -469,11 +469,13 @@ int identify_impl(const void *d_movie, int dtype, int64_t F, int64_t Y, int64_t 
         p.gate = nullptr;
         const bool wide = dtype == PMI_U32 || dtype == PMI_I32 || dtype == PMI_F32;
         static const bool no_narrow = tuning_env("PMI_IDENTIFY_NO_NARROW") != nullptr;
-        if (rc == PMI_OK && !fast && dtype == PMI_F32 && !no_narrow) {
+        if (rc == PMI_OK && !fast && wide && !no_narrow) {
             // float32 movies, whatever they hold: the packed scan on 16-bit keys it builds from the float32 rows as it loads
             // them, every exact decision on the float32 pixels — one pass over 4 bytes per pixel (a movie that holds 16-bit
-            // counts used to be narrowed to a uint16 copy first: 8 bytes moved per pixel, 2.3 against 3.2 TB/s of float32)
-            rc = launch_scan_u16_fast(d_movie, PMI_F32, Y, X, p.y0, p.x0, p.cy, p.cx, f_lo, label_offset, p.nframes, box, min_ng,
+            // counts used to be narrowed to a uint16 copy first: 8 bytes moved per pixel, 2.3 against 3.2 TB/s of float32).
+            // 32-bit integer movies (round 6): the same scan with the reference's cast to float32 (localize.py:332) in front
+            // of the keys and of every exact read; frames too narrow for one row range per lane set keep the routes below.
+            rc = launch_scan_u16_fast(d_movie, dtype, Y, X, p.y0, p.x0, p.cy, p.cx, f_lo, label_offset, p.nframes, box, min_ng,
                                       d_tab, recs, cap, d_total, count, s, &fast, nullptr, nullptr, nullptr, 0u, false,
                                       (const float *)d_movie, 0);
         }

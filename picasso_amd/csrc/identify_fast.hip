@@ -78,7 +78,20 @@ __device__ __forceinline__ u32 pk_sub_sat(u32 a, u32 b)
 //           net gradient, the threshold — reads the float32 pixels.  Equal keys do not mean equal pixels, so the neighbour
 //           rule that drops the right-hand / lower one of two equal candidates does not apply; the floor is computed from
 //           the lower edges of the keys' buckets and turned back into a key (conservative on both sides).
-enum { PT_U16 = 0, PT_U8 = 1, PT_I16 = 2, PT_KEY = 3 };
+//   PT_KEY_I32 / PT_KEY_U32  32-bit integer movies (round 6): the reference casts every frame to float32 before it looks at it
+//           (picasso/localize.py:332), so these are PT_KEY with one conversion per pixel in front — v_cvt_f32_i32 / _u32 as
+//           the row is loaded and wherever a pixel is read for an exact decision.  (They used to go through a uint16 copy when
+//           they held 16-bit counts — 2.4 TB/s — and through the generic LDS kernel otherwise — 0.4 TB/s.)
+enum { PT_U16 = 0, PT_U8 = 1, PT_I16 = 2, PT_KEY = 3, PT_KEY_I32 = 4, PT_KEY_U32 = 5 };
+constexpr bool pt_is_key(int PT) { return PT >= PT_KEY; }
+// the float32 the reference sees for a 4-byte pixel of a key scan
+template <int PT> __device__ __forceinline__ float wide_px(float raw)
+{
+    if constexpr (PT == PT_KEY_I32) return (float)(int32_t)__float_as_uint(raw);
+    else if constexpr (PT == PT_KEY_U32) return (float)__float_as_uint(raw);
+    else return raw;
+}
+template <int PT> __device__ __forceinline__ uint32_t wide_bits(uint32_t raw) { return __float_as_uint(wide_px<PT>(__uint_as_float(raw))); }
 __host__ __device__ __forceinline__ uint32_t key_image(uint32_t bits) { return (bits & 0x80000000u) ? ~bits : (bits | 0x80000000u); }
 __device__ __forceinline__ unsigned key_of_float(float f) { return key_image(__float_as_uint(f)) >> 16; }
 // a lower bound of every float32 whose key is k: the smallest of them — or, where that pattern is a NaN (the buckets that hold
@@ -92,6 +105,8 @@ __device__ __forceinline__ float key_lower_edge(unsigned k)
 template <int PT> struct Px { typedef uint16_t T; };
 template <> struct Px<PT_U8> { typedef uint8_t T; };
 template <> struct Px<PT_KEY> { typedef float T; };
+template <> struct Px<PT_KEY_I32> { typedef float T; };      // (4-byte pixels addressed as float32; wide_px makes the value)
+template <> struct Px<PT_KEY_U32> { typedef float T; };
 // the keys of two float32 pixels as one packed pair (low half: the first)
 __device__ __forceinline__ uint32_t key_pair(uint32_t a, uint32_t b)
 {
@@ -123,6 +138,7 @@ struct FastParams {
     float filt_alpha, filt_t;  // floor filter: a maximum v can only reach min_ng if v > alpha * (minimum above it) + t; t < 0: off
     float filt_kr, filt_kc, filt_krc;   // the same for stencils that wrap through index -1 (row, column, both): v > k * cfloor + t
     int filt_slack;            // counts by which later pixels may undercut the minimum seen so far before a chunk is run again
+    float filt_slackf;         // the same for the key scans, in the pixels' own unit (not clamped to 16 bits: a 32-bit integer movie's threshold may be 1e9)
     // pixel hand-off to the fit (uint16 movies): the exact stage has a candidate's (2H+3)^2 neighbourhood in registers and
     // leaves the box rows — BOX rows of H + 1 packed pairs (BOX + 1 pixels), 4 (H + 1) bytes per row — at pix[slot], so the
     // fit reads one or two cache lines per spot instead of BOX lines of the movie.  pix_cnt: one slot counter per shard,
@@ -191,8 +207,17 @@ constexpr int fast_round(int H) { return H <= 4 ? FAST_ROUND_SMALL : FAST_ROUND_
 // Round 3: with the rows in flight and the pixel history in one register ring (below) box 9 fits four waves (123 VGPRs),
 // boxes 11 and 13 three (145 / 161) — except the variants for frames wider than a wave and for two row ranges side by
 // side at box 13 (and the latter at box 11), which would spill at three and stay at two.
-constexpr int fast_waves_per_simd(int H, int P, bool EDGE)
+// PT_KEY (float32 / 32-bit integer pixels): a row in flight is 32 bytes per lane — eight registers until its keys are built —
+// and the exact stage holds three float32 neighbourhood rows: at the register budgets of the 16-bit scans the compiler spilled
+// 300 ... 650 registers from box 9 up (round 5: 9x9 325, 11x11 299, 13x13 387, 17x17 598).  One wave less per SIMD each.
+#ifndef FAST_KEY_WAVES_H4
+#define FAST_KEY_WAVES_H4 3
+#endif
+constexpr int fast_waves_per_simd(int H, int P, bool EDGE, int PT = 0)
 {
+    // (frames wider than the wave: the edge loads are 16 or 32 bytes more per row in flight — 246 spilled registers at box 7, 80 at box 9)
+    if (PT >= 3 /* the key scans */ && EDGE && H >= 3) return H == 3 ? 3 : 2;
+    if (PT >= 3 && H >= 4) return H == 4 ? FAST_KEY_WAVES_H4 : 2;
     return H <= 3 ? FAST_MIN_WAVES : (H == 4 ? FAST_WAVES_H4 : (H == 5 ? (P == 1 ? FAST_WAVES_H5 : 2) : (H == 6 ? (P == 1 && !EDGE ? FAST_WAVES_H6 : 2) : 2)));
 }
 #ifndef FAST_UNI_MIN_H
@@ -364,7 +389,7 @@ __device__ __forceinline__ float exact_ng(const typename Px<PT>::T *__restrict__
 // The same on float32 pixels (PT_KEY): three rows of the neighbourhood in registers, the next one fetched while a window
 // row is summed; the reference's expression as it stands (a non-finite pixel makes the sum NaN there too), and the
 // first-argmax rule on the float32 values.
-template <int H>
+template <int H, int PT = PT_KEY>
 __device__ __forceinline__ float exact_ng_f32(const float *__restrict__ src, int64_t X, int cy, int cx, int i, int j, bool &first_max)
 {
     constexpr int BOX = 2 * H + 1, W = 2 * H + 3;
@@ -376,14 +401,14 @@ __device__ __forceinline__ float exact_ng_f32(const float *__restrict__ src, int
     auto load_row = [&](int t, float (&r)[W]) {
         const float *row = t == 0 ? row0w : base + (int64_t)t * X;
         const Row q = *reinterpret_cast<const Row *>(row);
-        r[0] = row[c0w];
+        r[0] = wide_px<PT>(row[c0w]);
 #pragma unroll
-        for (int c = 1; c < W; c++) r[c] = q.v[c - 1];
+        for (int c = 1; c < W; c++) r[c] = wide_px<PT>(q.v[c - 1]);
     };
     float ra[W], rb[W], rc[W];
     load_row(0, ra);
     load_row(1, rb);
-    const float vc = base[(int64_t)(H + 1) * X + H];
+    const float vc = wide_px<PT>(base[(int64_t)(H + 1) * X + H]);
     float ng = 0.0f;
     first_max = true;
 #pragma unroll
@@ -397,6 +422,53 @@ __device__ __forceinline__ float exact_ng_f32(const float *__restrict__ src, int
             const float gy = sub_rn(rc[l + 1], ra[l + 1]);
             const float gx = sub_rn(rb[l + 2], rb[l]);
             ng = add_rn(ng, add_rn(mul_rn(gy, unit_y<H>(k, l)), mul_rn(gx, unit_x<H>(k, l))));
+        }
+#pragma unroll
+        for (int c = 0; c < W; c++) { ra[c] = rb[c]; rb[c] = rc[c]; }
+    }
+    return ng;
+}
+
+// The same with the window rows as a LOOP and the unit vectors from the table in LDS (boxes 9 and up): laid out flat the
+// (2H+1)^2 terms carry a literal pair each, and at box 13 the exact stage alone asked for more scalar and vector registers
+// than the scan around it (round 5: 387 spilled VGPRs, 531 SGPRs).  Same values (unit_vectors_match), same order.
+template <int H, int PT = PT_KEY>
+__device__ __forceinline__ float exact_ng_f32_rows(const float *__restrict__ src, int64_t X, int cy, int cx, int i, int j, bool &first_max,
+                                                   const float *__restrict__ sux, const float *__restrict__ suy)
+{
+    constexpr int BOX = 2 * H + 1, W = 2 * H + 3;
+    const float *base = src + (int64_t)(i - H - 1) * X + (j - H);           // neighbourhood row t, column 1
+    const int r0 = i - H - 1 < 0 ? i - H - 1 + cy : i - H - 1;                // numba negative-index wrap
+    const float *row0w = src + (int64_t)r0 * X + (j - H);
+    const int c0w = j - H - 1 < 0 ? cx - 1 - (j - H) : -1;
+    struct __attribute__((packed, aligned(4))) Row { float v[W - 1]; };
+    auto load_row = [&](const float *row, float (&r)[W]) {
+        const Row q = *reinterpret_cast<const Row *>(row);
+        r[0] = wide_px<PT>(row[c0w]);
+#pragma unroll
+        for (int c = 1; c < W; c++) r[c] = wide_px<PT>(q.v[c - 1]);
+    };
+    float ra[W], rb[W], rc[W];
+    load_row(row0w, ra);
+    load_row(base + X, rb);
+    const float vc = wide_px<PT>(base[(int64_t)(H + 1) * X + H]);
+    float ng = 0.0f;
+    first_max = true;
+#pragma unroll 1
+    for (int k = 0; k < BOX; k++) {
+        load_row(base + (int64_t)(k + 2) * X, rc);
+        const bool above = k < H, centre = k == H;
+        const float *ux = sux + k * BOX, *uy = suy + k * BOX;
+#pragma unroll
+        for (int l = 0; l < BOX; l++) {
+            const float o = rb[l + 1];
+            const bool skip = l == H && centre;                             // the centre itself (its unit vector is 0 / 0)
+            const bool ok = (above || (centre && l < H)) ? vc > o : vc >= o;
+            first_max = first_max && (skip || ok);
+            const float gy = sub_rn(rc[l + 1], ra[l + 1]);
+            const float gx = sub_rn(rb[l + 2], rb[l]);
+            const float t = add_rn(mul_rn(gy, uy[l]), mul_rn(gx, ux[l]));
+            ng = skip ? ng : add_rn(ng, t);
         }
 #pragma unroll
         for (int c = 0; c < W; c++) { ra[c] = rb[c]; rb[c] = rc[c]; }
@@ -426,7 +498,7 @@ __device__ __forceinline__ float exact_ng_f32(const float *__restrict__ src, int
 // the compiler then counts two loads per row and waits with the exact vmcnt — as a run-time branch it has to assume
 // the smaller count on every path and the wide frames ran at half their prefetch depth.
 template <int H, int D, int P = 1, int PT = PT_U16, bool EDGE = false>
-__global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_scan_u16_fast_kernel(
+__global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE, PT)) void identify_scan_u16_fast_kernel(
     FastParams p, const float *__restrict__ uxy, Record *__restrict__ recs, long long cap,
     unsigned long long *__restrict__ shard_cnt, int *__restrict__ frame_count)
 {
@@ -580,9 +652,9 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
     // slow exact path: overflow rescans (a plateau of equal pixels flooded the ring)
     auto process_slow = [&](const PX *ksrc, int fi, int i, int j, bool recheck) {
         // (PT_KEY: the pixels are the float32 ones; `pxs` indexes whichever frame holds them)
-        const float *fsrc = PT == PT_KEY ? frame_fsrc(fi) : nullptr;
+        const float *fsrc = pt_is_key(PT) ? frame_fsrc(fi) : nullptr;
         struct { const PX *k; const float *f; __device__ float operator[](int64_t idx) const {
-            if constexpr (PT == PT_KEY) return f[idx]; else return px_float<PT>(k[idx]); } } pxs{ksrc, fsrc};
+            if constexpr (pt_is_key(PT)) return wide_px<PT>(f[idx]); else return px_float<PT>(k[idx]); } } pxs{ksrc, fsrc};
         const int64_t src = 0;
         const float v = pxs[(int64_t)i * p.X + j];
         if (recheck) {
@@ -645,7 +717,8 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
             else {
                 bool first_max;
                 float ng;
-                if constexpr (PT == PT_KEY) ng = exact_ng_f32<H>(frame_fsrc(fi), p.X, p.cy, p.cx, i, j, first_max);
+                if constexpr (pt_is_key(PT) && H >= 4) ng = exact_ng_f32_rows<H, PT>(frame_fsrc(fi), p.X, p.cy, p.cx, i, j, first_max, sux, suy);
+                else if constexpr (pt_is_key(PT)) ng = exact_ng_f32<H, PT>(frame_fsrc(fi), p.X, p.cy, p.cx, i, j, first_max);
                 else ng = exact_ng<H, PT>(src, p.X, p.cy, p.cx, i, j, first_max, pixdst);
                 if (first_max) append(fi, i, j, ng, slot);
                 kept = first_max && (double)ng > p.min_ng;
@@ -767,11 +840,12 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                     const u32x2_t m = __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)voff, (int)soff, 0);
                     ro.m = make_uint4(__builtin_amdgcn_perm(0u, m.x, 0x0c010c00u), __builtin_amdgcn_perm(0u, m.x, 0x0c030c02u),
                                       __builtin_amdgcn_perm(0u, m.y, 0x0c010c00u), __builtin_amdgcn_perm(0u, m.y, 0x0c030c02u));
-                } else if constexpr (PT == PT_KEY) {
-                    // 8 float32 pixels = 32 bytes -> four packed pairs of keys
+                } else if constexpr (pt_is_key(PT)) {
+                    // 8 float32 pixels = 32 bytes -> four packed pairs of keys (32-bit integers: converted first)
                     const u32x4_t a = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
                     const u32x4_t b = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(voff + 16u), (int)soff, 0);
-                    ro.m = make_uint4(key_pair(a.x, a.y), key_pair(a.z, a.w), key_pair(b.x, b.y), key_pair(b.z, b.w));
+                    ro.m = make_uint4(key_pair(wide_bits<PT>(a.x), wide_bits<PT>(a.y)), key_pair(wide_bits<PT>(a.z), wide_bits<PT>(a.w)),
+                                      key_pair(wide_bits<PT>(b.x), wide_bits<PT>(b.y)), key_pair(wide_bits<PT>(b.z), wide_bits<PT>(b.w)));
                 } else {
                     const u32x4_t m = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)voff, (int)soff, 0);
                     ro.m = make_uint4(m.x, m.y, m.z, m.w);
@@ -790,12 +864,12 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                             const unsigned e = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)off_e, (int)soff, 0);
                             ro.e.x = __builtin_amdgcn_perm(0u, e, 0x0c010c00u); ro.e.y = __builtin_amdgcn_perm(0u, e, 0x0c030c02u);
                         }
-                    } else if constexpr (PT == PT_KEY) {
+                    } else if constexpr (pt_is_key(PT)) {
                         const u32x4_t e = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_e, (int)soff, 0);
-                        ro.e.x = key_pair(e.x, e.y); ro.e.y = key_pair(e.z, e.w);
+                        ro.e.x = key_pair(wide_bits<PT>(e.x), wide_bits<PT>(e.y)); ro.e.y = key_pair(wide_bits<PT>(e.z), wide_bits<PT>(e.w));
                         if constexpr (WIDE) {
                             const u32x4_t f = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(off_e + 16u), (int)soff, 0);
-                            ro.e.z = key_pair(f.x, f.y); ro.e.w = key_pair(f.z, f.w);
+                            ro.e.z = key_pair(wide_bits<PT>(f.x), wide_bits<PT>(f.y)); ro.e.w = key_pair(wide_bits<PT>(f.z), wide_bits<PT>(f.w));
                         }
                     } else if constexpr (WIDE) {
                         const u32x4_t e = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)off_e, (int)soff, 0);
@@ -828,7 +902,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
             int added = 0;                                    // candidates of this chunk, counted even when the ring is full
             int tail_lf = tail, rd_lf = clo;                  // ring state before, and first row of, the latest flush group
             u32 cmin = 0xffffffffu;                           // minimum of every pixel this lane streamed in the chunk (both halves)
-            const float beta = fmaf(1.0f - p.filt_alpha, PT == PT_KEY ? cf : (float)cfloor, p.filt_t);
+            const float beta = fmaf(1.0f - p.filt_alpha, pt_is_key(PT) ? cf : (float)cfloor, p.filt_t);
             // A maximum in row H (column H) has the first row (column) of its neighbourhood at index -1, i.e. in the LAST
             // row (column) of the frame (numba wraps; localize.py:233-243).  Those pixels are not among the ones the
             // running minimum or the cfloor check see — but they carry negative weights only (N_wrap in total) and are
@@ -982,7 +1056,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                             // a plateau of equal pixels (a saturated fiducial) sends its upper-left rim to the ring
                             // instead of every pixel.
                             // (keys: equal keys are not equal pixels — the right-hand one may be the larger)
-                            const u32 c = PT == PT_KEY ? 0u : pass;
+                            const u32 c = pt_is_key(PT) ? 0u : pass;
                             pass &= ~((c & 0x0000ffffu) << 16);                    // odd pixel, left neighbour = the even pixel of its pair
                             pass &= ~(((c >> 16) << 1) & 0x0000eeeeu);             // even pixel 2q (q > 0), left neighbour = odd pixel of pair q - 1
                             pass &= ~((c & 0x0fff0fffu) << 4);                     // same pixel, one row up (previous row slot)
@@ -1033,7 +1107,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                             const bool wraprow = rnext <= H && rnext + 3 >= H;
                             const float flw = wrapcol ? (wraprow ? beta_rc : beta_c) : beta_r;
                             u32 fi_;
-                            if constexpr (PT == PT_KEY) {
+                            if constexpr (pt_is_key(PT)) {
                                 // the bound from the lower edge of the minimum's bucket, back to the key of the bucket it falls into:
                                 // v > fl implies key(v) >= key(fl).  Wrapped stencils reach pixels the minimum has not seen and
                                 // that may be negative here: no floor for them; none either when the bound is not a number.
@@ -1070,8 +1144,8 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE)) void identify_
                 }
                 cw &= 0xffffu;
                 bool broken;
-                if constexpr (PT == PT_KEY) {
-                    const float cwf = key_lower_edge(cw), slackf = (float)p.filt_slack;
+                if constexpr (pt_is_key(PT)) {
+                    const float cwf = key_lower_edge(cw), slackf = p.filt_slackf;
                     broken = cwf < cf;                         // (a NaN lower edge compares false, and makes the next floor NaN = none)
                     cf = cwf - slackf;
                     if (__any(broken)) {
@@ -1145,10 +1219,22 @@ static int launch_fast(const FastParams &p, int pt, const float *d_tab, Record *
     if (P > 1 && p.pf) strncat(g_last_scan_kernel, " frames", sizeof(g_last_scan_kernel) - strlen(g_last_scan_kernel) - 1);
     if constexpr (P == 1) {
         if (p.segs > 1) {             // frames wider than a wave: the variant with the edge loads
-            if (pt == PT_KEY) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_KEY, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+            // (box 13 on 4-byte pixels with the edge loads: six rows in flight are 253 spilled registers, four are 2)
+            constexpr int DK = H == 6 ? 4 : D;
+            if (pt == PT_KEY) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, DK, 1, PT_KEY, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+            else if (pt == PT_KEY_I32) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, DK, 1, PT_KEY_I32, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+            else if (pt == PT_KEY_U32) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, DK, 1, PT_KEY_U32, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
             else if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_U8, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
             else if (pt == PT_I16) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_I16, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
             else hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_U16, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+            PMI_HIP(hipGetLastError());
+            return PMI_OK;
+        }
+    }
+    if constexpr (P == 1) {           // 32-bit integer pixels: one row range per lane set only (launch_scan_u16_fast)
+        if (pt == PT_KEY_I32 || pt == PT_KEY_U32) {
+            if (pt == PT_KEY_I32) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_KEY_I32>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+            else hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_KEY_U32>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
             PMI_HIP(hipGetLastError());
             return PMI_OK;
         }
@@ -1199,10 +1285,10 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     // uint16, uint8 and int16 movies (see Px); rows need no alignment beyond the pixel's own: gfx950 runs buffer and
     // global loads in unaligned mode, so odd widths only cost the loads that straddle a 64-byte boundary
     // (fmovie: a float32 movie — d_movie and fmovie are the same frames — scanned through keys built in registers)
-    const int pt = fmovie ? (dtype == PMI_F32 && (const void *)fmovie == d_movie ? PT_KEY : -1)
+    const int pt = fmovie ? ((const void *)fmovie != d_movie ? -1 : (dtype == PMI_F32 ? PT_KEY : (dtype == PMI_I32 ? PT_KEY_I32 : (dtype == PMI_U32 ? PT_KEY_U32 : -1))))
                           : (dtype == PMI_U16 ? PT_U16 : (dtype == PMI_U8 ? PT_U8 : (dtype == PMI_I16 ? PT_I16 : -1)));
     if (pt < 0) return PMI_OK;
-    const int pxb = pt == PT_U8 ? 1 : (pt == PT_KEY ? 4 : 2);
+    const int pxb = pt == PT_U8 ? 1 : (pt_is_key(pt) ? 4 : 2);
     if (cx < 16 || ((uintptr_t)d_movie & (uintptr_t)(pxb - 1))) return PMI_OK;
     if (cy > 65535 || cx > 65520 || X > 65535 || Y * X * pxb >= (1LL << 31)) return PMI_OK;   // 32-bit row offsets, 16-bit list columns
     const int g_fast_cus = device_cu_count();
@@ -1215,6 +1301,8 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
         else if (nch <= 16 && h <= 4) pack = 4;
         else if (nch <= 32) pack = 2;
     }
+    // (the 32-bit integer scans are built for one row range per lane set: narrow frames keep the routes they had)
+    if (pack > 1 && (pt == PT_KEY_I32 || pt == PT_KEY_U32)) return PMI_OK;
     FastParams p;
     p.movie = d_movie; p.Y = Y; p.X = X; p.y0 = y0; p.x0 = x0; p.cy = cy; p.cx = cx;
     p.f_lo = f_lo; p.label_off = label_off; p.nframes = nframes; p.box = box; p.min_ng = min_ng; p.gate = gate;
@@ -1224,7 +1312,7 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
     p.segs = pack > 1 ? 1 : (nch + 63) / 64;
     // Rows per unit: long units amortise the 2H + 2 pipeline rows a unit spends on its halo, short ones balance the
     // persistent waves (every wave runs ceil(units / waves) units).  Pick the length with the least total work.
-    const long long waves = (long long)g_fast_cus * 4 * fast_waves_per_simd(h, pack, pack == 1 && p.segs > 1);
+    const long long waves = (long long)g_fast_cus * 4 * fast_waves_per_simd(h, pack, pack == 1 && p.segs > 1, pt);
     static const int force_rbu = tuning_env("PMI_IDENTIFY_RBU") ? atoi(tuning_env("PMI_IDENTIFY_RBU")) : 0;
     int best_rbu = 0;
     double best_cost = 0.0;
@@ -1306,11 +1394,12 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
         p.filt_alpha = (float)(N_K / P_box * 0.998);
         p.filt_t = (float)std::max(0.0, min_ng / (P_box * 1.001) - 1.0);     // one count of slack for the float32 evaluation
         p.filt_slack = (int)std::min(65535.0, std::max(2.0, std::ceil(0.5 * min_ng / P_box)));
+        p.filt_slackf = (float)std::max(2.0, std::ceil(0.5 * min_ng / P_box));
         p.filt_kr = (float)std::max(0.0, (1.0 - N_row0 / P_box) * 0.998);
         p.filt_kc = (float)std::max(0.0, (1.0 - N_col0 / P_box) * 0.998);
         p.filt_krc = (float)std::max(0.0, (1.0 - (N_row0 + N_col0) / P_box) * 0.998);
     } else {
-        p.filt_alpha = 0.0f; p.filt_t = -1.0f; p.filt_slack = 0;
+        p.filt_alpha = 0.0f; p.filt_t = -1.0f; p.filt_slack = 0; p.filt_slackf = 0.0f;
         p.filt_kr = p.filt_kc = p.filt_krc = 0.0f;
     }
     static const int dbg = tuning_env("PMI_IDENTIFY_DBG") ? atoi(tuning_env("PMI_IDENTIFY_DBG")) : 0;

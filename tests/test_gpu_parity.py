@@ -518,9 +518,10 @@ def test_identify_plateaus_and_saturated_fiducials(be, orc, dtype, box):
 
 @pytest.mark.parametrize("dtype", [np.float32, np.int32, np.uint32])
 def test_identify_wide_movies_holding_counts(be, orc, dtype):
-    """32-bit movies whose pixels are 16-bit counts are narrowed to uint16 chunk by chunk and take the packed scan; a chunk
-    with one pixel that is not such a count (a fraction, a negative, 65536, NaN) takes the generic kernel — the table is
-    the reference's either way, chunk boundaries included."""
+    """32-bit movies whose pixels are 16-bit counts, clean and with pixels that are not such counts (a fraction, a negative,
+    65536, NaN).  Rounds 1 - 5 narrowed the integer ones to uint16 chunk by chunk (a spoiled chunk took the generic kernel);
+    since round 6 they take the key scan like float32 movies, and the chunked route serves only frames too narrow for it —
+    the table is the reference's either way, chunk boundaries included."""
     from picasso_amd import _lib
     assert _lib.load().pmi_identify_set_narrow_chunk(3) == 0          # several chunks on a small movie
     try:
@@ -608,6 +609,45 @@ def test_identify_float32_movies_with_any_content(be, orc, kind, box):
         assert n_last > 20
     finally:
         assert _lib.load().pmi_identify_set_narrow_chunk(0) == 0
+
+
+@pytest.mark.parametrize("dtype", [np.int32, np.uint32])
+@pytest.mark.parametrize("box", [5, 7, 9, 11, 13, 15, 17])
+def test_identify_32bit_integer_movies_through_the_key_scan(be, orc, dtype, box):
+    """32-bit integer movies compare as float32 in the reference (the frame is cast first, picasso/localize.py:332).  Round 6:
+    they take the packed scan on 16-bit keys like float32 movies, with that cast in front of the keys and of every exact
+    read (identify_fast.hip PT_KEY_I32 / PT_KEY_U32) — counts, values far beyond 16 bits, values beyond 2^24 (where the cast
+    rounds and makes ties the integers did not have), negative pixels, and the top of the uint32 range: the oracle's
+    table bit for bit, with and without an ROI, frames wider than one wavefront's 512 columns included."""
+    from picasso_amd import _lib
+    rng = np.random.default_rng(900 + box + (7 if dtype == np.uint32 else 0))
+    for (F, Y, X) in ((5, 96, 272), (2, 70, 1100)):
+        base = rng.poisson(60, size=(F, Y, X)).astype(np.int64)
+        for f in range(F):
+            for _ in range(max(6, X // 40)):
+                y, x = rng.integers(10, Y - 10), rng.integers(10, X - 10)
+                s = rng.uniform(0.9, 1.0 + 0.12 * box)
+                yy, xx = np.mgrid[y - 9:y + 10, x - 9:x + 10]
+                base[f, y - 9:y + 10, x - 9:x + 10] += np.rint(rng.uniform(800, 5000) * np.exp(-0.5 * ((yy - y) ** 2 + (xx - x) ** 2) / s ** 2)).astype(np.int64)
+        kinds = {"counts": (base, 3000.0), "x30011": (base * 30011, 3000.0 * 30011), "beyond_2^24": (base * 4096 + 16777000, 3000.0 * 4096)}
+        if dtype == np.int32:
+            kinds["negative"] = (base * 1000 - 2_000_000_000, 3000.0 * 1000)
+        else:
+            kinds["top_of_range"] = (base * 1000 + 4_200_000_000, 3000.0 * 1000)
+        for kind, (m64, min_ng) in kinds.items():
+            assert m64.min() >= np.iinfo(dtype).min and m64.max() <= np.iinfo(dtype).max
+            mov = m64.astype(dtype)
+            for roi in (None, ((3, 9), (Y - 2, X - 11))):
+                for t in (min_ng, -1e18):
+                    a = be.identify_arrays(mov, t, box, roi=roi)
+                    b = orc.identify(mov, t, box, roi=roi, threads=4)
+                    assert len(a[0]) == len(b[0]) and all(np.array_equal(p, q) for p, q in zip(a, b)), (kind, dtype, box, roi, t, len(a[0]), len(b[0]))
+            if X >= 512:        # (frames of at most 256 columns pack two row ranges per wavefront and keep the chunked route)
+                import ctypes
+                name = ctypes.create_string_buffer(128)
+                _lib.load().pmi_last_scan_kernel(name, 128)
+                assert b"identify_scan_u16_fast_kernel" in name.value and (b", 4, " in name.value or b", 5, " in name.value), name.value
+    assert len(b[0]) > 10
 
 
 def test_identify_capacity_retry(be, orc, testdata_movie):

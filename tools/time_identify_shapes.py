@@ -30,8 +30,12 @@ for H, W, dt in CASES:
         mov = mov.view(torch.int16).to(torch.float32)
     elif dt == "float32 x1.37":      # fractions: 16-bit keys + exact decisions on the float32 pixels
         mov = mov.view(torch.int16).to(torch.float32) * 1.37 + 0.25
-    code = {"uint16": 0, "uint16+20000": 0, "uint8": 1, "int16": 2, "float32": 5, "float32 x1.37": 5}[dt]
-    min_ng = 5000.0 / 8 if dt == "uint8" else 5000.0
+    elif dt == "int32":              # a camera's counts saved as 32-bit integers
+        mov = mov.view(torch.int16).to(torch.int32)
+    elif dt == "int32 x70000":       # 32-bit integers beyond 16 bits (they compare as float32 in the reference, localize.py:332)
+        mov = mov.view(torch.int16).to(torch.int32) * 70000
+    code = {"uint16": 0, "uint16+20000": 0, "uint8": 1, "int16": 2, "float32": 5, "float32 x1.37": 5, "int32": 4, "int32 x70000": 4}[dt]
+    min_ng = 5000.0 / 8 if dt == "uint8" else (5000.0 * 70000 if dt == "int32 x70000" else 5000.0)
     torch.cuda.synchronize()
     cap = max(4096, int(F * H * W / 1500))
     out = [torch.empty(cap, dtype=torch.int32, device="cuda") for _ in range(3)] + [torch.empty(cap, dtype=torch.float32, device="cuda")]

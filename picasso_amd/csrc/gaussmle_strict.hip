@@ -41,6 +41,7 @@ namespace pmi {
 
 namespace {
 
+typedef double d2_t __attribute__((ext_vector_type(2)));
 constexpr double K_SQRT_2PI = 2.5066282746310002;   // np.sqrt(2.0 * np.pi)
 constexpr double K_SQRT_2 = 1.4142135623730951;
 constexpr double K_SQRT_PI = 1.7724538509055159;
@@ -58,15 +59,27 @@ __device__ __forceinline__ void lds_sync()
 }
 
 // LDS of one group, in bytes: spot (float32), boundary values, column / row terms, per-pixel terms of one round,
-// accumulators
+// accumulators.  Round 6: every array is a structure of arrays — field q of record r at [q * stride + r] — so that the lanes
+// of a group, which work on consecutive records, touch consecutive 8-byte slots whatever the field (rounds 2 - 5 kept the
+// records together: 32-, 40- and 96-byte lane strides, SQ_LDS_BANK_CONFLICT 25 % of the LDS cycles of the all-strict launch).
+// What is left to choose is where the NEXT group of the wavefront starts (two 16-lane groups share a 32-lane ds_read_b64,
+// the chain lanes of two groups one ds_read_b128) and the row stride RS of the term array, whose rows the chain lanes read
+// 16 bytes at a time: tools/emul/lds_strict_layout.py (the bank model that reproduced the least-squares kernel's counters)
+// gives 1.51x the conflict-free cycles for the old layout at 7x7 and 1.06x for RS = 20, groups 3408 B apart — which is also
+// the most three workgroups of sixteen groups may take of the CU's 160 KB.
 template <int GS> struct SLds {
     static constexpr int MAXB = GS == 16 ? 7 : (GS == 32 ? 15 : PMI_MAX_BOX);
     static constexpr int SPOT = ((MAXB * MAXB * 4 + 15) / 16) * 16;
-    static constexpr int BND = 2 * (MAXB + 1) * 4 * 8;
-    static constexpr int COL = 2 * MAXB * 5 * 8;
-    static constexpr int TERM = GS * 12 * 8;
+    static constexpr int BS = 2 * (MAXB + 1);            // boundary records per field: (axis, k), k <= B
+    static constexpr int CS = 2 * MAXB;                  // column / row records per field: (axis, i)
+    static constexpr int RS = GS + (GS == 16 ? 4 : 2);   // slots per row of the term array (one row per accumulator)
+    static constexpr int BND = 4 * BS * 8;
+    static constexpr int COL = 5 * CS * 8;
+    static constexpr int TERM = 12 * RS * 8;
     static constexpr int ACC = 24 * 4;      // 12 accumulators + 6 updated parameters
-    static constexpr int BYTES = SPOT + BND + COL + TERM + ACC;
+    static constexpr int NATURAL = SPOT + BND + COL + TERM + ACC;
+    static constexpr int BYTES = GS == 16 ? 3408 : NATURAL;
+    static_assert(BYTES >= NATURAL && BYTES % 16 == 0 && (BS * 8) % 16 == 0 && (CS * 8) % 16 == 0 && (RS * 8) % 16 == 0, "LDS layout of a group");
 };
 
 }  // namespace
@@ -225,6 +238,7 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
     double *term = reinterpret_cast<double *>(mem + SLds<GS>::SPOT + SLds<GS>::BND + SLds<GS>::COL);
     float *accs = reinterpret_cast<float *>(mem + SLds<GS>::SPOT + SLds<GS>::BND + SLds<GS>::COL + SLds<GS>::TERM);
 
+    constexpr int BS = SLds<GS>::BS, CS = SLds<GS>::CS, RS = SLds<GS>::RS;
     const int B = p.box, npix = B * B;
     int64_t n = p.N;
     if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
@@ -353,8 +367,8 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
                     v2 = ai * ex;                                                    // term of Fx / Fy (:359)
                     v3 = (ai * ex) * (1.0 - 2.0 * (ai * ai));                        // term of dFxdt / dFydy (:364-371)
                 }
-                double *o = bnd + (a * nb + k) * 4;
-                o[0] = eA; o[1] = eD; o[2] = v2; o[3] = v3;
+                double *o = bnd + ja;                                                // record (a, k) = a * nb + k, field q at o[q * BS]
+                o[0] = eA; o[BS] = eD; o[2 * BS] = v2; o[3 * BS] = v3;
             }
             lds_sync();
             // phase B: lane -> (axis, pixel index i): PSF, b - a, (d-.5) b - (d+.5) a, sigma terms
@@ -363,7 +377,8 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
                 const double dmu = (double)(a ? th[1] : th[0]);
                 const float sgf = a ? sgy : th[4];
                 const double ds = (double)sgf;
-                const double *m = bnd + (a * nb + i) * 4, *q = m + 4;               // minus / plus boundary
+                const double *mq = bnd + (a * nb + i);                               // minus boundary; the plus boundary is the next record
+                const double m[4] = {mq[0], mq[BS], mq[2 * BS], mq[3 * BS]}, q[4] = {mq[1], mq[BS + 1], mq[2 * BS + 1], mq[3 * BS + 1]};
                 const double d = (double)i - dmu;
                 const double PSF = 0.5 * (q[0] - m[0]);
                 const double bma = m[1] - q[1];
@@ -385,8 +400,8 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
                     S1 = dPSF;
                     S2 = (1.0 / K_SQRT_PI) * ((-F / (double)s2) + (double)sinv * dF);   // :372-374
                 }
-                double *o = col + (a * B + i) * 5;
-                o[0] = PSF; o[1] = bma; o[2] = qq; o[3] = S1; o[4] = S2;
+                double *o = col + jb;                                                // record (a, i) = a * B + i
+                o[0] = PSF; o[CS] = bma; o[2 * CS] = qq; o[3 * CS] = S1; o[4 * CS] = S2;
             }
             lds_sync();
             // phase C + accumulation, GS pixels of the reference's (ii, jj) sequence per round
@@ -400,7 +415,8 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
                 const int seq = r0 + j;
                 if (jj >= B) { jj -= B; ii++; }
                 if (seq < npix) {
-                    const double *X = col + ii * 5, *Yc = col + (B + jj) * 5;
+                    const double *Xp = col + ii, *Yp = col + (B + jj);
+                    const double X[5] = {Xp[0], Xp[CS], Xp[2 * CS], Xp[3 * CS], Xp[4 * CS]}, Yc[5] = {Yp[0], Yp[CS], Yp[2 * CS], Yp[3 * CS], Yp[4 * CS]};
                     const double PSFx = X[0], PSFy = Yc[0];
                     float du[6], d2[6];
                     du[0] = (float)(N_ * PSFy * X[1] / cx);                          // :296
@@ -425,12 +441,12 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
                     if (model > 10e-3) { cf = data / model - 1; df = data / (model * model); }
                     cf = np_min_d(cf, 10e4);
                     df = np_min_d(df, 10e4);
-                    double *t = term + j * 12;
+                    double *t = term + j;                                            // row l: the terms of accumulator l, slot j: this pixel
 #pragma unroll
                     for (int l = 0; l < 6; l++) {
                         const float du2 = du[l] * du[l];                             // float32 ** 2
-                        t[l] = cf * (double)du[l];
-                        t[6 + l] = cf * (double)d2[l] - df * (double)du2;
+                        t[l * RS] = cf * (double)du[l];
+                        t[(6 + l) * RS] = cf * (double)d2[l] - df * (double)du2;
                     }
                 }
                 lds_sync();
@@ -438,17 +454,18 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
                     // :838-839, one accumulator per lane; eight terms are fetched ahead of the dependent chain of
                     // (float64 add, float32 round) steps
                     const int cnt = npix - r0 < GS ? npix - r0 : GS;
+                    const double *row = term + j * RS;
                     if (cnt == GS) {
 #pragma unroll
-                        for (int s0 = 0; s0 < GS; s0 += 8) {
-                            double t[8];
+                        for (int s0 = 0; s0 < GS; s0 += 16) {
+                            d2_t t[8];                                               // sixteen terms in eight 16-byte reads
 #pragma unroll
-                            for (int u = 0; u < 8; u++) t[u] = term[(s0 + u) * 12 + j];
+                            for (int u = 0; u < 8; u++) t[u] = *reinterpret_cast<const d2_t *>(row + s0 + 2 * u);
 #pragma unroll
-                            for (int u = 0; u < 8; u++) acc = (float)((double)acc + t[u]);
+                            for (int u = 0; u < 8; u++) { acc = (float)((double)acc + t[u].x); acc = (float)((double)acc + t[u].y); }
                         }
                     } else {
-                        for (int s = 0; s < cnt; s++) acc = (float)((double)acc + term[s * 12 + j]);
+                        for (int s = 0; s < cnt; s++) acc = (float)((double)acc + row[s]);
                     }
                 }
                 lds_sync();

@@ -274,6 +274,10 @@ def main():
     # where a rank's step went: kernels of the path (compute stream) and, beside them, the all-gather on its side stream
     # (from the moment the step's table was ready to the end of the collective — it includes waiting for the slowest rank)
     compute_ms = float(np.mean([a.elapsed_time(b) for a, b, _ in timeline])) if timeline else float("nan")
+    # the device's own clock over the timed region: first timed step's start event to the last one's end event (rank 0's
+    # stream).  The GPU-busy sampler of a harness cannot see a 50 ms region; these two numbers agreeing is the line's
+    # own evidence that `elapsed` is device time, not host time spent queueing
+    region_ms = float(timeline[0][0].elapsed_time(timeline[-1][1])) if timeline else float("nan")
     gather_ms = float(np.mean([b.elapsed_time(g) for _, b, g in timeline if g is not None])) if any(g is not None for _, _, g in timeline) else None
     per_rank = None
     if grouped:
@@ -355,7 +359,7 @@ def main():
                     "traffic": traffic, "traffic_source": traffic_source,
                     "measured_on": f"{args.profile_steps} single-range passes over the whole movie after the timed steps (HIP events "
                                    "around the kernels on their launch stream, inside the library); the same launches as "
-                                   "`bench.py --ranges 1`, profiles/r05_bench_ranges1_kernel_stats.txt",
+                                   "`bench.py --ranges 1`, profiles/r06_bench_ranges1_kernel_stats.txt",
                     "scan_kernel": scan_kernel,
                     "kernels": kernels}
         kernels["mle_fit"]["bound"] = "fp32 valu (no MFMA shape); algorithmic bytes are 166 B/spot"
@@ -367,6 +371,10 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None,
+            # HIP events on the compute stream: start of the first timed step to the end of the last, per step (rank 0); and the
+            # mean of the per-step event pairs.  `ms_per_step` above is the host clock between the two synchronisations.
+            "ms_per_step_hip_events": region_ms / args.steps if args.steps else None,
+            "ms_per_step_hip_events_mean_of_steps": compute_ms,
             # every spot in the reference's arithmetic (pmi_mle_set_mode strict), the same step, after the timed ones (no all-gather)
             "ms_per_step_strict": strict_ms,
             "value_strict": (n_total / (strict_ms * 1e-3)) if strict_ms else None,
@@ -404,7 +412,7 @@ def main():
     return result
 
 
-PMC_TRAFFIC_FILE = "profiles/r05_identify_pmc.json"
+PMC_TRAFFIC_FILE = "profiles/r06_identify_pmc.json"
 
 
 def last_scan_kernel(L):

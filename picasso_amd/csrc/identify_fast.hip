@@ -432,6 +432,9 @@ __device__ __forceinline__ float exact_ng_f32(const float *__restrict__ src, int
 // The same with the window rows as a LOOP and the unit vectors from the table in LDS (boxes 9 and up): laid out flat the
 // (2H+1)^2 terms carry a literal pair each, and at box 13 the exact stage alone asked for more scalar and vector registers
 // than the scan around it (round 5: 387 spilled VGPRs, 531 SGPRs).  Same values (unit_vectors_match), same order.
+// (The 16-bit scans keep their flat exact stage: as a loop it spills fewer scalars — 324 -> 123 at box 13 — but needs MORE
+// vector registers than the two batches of rows, and pays a trip to memory per window row instead of two per candidate:
+// measured, boxes 9 / 13 / 17 on 512 x 512 uint16: 4.04 / 3.41 / 2.06 -> 3.57 / 3.19 / 1.86 TB/s; not kept.)
 template <int H, int PT = PT_KEY>
 __device__ __forceinline__ float exact_ng_f32_rows(const float *__restrict__ src, int64_t X, int cy, int cx, int i, int j, bool &first_max,
                                                    const float *__restrict__ sux, const float *__restrict__ suy)

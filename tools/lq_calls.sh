@@ -1,6 +1,6 @@
 #!/bin/bash
 # per-dispatch timeline of the strict gausslq fit at the boxes given (default 7)
-OUT=gpurun_out/r05s; mkdir -p $OUT; export TMPDIR=/tmp; PD=$(mktemp -d /tmp/prof_XXXXXX)    # (a box may be one an earlier call left its /tmp on)
+OUT=${OUT:-gpurun_out/r06c}; mkdir -p $OUT; export TMPDIR=/tmp; PD=$(mktemp -d /tmp/prof_XXXXXX)    # (a box may be one an earlier call left its /tmp on)
 for b in ${BOXES:-7}; do
 (cd /tmp && rocprofv3 --kernel-trace --stats -d $PD -- python3 $OLDPWD/tools/time_gausslq.py 1048576 $b > $PD.log 2>&1)
 grep -E "^N=|mean nfev|second pass" $PD.log

@@ -3,7 +3,7 @@
 # --ranges 1), PMC of the scan as the benchmark launches it (fused path, exact stage deferred) and alone, instruction-mix
 # PMC of the Newton loop and of the least-squares kernels, the config-3 / config-5 lines.
 # usage (on the GPU box, from the repo root): bash tools/round_profiles.sh <outdir> [round tag]
-OUT=${1:-gpurun_out/prof}; TAG=${2:-r05}
+OUT=${1:-gpurun_out/prof}; TAG=${2:-r06}
 rm -rf /tmp/pmc_scan_fused /tmp/pmc_scan_alone /tmp/pmc_g8 /tmp/pmc_g8i /tmp/pmc_lqj /tmp/pmc_lqs /tmp/prof_bench /tmp/prof_bench1 /tmp/prof_c3 /tmp/prof_c5      # (a box may carry an earlier call's /tmp)
 mkdir -p $OUT; export TMPDIR=/tmp
 bash tools/pmc_scan.sh /tmp/pmc_scan_fused 10000 7 fused > $OUT/${TAG}_scan_pmc.txt 2>&1; cp /tmp/pmc_scan_fused/traffic.json $OUT/${TAG}_identify_pmc.json
@@ -27,5 +27,6 @@ python3 tools/rocprof_summary.py /tmp/prof_c5 > $OUT/${TAG}_config5_kernel_stats
 python3 tools/time_mle_eps.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_mle_eps.jsonl
 PMI_MLE_MODE=strict bash tools/pmc_first.sh /tmp/pmc_strict_$$ "mle_strict_kernel" python3 tools/ab_defer.py 10000 7 1 1 > $OUT/${TAG}_mle_strict_pmc.txt 2>&1     # every spot in the reference's arithmetic
 python3 tools/time_identify_shapes.py 7 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_identify_shapes.txt
+bash tools/identify_wide_types.sh $OUT/${TAG}_identify_wide_types_now.txt > /dev/null 2>&1
 (for m in refit strict; do for b in 3 5 7 9 11 13 15 21; do PMI_LQ_MODE=$m python3 tools/time_gausslq.py 1048576 $b 2>&1 | grep "^N=" | tail -1 | sed "s/^/[$m] /"; done; done; python3 tools/time_lq_ranges.py 2>&1 | grep -v amdgpu.ids) > $OUT/${TAG}_gausslq_times.txt 2>&1
 ls -la $OUT

@@ -133,7 +133,7 @@ constexpr int FISHER_STRIDE = 21;
 enum { FIT_STAGE_NEWTON = 1, FIT_STAGE_FINAL = 2, FIT_STAGE_INIT_ONLY = 4, FIT_STAGE_ITERATE_ONLY = 8 };
 // a fit that takes more iterations than this is re-fitted whatever its steps were.  Round 2 set it to 32 as a catch-all
 // for fits that creep or wobble; with the wobble and contraction flags of round 3 (below) the count adds nothing — the
-// CPU emulation (tools/emul/slow_rule.py: 48 cases x 30 000 spots) and the fuzz run find the same escapes, none, at 32, 48,
+// CPU emulation (docs/history/tools/emul/slow_rule.py: 48 cases x 30 000 spots) and the fuzz run find the same escapes, none, at 32, 48,
 // 64 and without it — and at 32 it re-fits healthy fits wherever they are naturally long (eps 1e-4: 6 % of config 2's
 // spots, 5x5 boxes: 30 %).  64 keeps the fits that run into the default max_it among the re-fitted.
 constexpr int FIT_SLOW_ITERATIONS = 64;

@@ -776,7 +776,7 @@ def test_gausslq_strict_mode_where_one_exp_decides_a_float32_rounding(be, orc):
     """With every sum in MINPACK's order, 2 spots of 29.2 million still differed from the oracle (tools/fuzz_parity.py 800 91
     lq, 13 minutes; 7e-5 and 8e-5 px, `info` and `nfev` equal): one float64 exp of the Gaussian profiles differs in its last
     bit between the device's libm and glibc — both within an ulp, neither the correctly rounded function — and flips ONE
-    float32 rounding of the stored model (gausslq.py:203).  tools/probe_lq_exp.py: the oracle gives the same theta with
+    float32 rounding of the stored model (gausslq.py:203).  docs/history/tools/probe_lq_exp.py: the oracle gives the same theta with
     libm's exp and with a correctly rounded one on both spots, i.e. the odd bit was the device's.  The strict mode now flags
     a profile value within 8 float64 ulps of a float32 rounding boundary and fits such a spot again with exp rounded
     correctly (csrc/exp_cr.h): both spots are lmdif's bit for bit."""

@@ -944,6 +944,8 @@ static void launch_g8(const FitParams &p, float *state, int cu_count, int stages
     const int64_t waves = (count + NSPW - 1) / NSPW;
     const dim3 flat((unsigned)((waves + FIT_WAVES - 1) / FIT_WAVES));
     // persistent iterate grid: 6 workgroups (24 waves, 73 VGPRs each) per CU, each wave owning >= 64 spots when possible
+    // (more, smaller chunks — 36 ... 144 waves' worth per CU, the surplus waiting for a slot — leave the fit where it is,
+    // 1.59 ms on config 2, and cost the step with two ranges in flight 0.1 - 0.2 ms: the scan beside it gets its slots later)
     const int64_t pw = std::max<int64_t>(1, std::min<int64_t>((int64_t)cu_count * 24, (count + 63) / 64));
     const dim3 pers((unsigned)((pw + FIT_WAVES - 1) / FIT_WAVES));
     if (stages & (FIT_STAGE_NEWTON | FIT_STAGE_INIT_ONLY))

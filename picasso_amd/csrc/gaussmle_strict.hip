@@ -65,8 +65,8 @@ __device__ __forceinline__ void lds_sync()
 // What is left to choose is where the NEXT group of the wavefront starts (two 16-lane groups share a 32-lane ds_read_b64,
 // the chain lanes of two groups one ds_read_b128) and the row stride RS of the term array, whose rows the chain lanes read
 // 16 bytes at a time: tools/emul/lds_strict_layout.py (the bank model that reproduced the least-squares kernel's counters)
-// gives 1.51x the conflict-free cycles for the old layout at 7x7 and 1.06x for RS = 20, groups 3408 B apart — which is also
-// the most three workgroups of sixteen groups may take of the CU's 160 KB.
+// gives 1.51x the conflict-free cycles for the old layout at 7x7 and 1.06x for RS = 20 with the two groups of a pair 3408 B
+// apart (80 bytes past a multiple of 256).
 template <int GS> struct SLds {
     static constexpr int MAXB = GS == 16 ? 7 : (GS == 32 ? 15 : PMI_MAX_BOX);
     static constexpr int SPOT = ((MAXB * MAXB * 4 + 15) / 16) * 16;
@@ -77,9 +77,17 @@ template <int GS> struct SLds {
     static constexpr int COL = 5 * CS * 8;
     static constexpr int TERM = 12 * RS * 8;
     static constexpr int ACC = 24 * 4;      // 12 accumulators + 6 updated parameters
-    static constexpr int NATURAL = SPOT + BND + COL + TERM + ACC;
-    static constexpr int BYTES = GS == 16 ? 3408 : NATURAL;
-    static_assert(BYTES >= NATURAL && BYTES % 16 == 0 && (BS * 8) % 16 == 0 && (CS * 8) % 16 == 0 && (RS * 8) % 16 == 0, "LDS layout of a group");
+    static constexpr int BYTES = SPOT + BND + COL + TERM + ACC;
+    // the second group of a 32-lane pair starts PAIR_PAD bytes later than BYTES would put it (16-lane groups only: with 32 or
+    // 64 lanes a group has the LDS's lane groups to itself): group g of a wavefront at g * BYTES + ((g + 1) / 2) * PAIR_PAD
+    static constexpr int PAIR_PAD = GS == 16 ? 112 : 0;
+    static constexpr int NSPW = 64 / GS;
+    static constexpr int WAVE_BYTES = NSPW * BYTES + (NSPW / 2) * PAIR_PAD;
+    static_assert(BYTES % 16 == 0 && PAIR_PAD % 16 == 0 && (BS * 8) % 16 == 0 && (CS * 8) % 16 == 0 && (RS * 8) % 16 == 0, "LDS layout of a group");
+    static_assert(GS != 16 || (BYTES + PAIR_PAD) % 256 == 80, "the chain lanes of a pair of groups share a ds_read_b128: rows 0..3 of one beside rows 4..11 of the other");
+    // three workgroups of FIT_WAVES wavefronts per CU: 160 KB in granules of 1280 B (with groups a uniform 3408 B apart the
+    // workgroup took 43 granules and only two fitted: the flag list of eps 1e-4 ran 13 % slower)
+    static_assert(3 * ((FIT_WAVES * WAVE_BYTES + 4 + 1279) / 1280) * 1280 <= 160 * 1024, "three workgroups per CU");
 };
 
 }  // namespace
@@ -228,10 +236,10 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
                                                             const unsigned *__restrict__ list_n)
 {
     constexpr int NSPW = 64 / GS;
-    __shared__ __attribute__((aligned(16))) char s_mem[FIT_WAVES][NSPW][SLds<GS>::BYTES];
+    __shared__ __attribute__((aligned(16))) char s_mem[FIT_WAVES][SLds<GS>::WAVE_BYTES];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     const int g = lane / GS, j = lane & (GS - 1);
-    char *mem = &s_mem[wid][g][0];
+    char *mem = &s_mem[wid][0] + g * SLds<GS>::BYTES + ((g + 1) >> 1) * SLds<GS>::PAIR_PAD;
     float *spot = reinterpret_cast<float *>(mem);
     double *bnd = reinterpret_cast<double *>(mem + SLds<GS>::SPOT);
     double *col = reinterpret_cast<double *>(mem + SLds<GS>::SPOT + SLds<GS>::BND);
@@ -513,7 +521,13 @@ static void launch_strict_gs(const FitParams &p, bool from_movie, const int32_t 
     constexpr int NSPW = 64 / GS;
     const int64_t groups_per_block = (int64_t)FIT_WAVES * NSPW;
     int64_t blocks = (max_items + groups_per_block - 1) / groups_per_block;
-    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)cu_count * 3));
+    // A flag list: three workgroups per CU, all resident, the entries past the first round handed out through the queue word
+    // (more workgroups change nothing: 6.19 - 6.27 ms at eps 1e-4 with 3 ... 24 per CU).  The whole batch (REFILL): every
+    // workgroup owns a fixed share, so the launch ends with its slowest share — twelve workgroups per CU instead of three
+    // (nine of them waiting for a slot) let the hardware deal the shares: config 2, all strict, one box: 10.78 ms per step
+    // with 3 per CU, 10.12 with 4, 9.78 with 6, 9.52 with 12, 9.58 / 9.71 / 9.97 / 10.5 with 16 / 24 / 32 / 48.
+    const int bl_mult = list ? 3 : 12;
+    blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)cu_count * bl_mult));
     static const char *renv = tuning_env("PMI_STRICT_LIST_REFILL");      // tuning: the list's groups refill one by one too
     if (list && renv && atoi(renv)) {
         if (from_movie) hipLaunchKernelGGL((mle_strict_kernel<NP, GS, true, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);

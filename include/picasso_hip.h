@@ -109,18 +109,19 @@ int pmi_scratch_bank(int bank);
  * Output rows are ordered by (frame, y, x); coordinates are frame coordinates.
  * If more than `cap` rows exist, returns PMI_ERR_CAPACITY and *out_n = needed.
  * Every pixel type compares as float32, as in the reference (picasso/localize.py:332).  uint16 / int16 / uint8 movies take the
- * packed scan; float32 / int32 / uint32 movies whose pixels are 16-bit counts are narrowed exactly, chunk by chunk, and take
- * it too; a float32 chunk with any other content (fractions, negatives, NaN, +-inf) is scanned on 16-bit keys — the upper
- * half of the order-preserving integer image of a float32 — with the first-argmax rule, the net gradient and the threshold
- * decided on the float32 pixels; the generic kernel serves boxes 19 / 21, 32-bit integers beyond 16 bits and crops narrower
- * than a stencil.  Same table whichever kernel runs. */
+ * packed scan; float32, int32 and uint32 movies — whatever they hold: counts, fractions, negatives, values beyond 16 bits,
+ * NaN, +-inf — are scanned in one pass on 16-bit keys (the upper half of the order-preserving integer image of the float32
+ * the reference would see; 32-bit integers are converted as its cast does), with the first-argmax rule, the net gradient and
+ * the threshold decided on those float32 values; 32-bit integer movies of 16-bit counts on frames of at most 256 columns are
+ * narrowed to uint16 chunk by chunk instead; the generic kernel serves boxes 19 / 21 and crops narrower than a stencil.
+ * Same table whichever kernel runs. */
 int pmi_identify(const void *movie, int dtype, int64_t F, int64_t Y, int64_t X,
                  int box, double min_ng, const int64_t *roi4, int64_t f_lo, int64_t f_hi,
                  int32_t *out_frame, int32_t *out_y, int32_t *out_x, float *out_ng,
                  int64_t cap, int64_t *out_n);
 
-/* 32-bit movies that hold 16-bit counts pass through a uint16 copy, `frames` frames at a time (0 = default: as many as
- * fit 1 GiB).  A memory knob; the table does not depend on it. */
+/* 32-bit integer movies of 16-bit counts on narrow frames (above) pass through a uint16 copy, `frames` frames at a time
+ * (0 = default: as many as fit 1 GiB).  A memory knob; the table does not depend on it. */
 int pmi_identify_set_narrow_chunk(int64_t frames);
 
 /* Device form.  d_out_n is a device int64 receiving the row count (rows beyond

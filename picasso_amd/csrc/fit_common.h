@@ -90,7 +90,6 @@ struct FitParams {
     int32_t *iterations;
     unsigned long long *queue;   // dynamic spot queue of this batch (counts from 0)
     unsigned *strict_queue;      // mle_strict_kernel over a list: the next entry to hand out (nullptr: entries are dealt round robin)
-    int strict_started;          // mle_strict_kernel<REFILL> over a list: the start values of the list's spots are in their theta rows (mle_strict_start_kernel ran over the list)
     int64_t first;               // first spot of this batch; the kernel handles [first, min(N, *d_n))
     double *fisher;              // upper triangle of the Fisher matrix, 21 doubles per spot of the batch
     // borderline-convergence flags (gaussmle_strict.hip): a spot whose largest tested step |delta| came within

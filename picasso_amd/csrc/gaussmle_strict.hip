@@ -189,7 +189,7 @@ __device__ __forceinline__ void strict_start_values(int B, int j, const float *s
 // wavefront: 0.53 ms for config 2's million spots against 0.75 with 16-lane groups — what is left is the gather of seven
 // movie rows per spot; building the kernel for the box bought 5 %), 4 lanes up to 15x15, 16 above.
 template <int NP, int GS, bool FROM_MOVIE>
-__global__ __launch_bounds__(FIT_NT) void mle_strict_start_kernel(FitParams p, const int32_t *__restrict__ list, const unsigned *__restrict__ list_n)
+__global__ __launch_bounds__(FIT_NT) void mle_strict_start_kernel(FitParams p)
 {
     constexpr int NSPW = 64 / GS;
     extern __shared__ __attribute__((aligned(16))) float s_start[];
@@ -200,13 +200,12 @@ __global__ __launch_bounds__(FIT_NT) void mle_strict_start_kernel(FitParams p, c
     float *fscr = spot + npix;
     int64_t n = p.N;
     if (p.d_n) { int64_t dn = *p.d_n; n = dn < n ? dn : n; }
-    int64_t items = list ? (int64_t)*list_n : n - p.first;
-    if (list && items > n - p.first) items = n - p.first;
+    const int64_t items = n - p.first;
     const int64_t total_groups = (int64_t)gridDim.x * FIT_WAVES * NSPW;
     for (int64_t w0 = ((int64_t)blockIdx.x * FIT_WAVES + wid) * NSPW; w0 < items; w0 += total_groups) {
         const int64_t w = w0 + g;
         const bool have = w < items;
-        const int64_t sidx = list ? (int64_t)list[have ? w : 0] : p.first + (have ? w : 0);
+        const int64_t sidx = p.first + (have ? w : 0);
         strict_load_spot<GS, FROM_MOVIE>(p, sidx, have, j, spot);
         float th[6];
         strict_start_values<NP, GS>(p.box, j, spot, fscr, th);
@@ -221,15 +220,14 @@ __global__ __launch_bounds__(FIT_NT) void mle_strict_start_kernel(FitParams p, c
 }
 
 template <int NP, int GS>
-static void launch_strict_start(const FitParams &p, bool from_movie, int64_t max_items, int cu_count, hipStream_t s,
-                                const int32_t *list = nullptr, const unsigned *list_n = nullptr)
+static void launch_strict_start(const FitParams &p, bool from_movie, int64_t max_items, int cu_count, hipStream_t s)
 {
     constexpr int NSPW = 64 / GS;
     const int64_t groups_per_block = (int64_t)FIT_WAVES * NSPW;
     const int64_t blocks = std::max<int64_t>(1, std::min<int64_t>((max_items + groups_per_block - 1) / groups_per_block, (int64_t)cu_count * 8));
     const size_t lds = (size_t)groups_per_block * (size_t)((p.box * p.box + GS) | 1) * sizeof(float);
-    if (from_movie) hipLaunchKernelGGL((mle_strict_start_kernel<NP, GS, true>), dim3((unsigned)blocks), dim3(FIT_NT), lds, s, p, list, list_n);
-    else hipLaunchKernelGGL((mle_strict_start_kernel<NP, GS, false>), dim3((unsigned)blocks), dim3(FIT_NT), lds, s, p, list, list_n);
+    if (from_movie) hipLaunchKernelGGL((mle_strict_start_kernel<NP, GS, true>), dim3((unsigned)blocks), dim3(FIT_NT), lds, s, p);
+    else hipLaunchKernelGGL((mle_strict_start_kernel<NP, GS, false>), dim3((unsigned)blocks), dim3(FIT_NT), lds, s, p);
 }
 
 // list: spot indices to fit (entries [0, *list_n)), or nullptr = every spot of [p.first, min(p.N, *p.d_n)).
@@ -331,7 +329,7 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
         sidx = list ? (int64_t)list[w] : p.first + w;
 
         strict_load_spot<GS, FROM_MOVIE>(p, sidx, true, j, spot);
-        if (REFILL && (!list || p.strict_started)) {
+        if (REFILL && !list) {
             // (the start values of the batch were computed by mle_strict_start_kernel, four spots per wavefront side by side:
             // here they would run for this group alone with the rest of the wavefront masked)
             const float *from = p.thetas + sidx * 6;
@@ -530,21 +528,10 @@ static void launch_strict_gs(const FitParams &p, bool from_movie, const int32_t 
     // with 3 per CU, 10.12 with 4, 9.78 with 6, 9.52 with 12, 9.58 / 9.71 / 9.97 / 10.5 with 16 / 24 / 32 / 48.
     const int bl_mult = list ? 3 : 12;
     blocks = std::max<int64_t>(1, std::min<int64_t>(blocks, (int64_t)cu_count * bl_mult));
-    static const char *renv = getenv("XX_LIST_MODE");      // TEMPORARY: 1 = refill, start values in the kernel; 2 = refill after a start-value pass over the list
-    static const char *rb = getenv("XX_LIST_BLOCKS");
-    const int lmode = renv ? atoi(renv) : 0;
-    if (list && lmode) {
-        FitParams q = p;
-        q.strict_started = lmode == 2 ? 1 : 0;
-        if (lmode == 2) {
-            if (p.box <= 7) launch_strict_start<NP, 1>(p, from_movie, max_items, cu_count, s, list, list_n);
-            else if (p.box <= 15) launch_strict_start<NP, 4>(p, from_movie, max_items, cu_count, s, list, list_n);
-            else launch_strict_start<NP, 16>(p, from_movie, max_items, cu_count, s, list, list_n);
-        }
-        int64_t b2 = (max_items + groups_per_block - 1) / groups_per_block;
-        b2 = std::max<int64_t>(1, std::min<int64_t>(b2, (int64_t)cu_count * (rb ? atoi(rb) : 12)));
-        if (from_movie) hipLaunchKernelGGL((mle_strict_kernel<NP, GS, true, true>), dim3((unsigned)b2), dim3(FIT_NT), 0, s, q, list, list_n);
-        else hipLaunchKernelGGL((mle_strict_kernel<NP, GS, false, true>), dim3((unsigned)b2), dim3(FIT_NT), 0, s, q, list, list_n);
+    static const char *renv = tuning_env("PMI_STRICT_LIST_REFILL");      // tuning: the list's groups refill one by one too
+    if (list && renv && atoi(renv)) {
+        if (from_movie) hipLaunchKernelGGL((mle_strict_kernel<NP, GS, true, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
+        else hipLaunchKernelGGL((mle_strict_kernel<NP, GS, false, true>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
     } else if (list) {
         if (from_movie) hipLaunchKernelGGL((mle_strict_kernel<NP, GS, true, false>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);
         else hipLaunchKernelGGL((mle_strict_kernel<NP, GS, false, false>), dim3((unsigned)blocks), dim3(FIT_NT), 0, s, p, list, list_n);

@@ -175,7 +175,7 @@ void release_fft_plans();   // xcorr.hip
 
 extern "C" {
 
-int pmi_version(void) { return 104; }   // 0.1.4: round 5 (state keyed by device, pmi_comm_library_path, an eighth reason in pmi_gausslq_last_tie_reasons)
+int pmi_version(void) { return 105; }   // 0.1.5: round 6 (same symbols; 32-bit integer movies on the key scan, side lanes per (device, bank))
 
 const char *pmi_last_error(void) { return pmi::g_err; }
 

@@ -51,6 +51,28 @@ __device__ __forceinline__ double np_min_d(double a, double b) { return (a != a)
 // float32 / float32, correctly rounded (float64 quotient rounds innocuously: 53 >= 2*24 + 2)
 __device__ __forceinline__ float div_rn(float a, float b) { return (float)((double)a / (double)b); }
 
+// n / d for a divisor all pixels of an iteration share, r = RN(1 / d): q = RN(n r) made faithful by one residual correction and
+// correctly rounded by a second (Markstein: with r the correctly rounded reciprocal, q faithful and the residual n - q d exact,
+// RN(q + (n - q d) r) is RN(n / d)) — five multiply-adds against a v_rcp_f64 (quarter rate), two v_div_scale, five fused
+// multiply-adds, v_div_fmas and v_div_fixup.  Exactness of the residuals needs n, q and n - q d inside the exponent range: the
+// caller takes this path only when d is in [2^-92, 2^93] and n is zero or in [2^-400, 2^530] (mid_or_zero on its factors).
+// A zero numerator may come out as +0 where the division gives -0: every use of these quotients multiplies or adds them into
+// float32 accumulators that never hold -0, so the sign of a zero is never seen.
+__device__ __forceinline__ double shared_div(double n, double d, double r)
+{
+    double q = n * r;
+    double e = __builtin_fma(-q, d, n);
+    q = __builtin_fma(e, r, q);
+    e = __builtin_fma(-q, d, n);
+    return __builtin_fma(e, r, q);
+}
+// zero, or an exponent in [2^-200, 2^200) (NaN and infinities fail)
+__device__ __forceinline__ bool mid_or_zero(double v)
+{
+    const unsigned e = ((unsigned)__double2hiint(v) >> 20) & 0x7ffu;
+    return (e - 823u) < 400u || v == 0.0;
+}
+
 __device__ __forceinline__ void lds_sync()
 {
     __builtin_amdgcn_wave_barrier();
@@ -380,6 +402,7 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
             }
             lds_sync();
             // phase B: lane -> (axis, pixel index i): PSF, b - a, (d-.5) b - (d+.5) a, sigma terms
+            bool rec_ok = true;                                  // the factors of this lane's records are zero or of middling size (shared_div)
             for (int jb = j; jb < 2 * B; jb += GS) {
                 const int a = jb >= B ? 1 : 0, i = jb - a * B;
                 const double dmu = (double)(a ? th[1] : th[0]);
@@ -391,6 +414,7 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
                 const double PSF = 0.5 * (q[0] - m[0]);
                 const double bma = m[1] - q[1];
                 const double qq = (d - 0.5) * m[1] - (d + 0.5) * q[1];
+                rec_ok = rec_ok && mid_or_zero(PSF) && mid_or_zero(bma) && mid_or_zero(qq);
                 double S1, S2;
                 if (NP == 6) {
                     const float s2 = sgf * sgf, s3 = sgf * s2, s5 = sgf * (s2 * s2);   // sigma ** n, float32 (:315)
@@ -418,6 +442,14 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
             const float sgx = th[4];
             const double cx = K_SQRT_2PI * (double)sgx, cy = K_SQRT_2PI * (double)sgy;
             const double c3x = K_SQRT_2PI * (double)(sgx * (sgx * sgx)), c3y = K_SQRT_2PI * (double)(sgy * (sgy * sgy));
+            // The four divisions by cx, cy, c3x, c3y of every pixel (gaussmle.py:296-302) share their divisors: reciprocal +
+            // two corrections (shared_div) when every factor of the group's numerators and the divisors are inside the range
+            // its proof needs — sigma in (2^-30, 2^30), photons finite, the column / row records zero or in [2^-200, 2^200) —,
+            // the plain divisions otherwise (a collapsed or exploding fit).  The same bits either way.
+            const unsigned long long okb = __ballot(rec_ok);
+            const unsigned long long gmask = GS == 64 ? ~0ull : (((1ull << (GS & 63)) - 1ull) << (lane & ~(GS - 1)));
+            const bool fast_div = (okb & gmask) == gmask && th[2] < 3.0e38f && sgx < 0x1p30f && sgy < 0x1p30f && sgx > 0x1p-30f && sgy > 0x1p-30f;
+            const double rcx = 1.0 / cx, rcy = 1.0 / cy, rc3x = 1.0 / c3x, rc3y = 1.0 / c3y;
             int ii = j0_ii, jj = j0_jj;                    // (ii, jj) of pixel r0 + j of the sequence, stepped without a division
             for (int r0 = 0; r0 < npix; r0 += GS, ii += gs_ii, jj += gs_jj) {
                 const int seq = r0 + j;
@@ -427,10 +459,17 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
                     const double X[5] = {Xp[0], Xp[CS], Xp[2 * CS], Xp[3 * CS], Xp[4 * CS]}, Yc[5] = {Yp[0], Yp[CS], Yp[2 * CS], Yp[3 * CS], Yp[4 * CS]};
                     const double PSFx = X[0], PSFy = Yc[0];
                     float du[6], d2[6];
-                    du[0] = (float)(N_ * PSFy * X[1] / cx);                          // :296
-                    d2[0] = (float)(N_ * X[2] * PSFy / c3x);                         // :297-302
-                    du[1] = (float)(N_ * PSFx * Yc[1] / cy);
-                    d2[1] = (float)(N_ * Yc[2] * PSFx / c3y);
+                    if (fast_div) {
+                        du[0] = (float)shared_div(N_ * PSFy * X[1], cx, rcx);        // :296
+                        d2[0] = (float)shared_div(N_ * X[2] * PSFy, c3x, rc3x);      // :297-302
+                        du[1] = (float)shared_div(N_ * PSFx * Yc[1], cy, rcy);
+                        d2[1] = (float)shared_div(N_ * Yc[2] * PSFx, c3y, rc3y);
+                    } else {
+                        du[0] = (float)(N_ * PSFy * X[1] / cx);
+                        d2[0] = (float)(N_ * X[2] * PSFy / c3x);
+                        du[1] = (float)(N_ * PSFx * Yc[1] / cy);
+                        d2[1] = (float)(N_ * Yc[2] * PSFx / c3y);
+                    }
                     du[2] = (float)(PSFx * PSFy); d2[2] = 0.f;
                     du[3] = 1.f; d2[3] = 0.f;
                     if (NP == 6) {

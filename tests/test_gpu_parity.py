@@ -559,7 +559,7 @@ def _wide_movie_cases(be, orc, dtype):
 
 
 @pytest.mark.parametrize("kind", ["fractions", "negative_offset", "tiny_scale", "nan_inf", "ties", "mixed_chunks"])
-@pytest.mark.parametrize("box", [5, 7, 9, 13])
+@pytest.mark.parametrize("box", [5, 7, 9, 11, 13, 15, 17])
 def test_identify_float32_movies_with_any_content(be, orc, kind, box):
     """float32 movies that are not 16-bit counts (the reference treats every movie as float32, picasso/localize.py:332): the
     packed scan runs on 16-bit keys — the upper half of the order-preserving integer image of a float32 — and the first-argmax

@@ -12,10 +12,11 @@ F = int(sys.argv[1]) if len(sys.argv) > 1 else 10000
 mov = synth.simulate_movie(F, 512, 512, emitters_per_frame=116, device="cuda").cpu().numpy()
 gb = mov.nbytes / 1e9
 cam = {"Baseline": 100.0, "Sensitivity": 1.0, "Gain": 1.0}
+MIBS = [int(v) for v in sys.argv[2].split(",")] if len(sys.argv) > 2 else [64, 128, 256]
 params = {"Min. Net Gradient": 5000.0, "Box Size": 7}
 localize.localize_streamed(mov[:500], cam, params)
 for devices in (None, [0, 0], None, [0, 0]):
-    for mib in (64, 128, 256):
+    for mib in (MIBS):
         ts = []
         for _ in range(3):
             t0 = time.perf_counter()

@@ -1210,6 +1210,10 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE, PT)) void ident
     flush();
 }
 
+// rows in flight of the key scans (4-byte pixels: a row in flight is eight registers until its keys are built): box 13 with
+// the edge loads four instead of six (253 spilled registers -> 2), boxes 15 / 17 two (seven / eight: 250 spilled)
+constexpr int key_depth(int H, int D, bool EDGE) { return H >= 7 ? 2 : (H == 6 && EDGE ? 4 : D); }
+
 template <int H, int D, int P = 1>
 static int launch_fast(const FastParams &p, int pt, const float *d_tab, Record *recs, long long cap,
                        unsigned long long *shard_cnt, int *frame_count, hipStream_t s)
@@ -1217,13 +1221,13 @@ static int launch_fast(const FastParams &p, int pt, const float *d_tab, Record *
     const long long blocks = (p.units + p.upw - 1) / p.upw;
     if (blocks > 0x7fffffffLL) { set_error("identify: too many blocks (%lld)", blocks); return PMI_ERR_ARG; }
     const dim3 g((unsigned)blocks), b(64);
-    snprintf(g_last_scan_kernel, sizeof(g_last_scan_kernel), "identify_scan_u16_fast_kernel<%d, %d, %d, %d, %s>%s", H, D, P, pt,
-             (P == 1 && p.segs > 1) ? "true" : "false", p.defer ? " defer" : "");
+    const bool edge = P == 1 && p.segs > 1;
+    snprintf(g_last_scan_kernel, sizeof(g_last_scan_kernel), "identify_scan_u16_fast_kernel<%d, %d, %d, %d, %s>%s", H,
+             pt_is_key(pt) ? key_depth(H, D, edge) : D, P, pt, edge ? "true" : "false", p.defer ? " defer" : "");
     if (P > 1 && p.pf) strncat(g_last_scan_kernel, " frames", sizeof(g_last_scan_kernel) - strlen(g_last_scan_kernel) - 1);
     if constexpr (P == 1) {
         if (p.segs > 1) {             // frames wider than a wave: the variant with the edge loads
-            // (box 13 on 4-byte pixels with the edge loads: six rows in flight are 253 spilled registers, four are 2)
-            constexpr int DK = H == 6 ? 4 : D;
+            constexpr int DK = key_depth(H, D, true);
             if (pt == PT_KEY) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, DK, 1, PT_KEY, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
             else if (pt == PT_KEY_I32) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, DK, 1, PT_KEY_I32, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
             else if (pt == PT_KEY_U32) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, DK, 1, PT_KEY_U32, true>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
@@ -1236,13 +1240,14 @@ static int launch_fast(const FastParams &p, int pt, const float *d_tab, Record *
     }
     if constexpr (P == 1) {           // 32-bit integer pixels: one row range per lane set only (launch_scan_u16_fast)
         if (pt == PT_KEY_I32 || pt == PT_KEY_U32) {
-            if (pt == PT_KEY_I32) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_KEY_I32>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
-            else hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, 1, PT_KEY_U32>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+            constexpr int DK = key_depth(H, D, false);
+            if (pt == PT_KEY_I32) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, DK, 1, PT_KEY_I32>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+            else hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, DK, 1, PT_KEY_U32>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
             PMI_HIP(hipGetLastError());
             return PMI_OK;
         }
     }
-    if (pt == PT_KEY) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_KEY>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
+    if (pt == PT_KEY) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, key_depth(H, D, false), P, PT_KEY>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
     else if (pt == PT_U8) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_U8>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
     else if (pt == PT_I16) hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_I16>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
     else hipLaunchKernelGGL((identify_scan_u16_fast_kernel<H, D, P, PT_U16>), g, b, 0, s, p, d_tab, recs, cap, shard_cnt, frame_count);
@@ -1434,8 +1439,11 @@ int launch_scan_u16_fast(const void *d_movie, int dtype, int64_t Y, int64_t X, i
         if (pack == 2) rc = launch_fast<6, 3, 2>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
         else rc = launch_fast<6, FAST_D_H6>(p, pt, d_tab, recs, cap, n_total, frame_count, s);
         break;
-    case 7: rc = launch_fast<7, 2>(p, pt, d_tab, recs, cap, n_total, frame_count, s); break;
-    default: rc = launch_fast<8, 2>(p, pt, d_tab, recs, cap, n_total, frame_count, s); break;
+    // boxes 15 and 17 (round 6): seven / eight rows in flight instead of two — with D = H the rows in flight and the pixel history
+    // are one ring again and the kernel needs no more registers than before (215 / 240; its peak is the exact stage); at two
+    // waves per SIMD and two rows each a CU had 16 KB of loads in flight, a third of what the memory system needs
+    case 7: rc = launch_fast<7, 7>(p, pt, d_tab, recs, cap, n_total, frame_count, s); break;
+    default: rc = launch_fast<8, 8>(p, pt, d_tab, recs, cap, n_total, frame_count, s); break;
     }
     if (rc == PMI_OK) *handled = true;
     return rc;

@@ -215,8 +215,8 @@ constexpr int fast_round(int H) { return H <= 4 ? FAST_ROUND_SMALL : FAST_ROUND_
 #endif
 constexpr int fast_waves_per_simd(int H, int P, bool EDGE, int PT = 0)
 {
-    // (frames wider than the wave: the edge loads are 16 or 32 bytes more per row in flight — 246 spilled registers at box 7, 80 at box 9)
-    if (PT >= 3 /* the key scans */ && EDGE && H >= 3) return H == 3 ? 3 : 2;
+    // (frames wider than the wave: the edge loads are 16 or 32 bytes more per row in flight — 246 spilled registers at box 7, 80 at box 9, 41-73 at box 5)
+    if (PT >= 3 /* the key scans */ && EDGE && H >= 2) return H <= 3 ? 3 : 2;
     if (PT >= 3 && H >= 4) return H == 4 ? FAST_KEY_WAVES_H4 : 2;
     return H <= 3 ? FAST_MIN_WAVES : (H == 4 ? FAST_WAVES_H4 : (H == 5 ? (P == 1 ? FAST_WAVES_H5 : 2) : (H == 6 ? (P == 1 && !EDGE ? FAST_WAVES_H6 : 2) : 2)));
 }

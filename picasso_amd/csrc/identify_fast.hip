@@ -220,6 +220,9 @@ constexpr int fast_waves_per_simd(int H, int P, bool EDGE, int PT = 0)
     if (PT >= 3 && H >= 4) return H == 4 ? FAST_KEY_WAVES_H4 : 2;
     return H <= 3 ? FAST_MIN_WAVES : (H == 4 ? FAST_WAVES_H4 : (H == 5 ? (P == 1 ? FAST_WAVES_H5 : 2) : (H == 6 ? (P == 1 && !EDGE ? FAST_WAVES_H6 : 2) : 2)));
 }
+#ifndef FAST_RING_MARGIN
+#define FAST_RING_MARGIN 128   // free entries of the candidate ring below which a chunk ends after the current flush group (= LIST - THRESH: where a ring that is drained only when nearly full is drained)
+#endif
 #ifndef FAST_UNI_MIN_H
 #define FAST_UNI_MIN_H 3      // smallest half-width whose scan keeps rows in flight and pixel history in one ring (box 5: 4.6 -> 4.3 TB/s with it, its two rows in flight are issued too late in the step)
 #endif
@@ -925,6 +928,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE, PT)) void ident
             }
 
             int sb = 0;
+            bool ring_full = false;
             for (; sb < nr; sb += U_) {
 #pragma unroll
                 for (int u = 0; u < U_; u++) {
@@ -1065,7 +1069,8 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE, PT)) void ident
                             pass &= ~((c & 0x0fff0fffu) << 4);                     // same pixel, one row up (previous row slot)
                         }
                         acc = 0;
-                        tail_lf = tail; rd_lf = rd0;
+                        if (ring_full) pass = 0u;                          // the ring is nearly full: the rest of this period's rows are left to the next chunk
+                        else { tail_lf = tail; rd_lf = rd0; }
                         // Append to the wave's ring: every round each lane that still has a candidate emits its
                         // lowest one, slots come from a ballot prefix count and the ring state stays in scalar
                         // registers.  (An LDS atomicAdd per lane is turned into a serial per-lane scan by the
@@ -1123,16 +1128,24 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE, PT)) void ident
                             fi_ = no_floor ? 0u : fi_;
                             F = fi_ | (fi_ << 16);
                         }
+                        // The ring is looked at after every flush group, not only once per unroll period (6 ... 16 rows): on
+                        // low-count 8-bit movies at boxes >= 15 — a quantised background where the floor cannot bite and two
+                        // pixels in a hundred tie for their window's maximum — a period's rows overflowed it, the chunk counted
+                        // as flooded and was rescanned pixel by pixel (20 GB/s instead of 1.3 Tpx/s, round 6).
+                        // (no branch out of the unrolled period: it would cost the register rings their static indices.  From here
+                        // to the period's end nothing is appended, and the chunk ends AFTER this group: one more row streams behind
+                        // it — unless this is the period's last step —, so the check of the floor's assumption covers its rows.)
+                        if (!ring_full && u < U_ - 1 && tail - head > LIST - FAST_RING_MARGIN && rd0 + t4 + 1 > clo) { ring_full = true; tail_lf = tail; rd_lf = rd0 + t4 + 1; }
                     }
                 }
-                if ((tail - head >= trigger && rd_lf > clo) || added > LIST - 64) { sb += U_; break; }
+                if (ring_full || (tail - head >= trigger && rd_lf > clo) || added > LIST - 64) { sb += U_; break; }
             }
             // Rows decided: every row whose decision step lies before sb.  A chunk that ends early (sb < nr) keeps
             // only the rows before its latest flush group: the neighbourhoods of those have streamed in completely,
             // so the check of the floor's assumption below covers them.
             bool flooded = added > LIST - (tail0 - head);
             int dn = min(len, sb - 2 * H - 1);
-            if (sb < nr && !flooded) { tail = tail_lf; dn = rd_lf - clo; }
+            if ((sb < nr || ring_full) && !flooded) { tail = tail_lf; dn = min(len, rd_lf - clo); }
             // a chunk that ended before it decided a single row (the ring filled within its first rows: whole rows of equal
             // keys, where the neighbour rule does not apply) makes no progress: one row the slow way
             if (dn < 1) { flooded = true; dn = 1; }
@@ -1192,7 +1205,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE, PT)) void ident
             }
             // (evaluating in place, inside the row loop, was tried: the scan's 120 live registers and the round's 50
             // do not fit, and the spills land in the row loop — 5.1 ms instead of 1.5)
-            if (!filter || tail - head >= trigger) {
+            if (!filter || tail - head >= trigger || ring_full) {
                 while (tail - head >= 64) exact_round(64);
                 if (filter) {
                     if (tail - head >= ROUND || (trigger < ROUND && tail > head)) exact_round(tail - head);

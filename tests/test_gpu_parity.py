@@ -650,6 +650,31 @@ def test_identify_32bit_integer_movies_through_the_key_scan(be, orc, dtype, box)
     assert len(b[0]) > 10
 
 
+@pytest.mark.parametrize("box", [9, 13, 15, 17])
+@pytest.mark.parametrize("dtype", [np.uint8, np.uint16])
+def test_identify_tie_dense_low_count_movies(be, orc, dtype, box):
+    """A quantised low-count background (Poisson(15): half a dozen distinct values) at a threshold the floor cannot bite on: one
+    or two pixels in a hundred tie for the maximum of their window and fill the wave's candidate ring within a few rows.  Round 6:
+    the ring is looked at after every flush group (a chunk ends with the group that leaves fewer than 128 free entries) — before,
+    at boxes 15 / 17 an unroll period's rows overflowed it and the chunk was rescanned pixel by pixel (the path of saturated
+    fiducials: the same table, at 20 GB/s).  The table is the oracle's bit for bit either way; this keeps the ring-full path
+    under test: frames wider than a wavefront's 512 columns too."""
+    rng = np.random.default_rng(77 + box)
+    for (F, Y, X) in ((4, 150, 512), (2, 90, 1100)):
+        mov = rng.poisson(15, size=(F, Y, X)).astype(np.float64)
+        for f in range(F):
+            for _ in range(8):
+                y, x = rng.integers(12, Y - 12), rng.integers(12, X - 12)
+                yy, xx = np.mgrid[y - 9:y + 10, x - 9:x + 10]
+                mov[f, y - 9:y + 10, x - 9:x + 10] += np.rint(rng.uniform(60, 200) * np.exp(-0.5 * ((yy - y) ** 2 + (xx - x) ** 2) / 1.4 ** 2))
+        mov = np.minimum(mov, 255).astype(dtype)
+        for min_ng in (600.0, 150.0, -1e9):
+            a = be.identify_arrays(mov, min_ng, box)
+            b = orc.identify(mov, min_ng, box, threads=4)
+            assert len(a[0]) == len(b[0]) and all(np.array_equal(p, q) for p, q in zip(a, b)), (dtype, box, (F, Y, X), min_ng, len(a[0]), len(b[0]))
+    assert len(b[0]) > 100
+
+
 def test_identify_capacity_retry(be, orc, testdata_movie):
     """More rows than the first capacity guess: PMI_ERR_CAPACITY -> retry with the exact count."""
     rng = np.random.default_rng(5)

@@ -525,6 +525,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE, PT)) void ident
     // Candidate ring: entries (row << 16 | column in the aligned row) + frame index.  A chunk of rows ends early when
     // the ring holds THRESH entries (only without the floor filter, i.e. min_ng <= 0: 2 % of the pixels are maxima).
     constexpr int LIST = 1024, THRESH = LIST - 128;
+    constexpr bool RING_CHECK_PER_GROUP = !(H == 3 && PT == PT_U16 && P == 1 && !EDGE);      // see the row loop
 
     __shared__ unsigned s_pos[LIST];
     __shared__ unsigned s_fi[LIST];
@@ -1069,13 +1070,14 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE, PT)) void ident
                             pass &= ~((c & 0x0fff0fffu) << 4);                     // same pixel, one row up (previous row slot)
                         }
                         acc = 0;
-                        if (ring_full) pass = 0u;                          // the ring is nearly full: the rest of this period's rows are left to the next chunk
+                        if (RING_CHECK_PER_GROUP && ring_full) pass = 0u;   // the ring is nearly full: the rest of this period's rows are left to the next chunk
                         else { tail_lf = tail; rd_lf = rd0; }
                         // Append to the wave's ring: every round each lane that still has a candidate emits its
                         // lowest one, slots come from a ballot prefix count and the ring state stays in scalar
                         // registers.  (An LDS atomicAdd per lane is turned into a serial per-lane scan by the
                         // compiler's atomic optimizer: ~9 SALU instructions per active lane, per flush.)
                         const u32 ebase = ((u32)(rd0 + sub_rows) << 16) + (u32)(c8 << 3);
+                        int grp_added = 0;                             // candidates of this flush group
                         for (;;) {
                             const bool has = pass != 0;
                             const unsigned long long bal = __ballot(has);
@@ -1090,6 +1092,7 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE, PT)) void ident
                             }
                             const int nb_ = __popcll(bal);
                             added += nb_;
+                            if constexpr (RING_CHECK_PER_GROUP) grp_added += nb_;
                             tail = min(tail + nb_, head + LIST);
                         }
                         // ---- the floor for the decisions of the next flush group ----
@@ -1135,7 +1138,13 @@ __global__ __launch_bounds__(64, fast_waves_per_simd(H, P, EDGE, PT)) void ident
                         // (no branch out of the unrolled period: it would cost the register rings their static indices.  From here
                         // to the period's end nothing is appended, and the chunk ends AFTER this group: one more row streams behind
                         // it — unless this is the period's last step —, so the check of the floor's assumption covers its rows.)
-                        if (!ring_full && u < U_ - 1 && tail - head > LIST - FAST_RING_MARGIN && rd0 + t4 + 1 > clo) { ring_full = true; tail_lf = tail; rd_lf = rd0 + t4 + 1; }
+                        // (room for twice what this group added, at least FAST_RING_MARGIN: a tie-dense movie at a threshold the
+                        // floor cannot bite on adds 150 and more per group)
+                        // (the hand-scheduled box-7 scan of uint16 frames no wider than the wave — config 2's kernel — keeps the check
+                        // per period: with this one the step with two frame ranges in flight was 1.5 % slower, same box, alternating:
+                        // 2.71 - 2.73 against 2.67 - 2.68 ms; alone the two scans take the same 1.00 - 1.03 ms)
+                        if constexpr (RING_CHECK_PER_GROUP)
+                        if (!ring_full && u < U_ - 1 && tail - head > LIST - max(FAST_RING_MARGIN, 2 * grp_added) && rd0 + t4 + 1 > clo) { ring_full = true; tail_lf = tail; rd_lf = rd0 + t4 + 1; }
                     }
                 }
                 if (ring_full || (tail - head >= trigger && rd_lf > clo) || added > LIST - 64) { sb += U_; break; }

@@ -321,23 +321,31 @@ def main():
     mle_mode, mle_margin = backend.get_mle_mode()
     refit = backend.last_refit_count(stream)
     scan_kernel = last_scan_kernel(L)
-    strict_ms = None
+    strict_ms = strict_dev_ms = None
     if args.strict_steps > 0 and mle_mode != "strict":
-        backend.set_mle_mode("strict", mle_margin)
-        try:
+        def strict_pass():
             run(table, d_n, cap)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(args.strict_steps):
                 run(table, d_n, cap)
             torch.cuda.synchronize()
-            strict_ms = 1e3 * (time.perf_counter() - t1) / args.strict_steps
+            return 1e3 * (time.perf_counter() - t1) / args.strict_steps
+        libm = backend.get_mle_libm()
+        backend.set_mle_mode("strict", mle_margin)
+        try:
+            strict_ms = strict_pass()
+            # ... and with the device library's erf / exp instead of glibc's bits (pmi_mle_set_libm: the kernel of round 5's
+            # arithmetic; the default pays for the reference's C library bit for bit, csrc/libm_glibc.h)
+            backend.set_mle_libm("device")
+            strict_dev_ms = strict_pass()
         finally:
+            backend.set_mle_libm(libm)
             backend.set_mle_mode(mle_mode, mle_margin)
         if grouped:
-            st = torch.tensor([strict_ms], dtype=torch.float64, device=dev)
+            st = torch.tensor([strict_ms, strict_dev_ms], dtype=torch.float64, device=dev)
             dist.all_reduce(st, op=dist.ReduceOp.MAX)
-            strict_ms = float(st.item())
+            strict_ms, strict_dev_ms = float(st[0].item()), float(st[1].item())
 
     result = None
     if rank == 0:
@@ -378,6 +386,7 @@ def main():
             # every spot in the reference's arithmetic (pmi_mle_set_mode strict), the same step, after the timed ones (no all-gather)
             "ms_per_step_strict": strict_ms,
             "value_strict": (n_total / (strict_ms * 1e-3)) if strict_ms else None,
+            "ms_per_step_strict_device_libm": strict_dev_ms,      # the same with the device library's erf / exp (PMI_LIBM_DEVICE)
             "refit_fraction": (refit / n_rank0) if n_rank0 else None,
             # float32 Newton loop; spots whose convergence test falls within rounding distance of eps are fitted again
             # with the reference's float64 intermediates INSIDE the timed step (csrc/gaussmle_strict.hip)

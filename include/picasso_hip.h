@@ -169,7 +169,7 @@ int pmi_gaussmle_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y,
  *                   distance of eps can end the fit an iteration earlier or later than the reference does;
  *   PMI_MLE_REFIT   (default) float32 loop, and every spot on which the two arithmetics can part — its largest tested
  *                   step came within `margin` (relative) of eps in some iteration; a curvature term was not negative;
- *                   a width fell below 0.3 px; a parameter swung back and forth without its steps shrinking (the
+ *                   a width fell below 0.5 px; a parameter swung back and forth without its steps shrinking (the
  *                   iteration does not contract); a pixel lay far off the model (|data / model - 1| or
  *                   |data / model^2| above 16); the fit took more than 64 iterations; or, seen from the Fisher matrix at the
  *                   fitted theta, the per-parameter update does not contract there (lambda_max of the normalised
@@ -186,6 +186,22 @@ int pmi_gaussmle_movie_dev(const void *d_movie, int dtype, int64_t F, int64_t Y,
 enum pmi_mle_mode { PMI_MLE_FAST = 0, PMI_MLE_REFIT = 1, PMI_MLE_STRICT = 2 };
 int pmi_mle_set_mode(int mode, double margin);
 int pmi_mle_get_mode(int *mode, double *margin);
+/* math.erf / math.exp of the reference (gaussmle.py:279, 295, 313, 357) are the C library's under numba, and faithful, not
+ * correctly rounded: which last bit they return depends on the libm.  A fit that contracts mostly forgets such a bit when
+ * it rounds to float32; a fit that does not — 3x3 boxes whose width collapses, fits that wander for a thousand iterations —
+ * carries it into another trajectory.  The reference-arithmetic kernel (the re-fit of PMI_MLE_REFIT, every spot of
+ * PMI_MLE_STRICT) evaluates the two functions
+ *   PMI_LIBM_GLIBC   (default) operation for operation as glibc >= 2.28 on x86-64 with FMA does (the libm of the machines
+ *                    the reference runs on, and of the oracle's) — csrc/libm_glibc.h;
+ *   PMI_LIBM_DEVICE  with the device library's functions (the behaviour up to round 5; the kernel is 12 - 15 % faster,
+ *                    and on 1e6 ordinary 7x7 fits no row differs).
+ * Process-wide; the environment variable PMI_MLE_LIBM = glibc | device overrides it.                              */
+enum pmi_libm { PMI_LIBM_DEVICE = 0, PMI_LIBM_GLIBC = 1 };
+int pmi_mle_set_libm(int which);
+int pmi_mle_get_libm(int *which);
+/* Diagnostic: d_out[i] = f(d_x[i]) for n float64 device values — fn 0 / 1: exp / erf as the kernel evaluates them under
+ * PMI_LIBM_GLIBC (the test compares them with the host's C library, bit for bit); fn 2 / 3: the device library's.     */
+int pmi_libm_eval_dev(int fn, const double *d_x, int64_t n, double *d_out, void *stream);
 int pmi_mle_last_refit_count(int64_t *n_refit, void *stream);
 int pmi_mle_last_flag_reasons(int64_t *counts, int n, void *stream);
 

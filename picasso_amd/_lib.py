@@ -60,6 +60,9 @@ SYMBOLS = {
                                       _f64, _i32, _i32, _p, _p, _p, _p, _p]),
     "pmi_mle_set_mode": (_i32, [_i32, _f64]),
     "pmi_mle_get_mode": (_i32, [_p, _p]),
+    "pmi_mle_set_libm": (_i32, [_i32]),
+    "pmi_mle_get_libm": (_i32, [_p]),
+    "pmi_libm_eval_dev": (_i32, [_i32, _p, _i64, _p, _p]),
     "pmi_mle_last_refit_count": (_i32, [_p, _p]),
     "pmi_mle_last_flag_reasons": (_i32, [_p, _i32, _p]),
     "pmi_locs_from_fits_dev": (_i32, [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _p, _i32, _p, _p]),

@@ -151,6 +151,24 @@ def get_mle_mode():
     return {v: k for k, v in MLE_MODES.items()}[m.value], g.value
 
 
+MLE_LIBMS = {"device": 0, "glibc": 1}
+
+
+def set_mle_libm(which: str = "glibc"):
+    """Whose erf / exp the reference-arithmetic MLE kernel evaluates (pmi_mle_set_libm): "glibc" (default) = the bits of
+    the C library the reference's math.erf / math.exp resolve to under numba (picasso/gaussmle.py:279, 295); "device" =
+    the device library's functions (12 - 15 % faster, another last bit on a few arguments in a hundred)."""
+    if which not in MLE_LIBMS:
+        raise ValueError(f"unknown libm {which!r}")
+    _lib.check(_lib.load().pmi_mle_set_libm(MLE_LIBMS[which]), "pmi_mle_set_libm")
+
+
+def get_mle_libm() -> str:
+    w = ctypes.c_int(0)
+    _lib.check(_lib.load().pmi_mle_get_libm(ctypes.byref(w)), "pmi_mle_get_libm")
+    return {v: k for k, v in MLE_LIBMS.items()}[w.value]
+
+
 def last_refit_count(stream=None) -> int:
     """Spots the last MLE call OF THE CALLING THREAD fitted a second time (synchronises `stream`).  The library keeps these
     statistics — like the scratch bank, `last_flag_reasons`, `last_lq_refit_count`, `last_lq_tie_reasons` — per thread: read

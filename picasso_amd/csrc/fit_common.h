@@ -83,7 +83,7 @@ struct FitParams {
     int64_t N;             // capacity / number of rows
     const int64_t *d_n;    // optional device row count
     int box;
-    float eps_f;           // unused (kept for layout)
+    int libm_glibc;        // mle_strict_kernel: erf / exp operation for operation as glibc's (libm_glibc.h) instead of the device library's
     double eps;
     int max_it;
     float *thetas, *crlbs, *loglik;
@@ -137,7 +137,8 @@ enum { FIT_STAGE_NEWTON = 1, FIT_STAGE_FINAL = 2, FIT_STAGE_INIT_ONLY = 4, FIT_S
 // 64 and without it — and at 32 it re-fits healthy fits wherever they are naturally long (eps 1e-4: 6 % of config 2's
 // spots, 5x5 boxes: 30 %).  64 keeps the fits that run into the default max_it among the re-fitted.
 constexpr int FIT_SLOW_ITERATIONS = 64;
-constexpr float FIT_NARROW_SIGMA = 0.3f;      // a fitted width below this (px) sends the spot to the re-fit
+constexpr float FIT_NARROW_SIGMA = 0.5f;      // a fitted width below this (px) sends the spot to the re-fit (0.3 until round 6: 5x5 and
+                                              // 7x7 fits of 0.31 ... 0.495 px at eps 1e-4 ended an iteration off the reference, no other flag raised)
 // the alternating component of a parameter's step sequence (second difference) that changes sign without shrinking below
 // FIT_WOBBLE_RATIO of its previous size, above the rounding floor (FIT_WOBBLE_FLOOR x |value| = 16 float32 ulps), for
 // FIT_WOBBLE_RUN iterations in a row — two in a row from iteration FIT_WOBBLE_LATE on, where a healthy fit's step clamps

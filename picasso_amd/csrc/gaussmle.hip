@@ -610,6 +610,8 @@ static int build_accept_list(const unsigned char *accept, int64_t first, int64_t
 //   PMI_MLE_STRICT  every spot in the reference's arithmetic
 static int g_mle_mode = PMI_MLE_REFIT;
 static double g_mle_margin = 0.001;
+// erf / exp of the reference-arithmetic kernel (pmi_mle_set_libm): glibc's bits (libm_glibc.h) or the device library's
+static int g_mle_libm = PMI_LIBM_GLIBC;
 // flag statistics of the calling thread's last fit: a device buffer of its own (SCR_STATS of the thread's scratch bank:
 // [0] = spots re-fitted, [1..FLAG_REASONS] = spots flagged per criterion), valid while the scratch generation stands
 static thread_local const unsigned *g_last_stats[2] = {nullptr, nullptr};      // [1]: the second frame range of a fused call
@@ -640,6 +642,15 @@ static int mle_mode_now()
         if (!strcmp(env, "refit")) return PMI_MLE_REFIT;
     }
     return g_mle_mode;
+}
+static int mle_libm_now()
+{
+    static const char *env = getenv("PMI_MLE_LIBM");      // "glibc" | "device" overrides pmi_mle_set_libm
+    if (env) {
+        if (!strcmp(env, "glibc")) return PMI_LIBM_GLIBC;
+        if (!strcmp(env, "device")) return PMI_LIBM_DEVICE;
+    }
+    return g_mle_libm;
 }
 
 int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
@@ -683,6 +694,7 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, (unsigned *)ptr, (int)(nb * 10), stats, 16);
     p.flag_reasons = stats + 1;
     p.fisher = (double *)fptr;
+    p.libm_glibc = mle_libm_now() == PMI_LIBM_GLIBC;
     static const char *menv = tuning_env("PMI_MLE_MARGIN");       // overrides the margin of pmi_mle_set_mode (tuning runs)
     const double margin = menv ? atof(menv) : g_mle_margin;
     // The tested step |delta| is a difference of float32 coordinates near box/2, i.e. a multiple of their ulp: the
@@ -900,6 +912,20 @@ int pmi_mle_set_mode(int mode, double margin)
     if (!(margin >= 0.0 && margin < 1.0)) { set_error("margin must lie in [0, 1)"); return PMI_ERR_ARG; }
     g_mle_mode = mode;
     g_mle_margin = margin;
+    return PMI_OK;
+}
+
+int pmi_mle_set_libm(int which)
+{
+    using namespace pmi;
+    if (which != PMI_LIBM_DEVICE && which != PMI_LIBM_GLIBC) { set_error("unknown libm %d", which); return PMI_ERR_ARG; }
+    g_mle_libm = which;
+    return PMI_OK;
+}
+
+int pmi_mle_get_libm(int *which)
+{
+    if (which) *which = pmi::mle_libm_now();
     return PMI_OK;
 }
 

@@ -37,9 +37,16 @@
 
 #pragma clang fp contract(off)
 
+#include "libm_glibc.h"
+
 namespace pmi {
 
 namespace {
+
+// 2^(k/128) for pmi_glibc::exp
+__constant__ uint64_t k_glibc_exp_tab[PMI_GLIBC_EXP_TABLE_WORDS] = {
+#include "libm_glibc_exp_table.inc"
+};
 
 typedef double d2_t __attribute__((ext_vector_type(2)));
 constexpr double K_SQRT_2PI = 2.5066282746310002;   // np.sqrt(2.0 * np.pi)
@@ -105,6 +112,7 @@ template <int GS> struct SLds {
     static constexpr int PAIR_PAD = GS == 16 ? 112 : 0;
     static constexpr int NSPW = 64 / GS;
     static constexpr int WAVE_BYTES = NSPW * BYTES + (NSPW / 2) * PAIR_PAD;
+    static_assert(4 * CS * 8 <= TERM, "the plus-boundary records of a group with a coordinate next to zero live in the term array (phase A)");
     static_assert(BYTES % 16 == 0 && PAIR_PAD % 16 == 0 && (BS * 8) % 16 == 0 && (CS * 8) % 16 == 0 && (RS * 8) % 16 == 0, "LDS layout of a group");
     static_assert(GS != 16 || (BYTES + PAIR_PAD) % 256 == 80, "the chain lanes of a pair of groups share a ds_read_b128: rows 0..3 of one beside rows 4..11 of the other");
     // three workgroups of FIT_WAVES wavefronts per CU: 160 KB in granules of 1280 B (with groups a uniform 3408 B apart the
@@ -304,6 +312,7 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
     int64_t w_lim = w0 + 2 * NSPW;                                       // end of the entries this wavefront holds
 
     const int nb = B + 1;
+    const bool glibc = p.libm_glibc != 0;          // erf / exp with glibc's bits (the reference's C library) or the device library's
     const int j0_ii = j / B, j0_jj = j - j0_ii * B, gs_ii = GS / B, gs_jj = GS - gs_ii * B;
     bool have = false, active = false, exhausted = false;
     int64_t sidx = 0;
@@ -375,30 +384,47 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
         {
             const float sgy = NP == 6 ? th[5] : th[4];
             // phase A: lane -> (axis, boundary k)
-            for (int ja = j; ja < 2 * nb; ja += GS) {            // (one pass unless the group is narrower than 2 (B + 1) lanes)
-                const int a = ja >= nb ? 1 : 0, k = ja - a * nb;
+            // A coordinate closer to zero than 2^-24 (and not zero) has bits below the last place of k - mu: (k - mu) + 1/2 and
+            // ((k + 1) - mu) - 1/2 then round differently, and the plus boundary of pixel k is no longer the minus boundary of
+            // pixel k + 1.  Such a group evaluates the 2 B plus boundaries as records of their own (in the term array, which
+            // is idle until phase C): a centre that sits on the first pixel's middle to 1e-17 px is a fuzzer's spot, but its
+            // bits are the reference's too.
+            const bool split = (th[0] != 0.f && fabsf(th[0]) < 0x1p-24f) || (th[1] != 0.f && fabsf(th[1]) < 0x1p-24f);
+            double *const plus = term;                           // record (a, i) = a * B + i, field q at plus[q * CS + ...]
+            for (int ja = j; ja < 2 * nb + (split ? 2 * B : 0); ja += GS) {      // (one pass unless the group is narrower than 2 (B + 1) lanes)
+                const bool pl = ja >= 2 * nb;
+                const int jr = pl ? ja - 2 * nb : ja;
+                const int a = jr >= (pl ? B : nb) ? 1 : 0, k = jr - a * (pl ? B : nb);
                 const double dmu = (double)(a ? th[1] : th[0]);
                 const float sgf = a ? sgy : th[4];
                 const double ds = (double)sgf;
-                const double b = k < B ? ((double)k - dmu) - 0.5 : ((double)(B - 1) - dmu) + 0.5;
+                const double b = pl ? ((double)k - dmu) + 0.5 : (k < B ? ((double)k - dmu) - 0.5 : ((double)(B - 1) - dmu) + 0.5);
                 const double sq_norm = 0.70710678118654757 / ds;                     // :276
-                const double eA = erf(b * sq_norm);                                  // :279
                 const double t = b / ds;
-                const double eD = exp(-0.5 * (t * t));                               // :294-295
+                double eA, eD;
+                if (glibc) {
+                    eA = pmi_glibc::erf(b * sq_norm, k_glibc_exp_tab);               // :279
+                    eD = pmi_glibc::exp(-0.5 * (t * t), k_glibc_exp_tab);            // :294-295
+                } else {
+                    eA = erf(b * sq_norm);
+                    eD = exp(-0.5 * (t * t));
+                }
                 double v2, v3;
                 if (NP == 6) {
                     const float s2 = sgf * sgf;
-                    const double eG = exp(-(b * b) / (2.0 * (double)s2));            // :312-313
+                    const double aG = -(b * b) / (2.0 * (double)s2);
+                    const double eG = glibc ? pmi_glibc::exp(aG, k_glibc_exp_tab) : exp(aG);      // :312-313
                     v2 = b * eG;                                                     // a ** 1 * exp
                     v3 = (b * (b * b)) * eG;                                         // a ** 3 * exp (square-and-multiply)
                 } else {
                     const double ai = b / (K_SQRT_2 * ds);                           // :354-357
-                    const double ex = exp(-(ai * ai));
+                    const double ex = glibc ? pmi_glibc::exp(-(ai * ai), k_glibc_exp_tab) : exp(-(ai * ai));
                     v2 = ai * ex;                                                    // term of Fx / Fy (:359)
-                    v3 = (ai * ex) * (1.0 - 2.0 * (ai * ai));                        // term of dFxdt / dFydy (:364-371)
+                    v3 = (ai * ex) * (1.0 - 2.0 * (ai * ai));                        // :364-371
                 }
-                double *o = bnd + ja;                                                // record (a, k) = a * nb + k, field q at o[q * BS]
-                o[0] = eA; o[BS] = eD; o[2 * BS] = v2; o[3 * BS] = v3;
+                double *o = pl ? plus + jr : bnd + jr;                               // record (a, k), field q at o[q * stride]
+                const int os = pl ? CS : BS;
+                o[0] = eA; o[os] = eD; o[2 * os] = v2; o[3 * os] = v3;
             }
             lds_sync();
             // phase B: lane -> (axis, pixel index i): PSF, b - a, (d-.5) b - (d+.5) a, sigma terms
@@ -409,7 +435,9 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
                 const float sgf = a ? sgy : th[4];
                 const double ds = (double)sgf;
                 const double *mq = bnd + (a * nb + i);                               // minus boundary; the plus boundary is the next record
-                const double m[4] = {mq[0], mq[BS], mq[2 * BS], mq[3 * BS]}, q[4] = {mq[1], mq[BS + 1], mq[2 * BS + 1], mq[3 * BS + 1]};
+                const double *pq = split ? plus + jb : mq + 1;                       // (or a record of its own, see phase A)
+                const int ps = split ? CS : BS;
+                const double m[4] = {mq[0], mq[BS], mq[2 * BS], mq[3 * BS]}, q[4] = {pq[0], pq[ps], pq[2 * ps], pq[3 * ps]};
                 const double d = (double)i - dmu;
                 const double PSF = 0.5 * (q[0] - m[0]);
                 const double bma = m[1] - q[1];
@@ -605,4 +633,23 @@ void launch_fit_strict(const FitParams &p, int method, bool from_movie, const in
     }
 }
 
+__global__ void libm_eval_kernel(int fn, const double *__restrict__ x, int64_t n, double *__restrict__ out)
+{
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = x[i];
+    out[i] = fn == 0 ? pmi_glibc::exp(v, k_glibc_exp_tab) : (fn == 1 ? pmi_glibc::erf(v, k_glibc_exp_tab) : (fn == 2 ? exp(v) : erf(v)));
+}
+
 }  // namespace pmi
+
+extern "C" int pmi_libm_eval_dev(int fn, const double *d_x, int64_t n, double *d_out, void *stream)
+{
+    using namespace pmi;
+    if (fn < 0 || fn > 3) { set_error("fn: 0 exp, 1 erf as in libm_glibc.h; 2 exp, 3 erf of the device library"); return PMI_ERR_ARG; }
+    if (n < 0) { set_error("negative n"); return PMI_ERR_ARG; }
+    if (n == 0) return PMI_OK;
+    hipLaunchKernelGGL(libm_eval_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, fn, d_x, n, d_out);
+    PMI_HIP(hipGetLastError());
+    return PMI_OK;
+}

@@ -1,0 +1,65 @@
+#!/usr/bin/env python3
+"""Differential run on the fits that can hang on the last bit of an erf: 3x3 and 5x5 boxes, narrow and off-centre spots,
+both methods, strict mode (theta and iterations bit for bit) and the default mode (iterations; 1e-3 px where converged) —
+once with glibc's erf / exp (csrc/libm_glibc.h, the default) and once with the device library's functions.
+usage: [BOXES=3,3,3,5] [LIBMS=glibc,device] python tools/fuzz_mle_libm.py [seconds] [seed] [dump dir]"""
+import os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import oracle as orc
+from picasso_amd import backend as be
+
+budget = float(sys.argv[1]) if len(sys.argv) > 1 else 60.0
+rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 11)
+t_end = time.time() + budget
+dump = sys.argv[3] if len(sys.argv) > 3 else None
+if dump:
+    os.makedirs(dump, exist_ok=True)
+rows = 0
+BOXES = [int(b) for b in os.environ.get("BOXES", "3,3,3,5").split(",")]
+LIBMS = os.environ.get("LIBMS", "glibc,device").split(",")
+off = {(l, m): 0 for l in LIBMS for m in ("strict", "refit")}
+worst = {k: 0.0 for k in off}
+while time.time() < t_end:
+    box = int(rng.choice(BOXES))
+    n = 20000
+    c = box // 2
+    idx = np.arange(box)
+    x0 = c + rng.uniform(-1.2, 1.2, n); y0 = c + rng.uniform(-1.2, 1.2, n)
+    sx = rng.uniform(0.05, 1.2, n); sy = rng.uniform(0.05, 1.2, n)
+    gx = np.exp(-0.5 * ((idx[None] - x0[:, None]) / sx[:, None]) ** 2); gx /= gx.sum(1, keepdims=True) + 1e-30
+    gy = np.exp(-0.5 * ((idx[None] - y0[:, None]) / sy[:, None]) ** 2); gy /= gy.sum(1, keepdims=True) + 1e-30
+    spots = rng.poisson(rng.uniform(20, 9000, n)[:, None, None] * gy[:, :, None] * gx[:, None, :] + rng.uniform(0.05, 60, n)[:, None, None]).astype(np.float32)
+    spots -= np.float32(rng.choice([0.0, 0.0, 3.0]))
+    method = ["sigmaxy", "sigma"][rng.integers(0, 2)]
+    eps = float(rng.choice([1e-3, 1e-3, 1e-4]))
+    max_it = int(rng.choice([100, 100, 1000]))
+    oth, ocr, oll, oit = orc.gaussmle(spots, eps, max_it, method, threads=orc.max_threads())
+    rows += n
+    for libm in LIBMS:
+        be.set_mle_libm(libm)
+        for mode in ("strict", "refit"):
+            be.set_mle_mode(mode)
+            th, cr, ll, it = be.gaussmle_arrays(spots, eps, max_it, method)
+            if mode == "strict":
+                bad = (it != oit) | ~np.all((th == oth) | (np.isnan(th) & np.isnan(oth)), axis=1)
+            else:
+                fin = np.all(np.isfinite(oth), axis=1) & (oit < max_it)
+                d = np.abs(th[:, [0, 1, 4, 5]] - oth[:, [0, 1, 4, 5]]).max(axis=1)
+                bad = (it != oit) | (fin & (d > 1e-3))
+            off[(libm, mode)] += int(bad.sum())
+            if libm == "glibc":
+                for w in np.flatnonzero(bad)[:6]:
+                    print(f"[{mode}] box {box} {method} eps {eps} max_it {max_it}: it {it[w]} / {oit[w]}\n    gpu    {[float(v).hex() for v in th[w]]}\n    oracle {[float(v).hex() for v in oth[w]]}", flush=True)
+                    if dump:
+                        np.savez(os.path.join(dump, f"libm_{mode}_{rows}_{w}.npz"), spots=spots[w:w + 1], box=box, method=method, eps=eps, max_it=max_it,
+                                 theta_gpu=th[w:w + 1], theta_orc=oth[w:w + 1], it_gpu=it[w:w + 1], it_orc=oit[w:w + 1])
+            if bad.any():
+                with np.errstate(invalid="ignore"):
+                    worst[(libm, mode)] = max(worst[(libm, mode)], float(np.nanmax(np.abs(th[bad][:, [0, 1, 4, 5]] - oth[bad][:, [0, 1, 4, 5]]))))
+        be.set_mle_mode("refit")
+    be.set_mle_libm("glibc")
+print(f"rows {rows}")
+for k in off:
+    print(f"  libm {k[0]:6s} mode {k[1]:6s}: {off[k]} rows off the oracle" + (f" (largest difference {worst[k]:.3g} px)" if off[k] else ""))
+sys.exit(1 if off.get(("glibc", "strict")) or off.get(("glibc", "refit")) else 0)

@@ -112,7 +112,6 @@ template <int GS> struct SLds {
     static constexpr int PAIR_PAD = GS == 16 ? 112 : 0;
     static constexpr int NSPW = 64 / GS;
     static constexpr int WAVE_BYTES = NSPW * BYTES + (NSPW / 2) * PAIR_PAD;
-    static_assert(4 * CS * 8 <= TERM, "the plus-boundary records of a group with a coordinate next to zero live in the term array (phase A)");
     static_assert(BYTES % 16 == 0 && PAIR_PAD % 16 == 0 && (BS * 8) % 16 == 0 && (CS * 8) % 16 == 0 && (RS * 8) % 16 == 0, "LDS layout of a group");
     static_assert(GS != 16 || (BYTES + PAIR_PAD) % 256 == 80, "the chain lanes of a pair of groups share a ds_read_b128: rows 0..3 of one beside rows 4..11 of the other");
     // three workgroups of FIT_WAVES wavefronts per CU: 160 KB in granules of 1280 B (with groups a uniform 3408 B apart the
@@ -386,19 +385,21 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
             // phase A: lane -> (axis, boundary k)
             // A coordinate closer to zero than 2^-24 (and not zero) has bits below the last place of k - mu: (k - mu) + 1/2 and
             // ((k + 1) - mu) - 1/2 then round differently, and the plus boundary of pixel k is no longer the minus boundary of
-            // pixel k + 1.  Such a group evaluates the 2 B plus boundaries as records of their own (in the term array, which
-            // is idle until phase C): a centre that sits on the first pixel's middle to 1e-17 px is a fuzzer's spot, but its
-            // bits are the reference's too.
+            // pixel k + 1.  Such a group runs phases A and B twice, for the even and for the odd pixels: in pass p the records
+            // of parity p are minus boundaries and each next one is the plus boundary of ITS pixel, so phase B still reads a
+            // pixel's two boundaries from records i and i + 1.  (A centre that sits on the first pixel's middle to 1e-17 px is
+            // a fuzzer's spot — but its bits are the reference's too.  The groups beside it in the wavefront repeat their pass.)
             const bool split = (th[0] != 0.f && fabsf(th[0]) < 0x1p-24f) || (th[1] != 0.f && fabsf(th[1]) < 0x1p-24f);
-            double *const plus = term;                           // record (a, i) = a * B + i, field q at plus[q * CS + ...]
-            for (int ja = j; ja < 2 * nb + (split ? 2 * B : 0); ja += GS) {      // (one pass unless the group is narrower than 2 (B + 1) lanes)
-                const bool pl = ja >= 2 * nb;
-                const int jr = pl ? ja - 2 * nb : ja;
-                const int a = jr >= (pl ? B : nb) ? 1 : 0, k = jr - a * (pl ? B : nb);
+            const int npass = __any(split) ? 2 : 1;
+            bool rec_ok = true;                                  // the factors of this lane's records are zero or of middling size (shared_div)
+            for (int pass = 0; pass < npass; pass++) {
+            for (int ja = j; ja < 2 * nb; ja += GS) {            // (one pass unless the group is narrower than 2 (B + 1) lanes)
+                const int a = ja >= nb ? 1 : 0, k = ja - a * nb;
                 const double dmu = (double)(a ? th[1] : th[0]);
                 const float sgf = a ? sgy : th[4];
                 const double ds = (double)sgf;
-                const double b = pl ? ((double)k - dmu) + 0.5 : (k < B ? ((double)k - dmu) - 0.5 : ((double)(B - 1) - dmu) + 0.5);
+                const bool plus_rec = split ? ((k & 1) != pass) : (k == B);          // the plus boundary of pixel k - 1
+                const double b = plus_rec ? ((double)(k - 1) - dmu) + 0.5 : ((double)k - dmu) - 0.5;
                 const double sq_norm = 0.70710678118654757 / ds;                     // :276
                 const double t = b / ds;
                 double eA, eD;
@@ -422,27 +423,24 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
                     v2 = ai * ex;                                                    // term of Fx / Fy (:359)
                     v3 = (ai * ex) * (1.0 - 2.0 * (ai * ai));                        // :364-371
                 }
-                double *o = pl ? plus + jr : bnd + jr;                               // record (a, k), field q at o[q * stride]
-                const int os = pl ? CS : BS;
-                o[0] = eA; o[os] = eD; o[2 * os] = v2; o[3 * os] = v3;
+                double *o = bnd + ja;                                                // record (a, k) = a * nb + k, field q at o[q * BS]
+                o[0] = eA; o[BS] = eD; o[2 * BS] = v2; o[3 * BS] = v3;
             }
             lds_sync();
             // phase B: lane -> (axis, pixel index i): PSF, b - a, (d-.5) b - (d+.5) a, sigma terms
-            bool rec_ok = true;                                  // the factors of this lane's records are zero or of middling size (shared_div)
             for (int jb = j; jb < 2 * B; jb += GS) {
                 const int a = jb >= B ? 1 : 0, i = jb - a * B;
                 const double dmu = (double)(a ? th[1] : th[0]);
                 const float sgf = a ? sgy : th[4];
                 const double ds = (double)sgf;
                 const double *mq = bnd + (a * nb + i);                               // minus boundary; the plus boundary is the next record
-                const double *pq = split ? plus + jb : mq + 1;                       // (or a record of its own, see phase A)
-                const int ps = split ? CS : BS;
-                const double m[4] = {mq[0], mq[BS], mq[2 * BS], mq[3 * BS]}, q[4] = {pq[0], pq[ps], pq[2 * ps], pq[3 * ps]};
+                const double m[4] = {mq[0], mq[BS], mq[2 * BS], mq[3 * BS]}, q[4] = {mq[1], mq[BS + 1], mq[2 * BS + 1], mq[3 * BS + 1]};
+                const bool mine = !split || (i & 1) == pass;                         // (a split group: the pixels of this pass's parity)
                 const double d = (double)i - dmu;
                 const double PSF = 0.5 * (q[0] - m[0]);
                 const double bma = m[1] - q[1];
                 const double qq = (d - 0.5) * m[1] - (d + 0.5) * q[1];
-                rec_ok = rec_ok && mid_or_zero(PSF) && mid_or_zero(bma) && mid_or_zero(qq);
+                rec_ok = rec_ok && (!mine || (mid_or_zero(PSF) && mid_or_zero(bma) && mid_or_zero(qq)));
                 double S1, S2;
                 if (NP == 6) {
                     const float s2 = sgf * sgf, s3 = sgf * s2, s5 = sgf * (s2 * s2);   // sigma ** n, float32 (:315)
@@ -460,10 +458,13 @@ __global__ __launch_bounds__(FIT_NT, 3) void mle_strict_kernel(FitParams p, cons
                     S1 = dPSF;
                     S2 = (1.0 / K_SQRT_PI) * ((-F / (double)s2) + (double)sinv * dF);   // :372-374
                 }
-                double *o = col + jb;                                                // record (a, i) = a * B + i
-                o[0] = PSF; o[CS] = bma; o[2 * CS] = qq; o[3 * CS] = S1; o[4 * CS] = S2;
+                if (mine) {
+                    double *o = col + jb;                                            // record (a, i) = a * B + i
+                    o[0] = PSF; o[CS] = bma; o[2 * CS] = qq; o[3 * CS] = S1; o[4 * CS] = S2;
+                }
             }
             lds_sync();
+            }
             // phase C + accumulation, GS pixels of the reference's (ii, jj) sequence per round
             float acc = 0.f;
             const double N_ = (double)th[2], bgd = (double)th[3];

@@ -123,22 +123,21 @@ PMI_LIBM_FN double erf(double x, const uint64_t *tab)
         return hx >= 0 ? pq + 0x1.b0ac160000000p-1 : -0x1.b0ac160000000p-1 - pq;
     }
     if (ix >= 0x40180000) return hx >= 0 ? 1.0 - 0x1.56e1fc2f8f359p-997 : 0x1.56e1fc2f8f359p-997 - 1.0;      // |x| >= 6
-    // 1.25 <= |x| < 6: two coefficient sets, one evaluation tree — the set for |x| >= 1 / 0.35 has one term less in each
-    // polynomial; a zero coefficient in its place leaves every intermediate as it was (0 s - c = -c; t + 0 s^8 = t, t > 0)
-    const bool lo = ix < 0x4006db6e;
+    // 1.25 <= |x| < 6: R / S in 1 / x^2, one coefficient set below 1 / 0.35 and one above (a term less in each polynomial)
     const double s = 1.0 / (x * x), s2 = s * s, s4 = s2 * s2, s6 = s2 * s4;
-    const double ra3 = lo ? -0x1.f300ae4cba38dp+5 : -0x1.4145d43c5ed98p+7, ra2 = lo ? 0x1.51e0441b0e726p+3 : 0x1.1c209555f995ap+4;
-    const double ra1 = lo ? -0x1.63416e4ba7360p-1 : -0x1.993ba70c285dep-1, ra0 = lo ? 0x1.43412600d6435p-7 : 0x1.4341239e86f4ap-7;
-    const double ra5 = lo ? -0x1.7135cebccabb2p+7 : -0x1.004616a2e5992p+10, ra4 = lo ? 0x1.44cb184282266p+7 : 0x1.3ec881375f228p+9;
-    const double ra7 = lo ? -0x1.3a0efc69ac25cp+3 : 0.0, ra6 = lo ? 0x1.4526557e4d2f2p+6 : 0x1.e384e9bdc383fp+8;
-    const double R = (((s * ra3 - ra2) * s2 + (ra1 * s - ra0)) + (ra5 * s - ra4) * s4) + (ra7 * s - ra6) * s6;
-    const double sa3 = lo ? 0x1.b290dd58a1a71p+8 : 0x1.802eb189d5118p+10, sa2 = lo ? 0x1.1350c526ae721p+7 : 0x1.45cae221b9f0ap+8;
-    const double sa1 = lo ? 0x1.3a6b9bd707687p+4 : 0x1.e568b261d5190p+4;
-    const double sa5 = lo ? 0x1.ad02157700314p+8 : 0x1.3f219cedf3be6p+11, sa4 = lo ? 0x1.42b1921ec2868p+9 : 0x1.8ffb7688c246ap+11;
-    const double sa7 = lo ? 0x1.a47ef8e484a93p+2 : -0x1.670e242712d62p+4, sa6 = lo ? 0x1.b28a3ee48ae2cp+6 : 0x1.da874e79fe763p+8;
-    const double sa8 = lo ? -0x1.eeff2ee749a62p-5 : 0.0;
-    const double S12 = s2 * (sa3 * s + sa2) + (sa1 * s + 1.0);
-    const double S = ((s * sa7 + sa6) * s6 + (S12 + (sa5 * s + sa4) * s4)) + (s4 * s4) * sa8;
+    double R, S;
+    if (ix < 0x4006db6e) {
+        R = (((s * -0x1.f300ae4cba38dp+5 - 0x1.51e0441b0e726p+3) * s2 + (-0x1.63416e4ba7360p-1 * s - 0x1.43412600d6435p-7))
+             + (-0x1.7135cebccabb2p+7 * s - 0x1.44cb184282266p+7) * s4) + (-0x1.3a0efc69ac25cp+3 * s - 0x1.4526557e4d2f2p+6) * s6;
+        const double S12 = s2 * (0x1.b290dd58a1a71p+8 * s + 0x1.1350c526ae721p+7) + (0x1.3a6b9bd707687p+4 * s + 1.0);
+        S = ((s * 0x1.a47ef8e484a93p+2 + 0x1.b28a3ee48ae2cp+6) * s6 + (S12 + (0x1.ad02157700314p+8 * s + 0x1.42b1921ec2868p+9) * s4))
+            + (s4 * s4) * -0x1.eeff2ee749a62p-5;
+    } else {
+        R = (((s * -0x1.4145d43c5ed98p+7 - 0x1.1c209555f995ap+4) * s2 + (-0x1.993ba70c285dep-1 * s - 0x1.4341239e86f4ap-7))
+             + (-0x1.004616a2e5992p+10 * s - 0x1.3ec881375f228p+9) * s4) + -0x1.e384e9bdc383fp+8 * s6;
+        const double S12 = s2 * (0x1.802eb189d5118p+10 * s + 0x1.45cae221b9f0ap+8) + (0x1.e568b261d5190p+4 * s + 1.0);
+        S = (s * -0x1.670e242712d62p+4 + 0x1.da874e79fe763p+8) * s6 + (S12 + (0x1.3f219cedf3be6p+11 * s + 0x1.8ffb7688c246ap+11) * s4);
+    }
     const double z = from_bits(to_bits(ax) & 0xffffffff00000000ull);
     const double e1 = exp((-z) * z - 0x1.2000000000000p-1, tab);
     const double e2 = exp((z - ax) * (z + ax) + R / S, tab);

@@ -175,7 +175,7 @@ void release_fft_plans();   // xcorr.hip
 
 extern "C" {
 
-int pmi_version(void) { return 105; }   // 0.1.5: round 6 (same symbols; 32-bit integer movies on the key scan, side lanes per (device, bank))
+int pmi_version(void) { return 106; }   // 0.1.6: round 6 (32-bit integer movies on the key scan, side lanes per (device, bank); + pmi_mle_set_libm / pmi_mle_get_libm / pmi_libm_eval_dev)
 
 const char *pmi_last_error(void) { return pmi::g_err; }
 

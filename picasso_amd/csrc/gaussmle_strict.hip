@@ -22,7 +22,10 @@
 // values (d - 1/2, d + 1/2), so it is evaluated once per boundary (phase A), combined per
 // column / row (phase B) and per pixel (phase C) with the reference's operation order, which
 // gives the same bits as evaluating it B^2 times.  (d + 1/2 of pixel k and d - 1/2 of pixel
-// k + 1 are the same float64 whenever k - mu is exact, i.e. |mu| > 3e-8.)
+// k + 1 are the same float64 whenever k - mu is exact, i.e. |mu| >= 2^-24 or mu = 0; a group
+// with a coordinate in between evaluates the two boundaries of every pixel separately, see
+// `split` in phase A.)  erf and exp themselves are evaluated with the bits of the reference's
+// C library (libm_glibc.h; pmi_mle_set_libm selects the device library's functions instead).
 //
 // Mapping: a group of GS lanes per spot — GS = 16 / 32 / 64 (four / two / one spot per
 // wavefront) for boxes <= 7 / <= 15 / larger, for the flagged-spot list and for PMI_MLE_STRICT

@@ -26,6 +26,7 @@ python3 tools/bench_configs.py --only 5 > $OUT/${TAG}_config5.jsonl 2> $OUT/conf
 python3 tools/rocprof_summary.py /tmp/prof_c5 > $OUT/${TAG}_config5_kernel_stats.txt
 python3 tools/time_mle_eps.py 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_mle_eps.jsonl
 PMI_MLE_MODE=strict bash tools/pmc_first.sh /tmp/pmc_strict_$$ "mle_strict_kernel" python3 tools/ab_defer.py 10000 7 1 1 > $OUT/${TAG}_mle_strict_pmc.txt 2>&1     # every spot in the reference's arithmetic
+PMI_MLE_LIBM=device PMI_MLE_MODE=strict bash tools/pmc_first.sh /tmp/pmc_strict_dev_$$ "mle_strict_kernel" python3 tools/ab_defer.py 10000 7 1 1 > $OUT/${TAG}_mle_strict_device_libm_pmc.txt 2>&1     # ... with the device library's erf / exp
 python3 tools/time_identify_shapes.py 7 2>&1 | grep -v amdgpu.ids > $OUT/${TAG}_identify_shapes.txt
 bash tools/identify_wide_types.sh $OUT/${TAG}_identify_wide_types_now.txt > /dev/null 2>&1
 (for m in refit strict; do for b in 3 5 7 9 11 13 15 21; do PMI_LQ_MODE=$m python3 tools/time_gausslq.py 1048576 $b 2>&1 | grep "^N=" | tail -1 | sed "s/^/[$m] /"; done; done; python3 tools/time_lq_ranges.py 2>&1 | grep -v amdgpu.ids) > $OUT/${TAG}_gausslq_times.txt 2>&1

@@ -137,6 +137,12 @@ enum { FIT_STAGE_NEWTON = 1, FIT_STAGE_FINAL = 2, FIT_STAGE_INIT_ONLY = 4, FIT_S
 // 64 and without it — and at 32 it re-fits healthy fits wherever they are naturally long (eps 1e-4: 6 % of config 2's
 // spots, 5x5 boxes: 30 %).  64 keeps the fits that run into the default max_it among the re-fitted.
 constexpr int FIT_SLOW_ITERATIONS = 64;
+// the margin around eps inside which a tested step flags the spot grows by this per iteration beyond the sixteenth (see the
+// fast kernels; -DPMI_MARGIN_GROWTH=... builds a library for A/B runs)
+#ifndef PMI_MARGIN_GROWTH
+#define PMI_MARGIN_GROWTH 0.0625f
+#endif
+constexpr float FIT_MARGIN_GROWTH = PMI_MARGIN_GROWTH;
 constexpr float FIT_NARROW_SIGMA = 0.5f;      // a fitted width below this (px) sends the spot to the re-fit (0.3 until round 6: 5x5 and
                                               // 7x7 fits of 0.31 ... 0.495 px at eps 1e-4 ended an iteration off the reference, no other flag raised)
 // the alternating component of a parameter's step sequence (second difference) that changes sign without shrinking below

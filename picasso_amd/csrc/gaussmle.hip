@@ -30,7 +30,7 @@ namespace pmi {
 // takes many steps close to eps and the float32 loop drifts from the reference by more than a few ulps)
 __device__ __forceinline__ unsigned borderline(float D, int kk, float eps_lo, float eps_hi)
 {
-    const float wide = fmaxf(1.0f, (float)(kk - 1) * 0.0625f);
+    const float wide = fmaxf(1.0f, (float)(kk - 1) * FIT_MARGIN_GROWTH);
     const float epsf = 0.5f * (eps_lo + eps_hi), epsm = 0.5f * (eps_hi - eps_lo) * wide;
     return ((D >= epsf - epsm && D < epsf + epsm) ? FLAG_MARGIN : 0u) | (kk > FIT_SLOW_ITERATIONS ? FLAG_SLOW : 0u);
 }

@@ -419,7 +419,7 @@ __device__ __forceinline__ bool newton_step(const float (&d)[B], float (&th)[6],
     // (the margin widens with the iteration count: a slow fit takes many steps close to eps and the two arithmetics
     // drift apart by more than a few ulps), and so are spots whose curvature term is not negative for some
     // parameter — the update then runs uphill or into its clamp and the trajectory is chaotic in any arithmetic
-    const float wide = fmaxf(1.0f, (float)kk * 0.0625f);
+    const float wide = fmaxf(1.0f, (float)kk * FIT_MARGIN_GROWTH);
     const float epsf = 0.5f * (eps_lo + eps_hi), epsm = 0.5f * (eps_hi - eps_lo) * wide;
     // ... and spots whose width collapses below a third of a pixel (a single hot pixel in a small box): the likelihood
     // is then flat in the position inside the pixel and the two arithmetics end up to 1e-2 px apart on equal counts

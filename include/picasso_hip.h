@@ -191,12 +191,17 @@ int pmi_mle_get_mode(int *mode, double *margin);
  * it rounds to float32; a fit that does not — 3x3 boxes whose width collapses, fits that wander for a thousand iterations —
  * carries it into another trajectory.  The reference-arithmetic kernel (the re-fit of PMI_MLE_REFIT, every spot of
  * PMI_MLE_STRICT) evaluates the two functions
- *   PMI_LIBM_GLIBC   (default) operation for operation as glibc >= 2.28 on x86-64 with FMA does (the libm of the machines
- *                    the reference runs on, and of the oracle's) — csrc/libm_glibc.h;
- *   PMI_LIBM_DEVICE  with the device library's functions (the behaviour up to round 5; the kernel is 12 - 15 % faster,
- *                    and on 1e6 ordinary 7x7 fits no row differs).
- * Process-wide; the environment variable PMI_MLE_LIBM = glibc | device overrides it.                              */
-enum pmi_libm { PMI_LIBM_DEVICE = 0, PMI_LIBM_GLIBC = 1 };
+ *   PMI_LIBM_GLIBC   operation for operation as glibc >= 2.28 on x86-64 with FMA does (the libm of the machines the
+ *                    reference runs on, and of the oracle's) — csrc/libm_glibc.h; the kernel takes 12 - 18 % longer;
+ *   PMI_LIBM_DEVICE  with the device library's functions (the behaviour up to round 5; on 1e6 ordinary 7x7 fits no row
+ *                    differs);
+ *   PMI_LIBM_AUTO    (default) glibc's bits wherever a result was ever seen to hang on them: every spot of
+ *                    PMI_MLE_STRICT at any box, and the re-fit of PMI_MLE_REFIT on boxes up to 5x5; the device
+ *                    library's in the re-fit of larger boxes, where the default mode's contract (the reference's
+ *                    iteration count on every row, 1e-3 px wherever it converged) has not depended on them in 1e8
+ *                    fuzzed fits and the list's latency is part of the timed step (2 % of config 2's).
+ * Process-wide; the environment variable PMI_MLE_LIBM = auto | glibc | device overrides it.                       */
+enum pmi_libm { PMI_LIBM_DEVICE = 0, PMI_LIBM_GLIBC = 1, PMI_LIBM_AUTO = 2 };
 int pmi_mle_set_libm(int which);
 int pmi_mle_get_libm(int *which);
 /* Diagnostic: d_out[i] = f(d_x[i]) for n float64 device values — fn 0 / 1: exp / erf as the kernel evaluates them under

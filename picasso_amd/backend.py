@@ -151,13 +151,14 @@ def get_mle_mode():
     return {v: k for k, v in MLE_MODES.items()}[m.value], g.value
 
 
-MLE_LIBMS = {"device": 0, "glibc": 1}
+MLE_LIBMS = {"device": 0, "glibc": 1, "auto": 2}
 
 
-def set_mle_libm(which: str = "glibc"):
-    """Whose erf / exp the reference-arithmetic MLE kernel evaluates (pmi_mle_set_libm): "glibc" (default) = the bits of
-    the C library the reference's math.erf / math.exp resolve to under numba (picasso/gaussmle.py:279, 295); "device" =
-    the device library's functions (12 - 15 % faster, another last bit on a few arguments in a hundred)."""
+def set_mle_libm(which: str = "auto"):
+    """Whose erf / exp the reference-arithmetic MLE kernel evaluates (pmi_mle_set_libm): "glibc" = the bits of the C library
+    the reference's math.erf / math.exp resolve to under numba (picasso/gaussmle.py:279, 295), 12 - 18 % slower; "device" = the
+    device library's functions; "auto" (default) = glibc's for every spot of the strict mode and for the re-fit of boxes up
+    to 5x5, the device library's in the re-fit of larger boxes."""
     if which not in MLE_LIBMS:
         raise ValueError(f"unknown libm {which!r}")
     _lib.check(_lib.load().pmi_mle_set_libm(MLE_LIBMS[which]), "pmi_mle_set_libm")

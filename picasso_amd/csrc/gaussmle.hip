@@ -610,8 +610,9 @@ static int build_accept_list(const unsigned char *accept, int64_t first, int64_t
 //   PMI_MLE_STRICT  every spot in the reference's arithmetic
 static int g_mle_mode = PMI_MLE_REFIT;
 static double g_mle_margin = 0.001;
-// erf / exp of the reference-arithmetic kernel (pmi_mle_set_libm): glibc's bits (libm_glibc.h) or the device library's
-static int g_mle_libm = PMI_LIBM_GLIBC;
+// erf / exp of the reference-arithmetic kernel (pmi_mle_set_libm): glibc's bits (libm_glibc.h), the device library's, or
+// glibc's where a result was seen to hang on them (see fit_impl)
+static int g_mle_libm = PMI_LIBM_AUTO;
 // flag statistics of the calling thread's last fit: a device buffer of its own (SCR_STATS of the thread's scratch bank:
 // [0] = spots re-fitted, [1..FLAG_REASONS] = spots flagged per criterion), valid while the scratch generation stands
 static thread_local const unsigned *g_last_stats[2] = {nullptr, nullptr};      // [1]: the second frame range of a fused call
@@ -645,8 +646,9 @@ static int mle_mode_now()
 }
 static int mle_libm_now()
 {
-    static const char *env = getenv("PMI_MLE_LIBM");      // "glibc" | "device" overrides pmi_mle_set_libm
+    static const char *env = getenv("PMI_MLE_LIBM");      // "auto" | "glibc" | "device" overrides pmi_mle_set_libm
     if (env) {
+        if (!strcmp(env, "auto")) return PMI_LIBM_AUTO;
         if (!strcmp(env, "glibc")) return PMI_LIBM_GLIBC;
         if (!strcmp(env, "device")) return PMI_LIBM_DEVICE;
     }
@@ -694,7 +696,11 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
     hipLaunchKernelGGL(zero_words_kernel, dim3(1), dim3(256), 0, s, (unsigned *)ptr, (int)(nb * 10), stats, 16);
     p.flag_reasons = stats + 1;
     p.fisher = (double *)fptr;
-    p.libm_glibc = mle_libm_now() == PMI_LIBM_GLIBC;
+    // erf / exp with glibc's bits: every launch (GLIBC), none (DEVICE), or the all-strict launch at any box and the re-fit
+    // lists of boxes up to 5x5 (AUTO)
+    const int libm = mle_libm_now();
+    const bool libm_all = libm != PMI_LIBM_DEVICE;
+    p.libm_glibc = libm == PMI_LIBM_GLIBC || (libm == PMI_LIBM_AUTO && p.box <= 5);
     static const char *menv = tuning_env("PMI_MLE_MARGIN");       // overrides the margin of pmi_mle_set_mode (tuning runs)
     const double margin = menv ? atof(menv) : g_mle_margin;
     // The tested step |delta| is a difference of float32 coordinates near box/2, i.e. a multiple of their ulp: the
@@ -767,7 +773,9 @@ int fit_impl(FitParams p, int method, bool from_movie, hipStream_t s)
             launch_fit_g8(q, method, false, g_cu_count, state, FIT_STAGE_FINAL, s);
         } else {
         if (mode == PMI_MLE_STRICT) {
-            launch_fit_strict(p, method, from_movie, nullptr, nullptr, count, g_cu_count, s);
+            FitParams ps = p;
+            ps.libm_glibc = libm_all;
+            launch_fit_strict(ps, method, from_movie, nullptr, nullptr, count, g_cu_count, s);
         } else {
             if (g8) launch_fit_g8(p, method, from_movie, g_cu_count, state, FIT_STAGE_NEWTON, s);
             else wave_per_spot(FIT_STAGE_NEWTON);
@@ -918,7 +926,7 @@ int pmi_mle_set_mode(int mode, double margin)
 int pmi_mle_set_libm(int which)
 {
     using namespace pmi;
-    if (which != PMI_LIBM_DEVICE && which != PMI_LIBM_GLIBC) { set_error("unknown libm %d", which); return PMI_ERR_ARG; }
+    if (which != PMI_LIBM_DEVICE && which != PMI_LIBM_GLIBC && which != PMI_LIBM_AUTO) { set_error("unknown libm %d", which); return PMI_ERR_ARG; }
     g_mle_libm = which;
     return PMI_OK;
 }

@@ -166,7 +166,7 @@ def test_fuzz_residuals_are_bounded(be, orc, path):
     try:
         g = be.gaussmle_arrays(spots, eps, max_it, method)
     finally:
-        be.set_mle_libm("glibc")
+        be.set_mle_libm("auto")
     was = np.abs(z["theta_gpu"].astype(np.float64) - z["theta_orc"])[0]
     now = np.abs(g[0].astype(np.float64) - o[0])[0]
     was_it = abs(int(z["it_gpu"][0]) - int(z["it_orc"][0]))

@@ -153,7 +153,7 @@ def test_gaussmle_vs_numba_promotion_goldens(be, name, method):
                 th, cr, ll, it = be.gaussmle_arrays(d["spots"], eps, max_it, method)
             finally:
                 be.set_mle_mode("refit")
-                be.set_mle_libm("glibc")
+                be.set_mle_libm("auto")
             assert np.array_equal(it, git), (name, key, libm)
             same = np.array([np.array_equal(a, b, equal_nan=True) for a, b in zip(th, gth)])
             assert same.all(), (name, key, libm, np.flatnonzero(~same)[:8])

@@ -24,8 +24,9 @@
 // gives the same bits as evaluating it B^2 times.  (d + 1/2 of pixel k and d - 1/2 of pixel
 // k + 1 are the same float64 whenever k - mu is exact, i.e. |mu| >= 2^-24 or mu = 0; a group
 // with a coordinate in between evaluates the two boundaries of every pixel separately, see
-// `split` in phase A.)  erf and exp themselves are evaluated with the bits of the reference's
-// C library (libm_glibc.h; pmi_mle_set_libm selects the device library's functions instead).
+// `split` in phase A.)  erf and exp themselves: with the bits of the reference's C library
+// (libm_glibc.h) or the device library's, per launch (FitParams::libm_glibc; pmi_mle_set_libm:
+// by default glibc's for every spot of the strict mode and in the lists of boxes up to 5x5).
 //
 // Mapping: a group of GS lanes per spot — GS = 16 / 32 / 64 (four / two / one spot per
 // wavefront) for boxes <= 7 / <= 15 / larger, for the flagged-spot list and for PMI_MLE_STRICT

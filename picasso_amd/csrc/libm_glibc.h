@@ -10,6 +10,10 @@
 // (libm.so.6 of glibc 2.35, Ubuntu 22.04; read off its disassembly).  tests/test_libm_glibc.py compiles this header for the
 // host and compares it with the C library's functions on 2e7 arguments, special values and range ends included.
 //
+// (The coefficients are the published ones of those two algorithms — Sun's fdlibm erf, freely distributable, and the exp of
+// Arm's optimized-routines, MIT, which glibc adopted in 2.28 — checked here against the constants inside libm.so.6; the 2 KiB
+// table is generated from its defining formula, tools/gen_glibc_exp_table.py.)
+//
 // Everything here must be compiled WITHOUT contraction (the including file sets `#pragma clang fp contract(off)`; the host
 // test passes -ffp-contract=off); the fused operations are written out.
 #pragma once

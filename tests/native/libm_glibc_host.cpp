@@ -32,8 +32,17 @@ int64_t cmp_erf(const double *x, int64_t n, int64_t *first_bad)
     return bad;
 }
 // the C library's own values, for the device-side comparison (tests/test_gpu_parity.py)
-void ref_exp(const double *x, int64_t n, double *out) { for (int64_t i = 0; i < n; i++) out[i] = ::exp(x[i]); }
-void ref_erf(const double *x, int64_t n, double *out) { for (int64_t i = 0; i < n; i++) out[i] = ::erf(x[i]); }
+// (parallel when built with -fopenmp: tools/libm_device_exhaustive.py)
+void ref_exp(const double *x, int64_t n, double *out)
+{
+#pragma omp parallel for
+    for (int64_t i = 0; i < n; i++) out[i] = ::exp(x[i]);
+}
+void ref_erf(const double *x, int64_t n, double *out)
+{
+#pragma omp parallel for
+    for (int64_t i = 0; i < n; i++) out[i] = ::erf(x[i]);
+}
 double one_exp(double x) { return pmi_glibc::exp(x, k_tab); }
 double one_erf(double x) { return pmi_glibc::erf(x, k_tab); }
 }

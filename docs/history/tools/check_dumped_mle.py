@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """The spots a fuzz run dumped (npz: spots, box, method, eps, max_it) again, strict and default mode, against the oracle.
-usage: python tools/check_dumped_mle.py <dir>"""
+usage: python docs/history/tools/check_dumped_mle.py <dir>"""
 import glob, os, sys
 import numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))))
 from oracle import oracle as orc
 from picasso_amd import backend as be
 

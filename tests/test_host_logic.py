@@ -309,19 +309,19 @@ def test_streamed_scheduler_deals_chunks_over_lanes_in_frame_order():
             self.slots = [None, None]
 
         def bind(self):
-            self.bound.add(threading.get_ident())
+            self.bound.add(threading.current_thread())      # (the Thread object: the OS may hand a finished thread's ident to the next)
 
         def open(self):
-            assert threading.get_ident() in self.bound
+            assert threading.current_thread() in self.bound
             self.opened += 1
 
         def upload(self, k, chunk):
-            assert threading.get_ident() in self.bound and not self.busy[k], "a staging slot was loaded while its chunk ran"
+            assert threading.current_thread() in self.bound and not self.busy[k], "a staging slot was loaded while its chunk ran"
             self.slots[k] = np.array(chunk)
             self.uploads.append((k, int(chunk[0, 0, 0])))
 
         def run(self, k, c0):
-            assert threading.get_ident() in self.bound
+            assert threading.current_thread() in self.bound
             self.busy[k] = True
             time.sleep(self.delay)
             frames = self.slots[k][:, 0, 0].astype(np.uint32)
@@ -356,7 +356,7 @@ def test_streamed_scheduler_deals_chunks_over_lanes_in_frame_order():
     solo = FakeLane(9)
     parts = localize._run_lanes(movie, chunks, [solo])
     assert pd.concat(parts, ignore_index=True)["frame"].tolist() == list(range(F))
-    assert threading.get_ident() not in solo.bound and len(solo.bound) == 2
+    assert threading.current_thread() not in solo.bound and len(solo.bound) == 2
     # abort after the fourth chunk has been handed out: None, every lane closed
     lanes = [FakeLane(0, 0.001), FakeLane(1, 0.001)]
     asked = [0]

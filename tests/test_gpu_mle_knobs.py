@@ -215,6 +215,28 @@ def test_round6_fuzz_finds_carry_the_oracles_bits(be, orc, path):
     assert np.all(np.abs(g[0][fin][:, [0, 1, 4, 5]] - o[0][fin][:, [0, 1, 4, 5]]) <= 1e-3)
 
 
+def test_open_residual_runaway_fit_with_a_cancelling_curvature_term(be, orc):
+    """The one spot the round's last fuzz run left (tests/golden/mle_fuzz_regressions/open): a 7x7 `sigmaxy` fit
+    whose curvature term for sigma_x cancels to 2e-6 of its two sums at the start values — positive in the reference, which then
+    runs away to max_it under its step clamp; negative in the float32 loop, which converges, and no flag asks.  The strict mode
+    must be the reference's bits; the default mode is recorded as an expected failure until the curvature flag looks at the
+    size of the term and not only at its sign."""
+    import os
+    from conftest import GOLDEN
+    z = np.load(os.path.join(GOLDEN, "mle_fuzz_regressions", "open", "mle_6601_1014.npz"))
+    spots, eps, max_it, method = z["spots"], float(z["eps"]), int(z["max_it"]), str(z["method"])
+    o = orc.gaussmle(spots, eps, max_it, method, threads=1)
+    be.set_mle_mode("strict")
+    try:
+        g = be.gaussmle_arrays(spots, eps, max_it, method)
+    finally:
+        be.set_mle_mode("refit")
+    assert np.array_equal(g[3], o[3]) and np.array_equal(g[0], o[0], equal_nan=True)
+    g = be.gaussmle_arrays(spots, eps, max_it, method)
+    if not np.array_equal(g[3], o[3]):
+        pytest.xfail(f"open residual (DESIGN.md 10.8): {int(g[3][0])} iterations against the reference's {int(o[3][0])}")
+
+
 @pytest.mark.parametrize("box,n,groups", [(7, 120000, 12288), (13, 40000, 6144)])
 def test_refit_lists_longer_than_one_round_of_the_refit_kernel(be, orc, box, n, groups):
     """The re-fit kernel deals the first `groups` entries of its list to its lane groups and hands the rest out through a
